@@ -1,0 +1,24 @@
+"""Case tables shared by the golden generator (tools/gen_golden.py) and the tests."""
+import numpy as np
+import torch
+
+NET_CASES = [
+    ("cfg1_64x64_x2", 64, 64, (2, 2)),
+    ("odd_17x21_x1p5_4", 17, 21, (1.5, 4)),
+    ("s12x14_x3p7", 12, 14, (3.7, 3.7)),
+    ("s13x16_x4", 13, 16, (4, 4)),
+    ("s16x20_x3p5_2", 16, 20, (3.5, 2)),
+]
+SATU_CASES = [("x4", 6, 7, (4, 4)), ("x1p5_4", 7, 6, (1.5, 4)), ("x3p7", 5, 6, (3.7, 3.7)),
+              ("x2p95_3p75", 6, 5, (2.95, 3.75))]
+OSCONV_CASES = [("c192", "f2p_win.blocks.1.osconv", 192), ("c320", "h_win.0.blocks.0.osconv", 320),
+                ("c64", "adapt.2.adapt", 64)]
+OSCONV_SCALES = [(4, 4), (1.5, 4), (3.7, 3.7)]
+YAML_SCALES = [(round(4.0 - 0.1 * i, 1),) * 2 for i in range(30)] + [
+    (1.5, 4), (2, 4), (2, 3.75), (1.5, 3.5), (1.6, 3.05), (1.7, 3.75),
+    (2.95, 3.75), (3.9, 2), (3.5, 1.5), (3.5, 2), (3.5, 1.75), (4, 1.4)]
+GRID_SIZES = [(180, 320), (135, 239), (144, 176)]
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy((scale * np.random.RandomState(seed).standard_normal(shape)).astype(np.float32))

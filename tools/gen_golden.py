@@ -1,0 +1,107 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE arch here.
+
+Build-container only (needs /root/reference).  Everything written is data: outputs of the
+reference's own `SAVSR`, `OSConv2d`, `OSAdapt`, `STAUpsample` modules on key-seeded weights
+(savsr_amd/utils/synth.py) and numpy-RandomState inputs that any machine can regenerate, plus
+the integer LR index grids / output sizes for every scale in options/test/SAVSR/*.yml.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_import  # noqa: E402
+from savsr_amd.utils import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# (h, w, scale) full-network cases; all full width (num_feat 64, default depth)
+NET_CASES = [
+    ("cfg1_64x64_x2", 64, 64, (2, 2)),          # BASELINE config 1
+    ("odd_17x21_x1p5_4", 17, 21, (1.5, 4)),     # odd sizes -> reflect pad path, asymmetric scale
+    ("s12x14_x3p7", 12, 14, (3.7, 3.7)),        # non-integer symmetric scale
+    ("s13x16_x4", 13, 16, (4, 4)),              # odd height, integer scale
+    ("s16x20_x3p5_2", 16, 20, (3.5, 2)),        # asymmetric, h-scale > w-scale
+]
+SATU_CASES = [("x4", 6, 7, (4, 4)), ("x1p5_4", 7, 6, (1.5, 4)), ("x3p7", 5, 6, (3.7, 3.7)), ("x2p95_3p75", 6, 5, (2.95, 3.75))]
+
+YAML_SCALES = [(round(4.0 - 0.1 * i, 1),) * 2 for i in range(30)] + [
+    (1.5, 4), (2, 4), (2, 3.75), (1.5, 3.5), (1.6, 3.05), (1.7, 3.75),
+    (2.95, 3.75), (3.9, 2), (3.5, 1.5), (3.5, 2), (3.5, 1.75), (4, 1.4)]
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy((scale * np.random.RandomState(seed).standard_normal(shape)).astype(np.float32))
+
+
+def main():
+    torch.set_num_threads(8)
+    ref = ref_import.load_reference_arch()
+    net = ref.SAVSR().eval()
+    manifest = synth.manifest_of(net.state_dict())
+    with open(os.path.join(GOLD, "state_manifest.json"), "w") as f:
+        json.dump(manifest, f)
+    sd = synth.synth_state_dict(manifest, seed=0)
+    net.load_state_dict(sd, strict=True)
+
+    out = {}
+    with torch.no_grad():
+        # ---- whole network -------------------------------------------------------------
+        for name, h, w, sc in NET_CASES:
+            lq = synth.synth_clip(7, 3, h, w, seed=0)
+            net.set_scale(sc)
+            grabbed = {}
+            hk = net.upsample.register_forward_hook(lambda m, i, o: grabbed.__setitem__("satu", o))
+            sr = net(lq)
+            hk.remove()
+            out[f"net/{name}/sr"] = sr.numpy()
+            # strided sample of the SATU output (64 channels at HR) keeps the fixture small
+            out[f"net/{name}/satu_s"] = grabbed["satu"][:, ::4, ::3, ::3].contiguous().numpy()
+            print(name, tuple(sr.shape), float(sr.abs().max()))
+        # ---- OSConv2d (Cin 192 / 320 / 64 instances) ----------------------------------------
+        for tag, mod, cin in [("c192", net.f2p_win.blocks[1].osconv, 192), ("c320", net.h_win[0].blocks[0].osconv, 320),
+                              ("c64", net.adapt[2].adapt, 64)]:
+            for sc in [(4, 4), (1.5, 4), (3.7, 3.7)]:
+                x = rnd((1, cin, 10, 12), 11 + cin, 0.7)
+                y = mod(x, sc)
+                out[f"osconv/{tag}/{sc[0]}_{sc[1]}"] = y.numpy()
+        # batch 2 (groups = b path, savsr_arch.py:166-167)
+        x = rnd((2, 192, 6, 8), 77, 0.7)
+        out["osconv/c192_b2/4_4"] = net.p2f_win.blocks[2].osconv(x, (4, 4)).numpy()
+        # ---- OSAdapt ----------------------------------------------------------------------
+        x = rnd((1, 64, 10, 12), 5, 0.8)
+        out["osadapt/a1/2.5_2.5"] = net.adapt[1](x, (2.5, 2.5)).numpy()
+        # ---- STAUpsample --------------------------------------------------------------------
+        for tag, h, w, sc in SATU_CASES:
+            x = rnd((1, 64, h, w), 21, 1.0)
+            st = rnd((1, 64, h, w), 22, 0.6)
+            y = net.upsample(x, sc, st)
+            out[f"satu/{tag}/out"] = y.numpy()
+            kw = net.upsample.kernel_conv(st)
+            out[f"satu/{tag}/sta"] = net.upsample.sta_conv(x, kw).numpy()
+        # ---- integer grids + output sizes for every YAML scale at 180x320 and odd sizes --------
+        for sc in YAML_SCALES:
+            for (h, w) in [(180, 320), (135, 239), (144, 176)]:
+                H, W = ref.get_HW(h, w, sc)
+                ys = torch.arange(0, H, 1).float()
+                xs = torch.arange(0, W, 1).float()
+                fh = torch.floor((ys + 0.5) / sc[0] + 1e-3)
+                fw = torch.floor((xs + 0.5) / sc[1] + 1e-3)
+                key = f"grid/{sc[0]}_{sc[1]}/{h}x{w}"
+                out[key + "/HW"] = np.array([H, W], dtype=np.int32)
+                out[key + "/fh"] = fh.numpy().astype(np.int16)
+                out[key + "/fw"] = fw.numpy().astype(np.int16)
+    np.savez_compressed(os.path.join(GOLD, "reference_outputs.npz"), **out)
+    sz = os.path.getsize(os.path.join(GOLD, "reference_outputs.npz"))
+    print("wrote", len(out), "arrays,", sz / 1e6, "MB")
+
+
+if __name__ == "__main__":
+    main()
