@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""SAVSR hot-path benchmark on MI355X: HR Mpixels/s on synthetic 7x3x180x320 -> 720x1280 clips.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (SAVSR.forward, BASELINE config 2) over one synthetic clip
+already resident in HBM = one 720x1280 output frame.  Clips are independent, so for N > 1 every
+rank runs its own K clips (weak scaling, no data-path collective); the only collective is one
+RCCL all_gather of the per-frame [PSNR-Y, checksum] rows, as the reference reduces its metric
+tensor once per dataset (video_base_model.py:108-113).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+LR_H, LR_W, SCALE = 180, 320, (4, 4)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(sd, threads):
+    """Oracle (CPU restatement of the reference path, kind='port') on a bounded sample: one frame of a
+    quarter-area crop (7x3x90x160, x4 -> 360x640) of the workload clip."""
+    from oracle import savsr_oracle as O
+    from savsr_amd.utils import synth
+    torch.set_num_threads(threads)
+    lq = synth.synth_clip(7, 3, LR_H, LR_W, seed=0)[..., :90, :160].contiguous()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        out = O.forward(sd, lq, SCALE)
+        dt = time.perf_counter() - t0
+    hr_px = out.shape[-1] * out.shape[-2]
+    return {"value": round(hr_px / dt / 1e6, 5), "unit": "HR Mpixel/s", "cores": threads, "kind": "port",
+            "sample": f"1 frame, oracle/savsr_oracle.py on a 7x3x90x160 crop (x4 -> 360x640) of the workload clip, {dt:.2f} s"}, out, lq
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)    # RCCL over xGMI
+
+    import savsr_amd
+    from savsr_amd.metrics import calculate_psnr, tensor2img
+    from savsr_amd.utils import synth
+
+    sd = synth.synth_state_dict(seed=0)                   # random-init weights of the full architecture
+    net = savsr_amd.build_network(dict(type="SAVSR", num_in_ch=3, num_feat=64, num_frame=7, slid_win=3, fusion_win=5,
+                                       interval=0, w1_num_block=4, w2_num_block=2, n_resgroups=4, n_resblocks=8,
+                                       center_frame_idx=None)).eval()
+    net.load_state_dict(sd, strict=True)
+    net.to(dev)
+    net.set_scale(SCALE)
+    eng = net.engine()
+    H, W = LR_H * SCALE[0], LR_W * SCALE[1]
+
+    # distinct clips per rank and per step, resident in HBM before the timed region
+    n_clips = min(args.steps, 4)
+    clips = [synth.synth_clip(7, 3, LR_H, LR_W, seed=100 * rank + i).to(dev) for i in range(n_clips)]
+    gt = synth.synth_gt(3, H, W, seed=0)
+
+    for i in range(args.warmup):
+        net(clips[i % n_clips])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    eng.satu_events = []          # HIP events on the launch stream around the SATU launches
+    rows = torch.zeros(args.steps, 2, device=dev)
+    t0 = time.perf_counter()
+    out = None
+    for i in range(args.steps):
+        out = net(clips[i % n_clips])
+        rows[i, 0] = out.sum()    # device-side checksum; PSNR of the last frame is computed after timing
+    if dist is not None:
+        gathered = torch.empty(world * args.steps, 2, device=dev)
+        dist.all_gather_into_tensor(gathered, rows)
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    satu_ms = [a.elapsed_time(b) for a, b in eng.satu_events]
+    eng.satu_events = None
+
+    if rank == 0:
+        hr_mpx = H * W / 1e6
+        value = world * args.steps * hr_mpx / elapsed
+        satu_avg_s = (sum(satu_ms) / len(satu_ms)) / 1e3
+        alg_bytes = 4 * 64 * (2 * LR_H * LR_W + H * W)        # read x, st once + write out once
+        achieved = alg_bytes / satu_avg_s / 1e9
+        psnr = calculate_psnr(tensor2img(out[0].cpu()), tensor2img(gt), 0, test_y_channel=True)
+        line = {
+            "metric": "HR Mpixels/sec (Vid4-shape x4, 7-frame window)", "value": round(value, 3), "unit": "HR Mpixel/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: synthetic 7x3x180x320 clips, scale x4 -> 720x1280, key-seeded random-init weights",
+                       "frames_per_step": 1, "parallelism": f"clip-sharded dp{world}"},
+            "psnr_y_vs_synthetic_gt": round(float(psnr), 4),
+            "roofline": {"kernel": "SATU (phase table + LR stage + HR upsample)", "bound": "hbm", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes": alg_bytes, "avg_ms": round(1e3 * satu_avg_s, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            cb, ref, lq_c = cpu_baseline(sd, threads)
+            got = net(lq_c.to(dev))
+            cb["gpu_vs_oracle_max_abs_on_sample"] = float((got.cpu() - ref).abs().max())
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

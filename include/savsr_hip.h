@@ -1,0 +1,192 @@
+/*
+ * savsr_hip.h -- C ABI of libsavsr_hip.so, the MI355X (gfx950) kernel library behind
+ * savsr_amd.archs.savsr_arch.SAVSR.forward().
+ *
+ * The reference (Weepingchestnut/SAVSR) has no native code on this path: every step of
+ * lbasicsr/archs/savsr_arch.py is an un-fused ATen call.  Each entry point below therefore cites
+ * the reference Python lines whose arithmetic it replaces, not a reference FFI symbol.
+ *
+ * Conventions:
+ *   - plain C, raw DEVICE pointers + explicit int shapes/strides (in floats) + a hipStream_t
+ *     passed as void*; no torch types anywhere in this file;
+ *   - every call only ENQUEUES work on the caller's stream: no allocation, no host sync, no
+ *     global mutable state => re-entrant across streams/threads and hipGraph-capturable;
+ *   - return 0 = ok, <0 = invalid argument (SAVSR_E_*), >0 = hipError_t of the failed launch;
+ *     the message is available from savsr_last_error() (thread-local);
+ *   - all tensors fp32, channel-planar ([C][h][w]) unless stated otherwise;
+ *   - output sizes H, W are computed by the CALLER with Python round() so that get_HW
+ *     (savsr_arch.py:745-751) stays bit-exact.
+ */
+#ifndef SAVSR_HIP_H
+#define SAVSR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAVSR_ABI_VERSION 1
+
+#define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
+#define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
+
+/* activation codes for the conv epilogue */
+#define SAVSR_ACT_NONE    0
+#define SAVSR_ACT_RELU    1
+#define SAVSR_ACT_LRELU   2   /* slope in savsr_conv_desc.slope (0.2 in propagation, savsr_arch.py:426) */
+#define SAVSR_ACT_SIGMOID 3
+
+#define SAVSR_MAX_SRC 5
+
+const char* savsr_version(void);
+const char* savsr_last_error(void);
+int savsr_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense conv (3x3 pad 1, or 1x1), stride 1, as an fp32-MFMA implicit GEMM with a fused
+ * epilogue.  Replaces every nn.Conv2d / F.conv2d on the path:
+ *   WindowUnit_l1/l2 convs   savsr_arch.py:429-442,456-462,480-483,488,498
+ *   ResidualBlock convs      savsr_arch.py:388-397,402-415  (cat-free: the `torch.cat` inputs
+ *                            of :404,:412,:462,:498,:721 are passed as separate sources)
+ *   OSConv2d dynamic conv    savsr_arch.py:156-171 (weights produced on device by
+ *                            savsr_osconv_aggregate; gates folded into the weights, :148-149)
+ *   OSAdapt mask convs       savsr_arch.py:189-206 (eval BatchNorm folded by the caller)
+ *   RCAB / ResidualGroup     savsr_arch.py:541-543,567, conv_last :733, h_win_conv_h :723
+ *
+ *   y   = act( sum_{src,ci,ky,kx} W[co][ci][ky][kx] * in[ci](y+ky-p, x+kx-p) + bias[co] )
+ *   out = y * (mul_px ? mul_px[y][x] : 1) + (res1 ? res1[co][y][x] : 0)
+ *                                         + (res2 ? res2_scale * res2[co][y][x] : 0)
+ * Zero padding outside [0,h) x [0,w).  The input channel axis is the concatenation of
+ * `nsrc` sources of `src_ch` channels each.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct savsr_conv_desc {
+    const float* src[SAVSR_MAX_SRC];   /* device pointers, each [src_ch][h][w] with the strides below */
+    int64_t      src_plane[SAVSR_MAX_SRC]; /* floats between channels */
+    int32_t      src_row[SAVSR_MAX_SRC];   /* floats between rows     */
+    int32_t      nsrc;
+    int32_t      src_ch;
+    int32_t      h, w;
+    int32_t      cin;                  /* = nsrc * src_ch */
+    int32_t      cout;
+    int32_t      ksize;                /* 1 or 3 */
+    const float* wpacked;              /* device; layout of savsr_conv_packed_floats()/pack_index() */
+    const float* bias;                 /* [cout] or NULL */
+    int32_t      act;
+    float        slope;
+    const float* mul_px;               /* [h][w] (row stride w) or NULL   -- OSAdapt mask, :214 */
+    const float* res1;                 /* [cout][h][w] or NULL, strides = out strides            */
+    const float* res2;                 /* [cout][h][w] or NULL, strides = out strides            */
+    float        res2_scale;           /* gamma (savsr_arch.py:732)                              */
+    float*       out;                  /* [cout][h][w] */
+    int64_t      out_plane;
+    int32_t      out_row;
+} savsr_conv_desc;
+
+/* Number of floats of the packed weight buffer for a (cout, cin, ksize) conv. */
+int64_t savsr_conv_packed_floats(int cout, int cin, int ksize);
+/* Index into the packed buffer of W[co][ci][ky*ksize+kx]; entries never addressed are padding
+ * and must be zero.  (Host helper; the Python side packs with the same formula.) */
+int64_t savsr_conv_pack_index(int cout, int cin, int ksize, int co, int ci, int tap);
+int savsr_conv2d(const savsr_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-channel spatial mean over the concatenation of sources:  AdaptiveAvgPool2d(1)
+ * (savsr_arch.py:129,146 for OSConv; :515 for RCAN ChannelAttention).  mean: [nsrc*src_ch].
+ * ------------------------------------------------------------------------------------------ */
+int savsr_channel_mean(const float* const* src, const int64_t* src_plane, const int32_t* src_row,
+                       int nsrc, int src_ch, int h, int w, float* mean, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * OSConv scale routing + ScaleAttention (savsr_arch.py:143-151, 91-96, 69-89):
+ *   v  = ReLU(L2 ReLU(L1 [1/sh, 1/sw, mean] + c1) + c2)
+ *   a  = ReLU(bn_scale * (Wfc v) + bn_shift)            (eval BatchNorm folded by the caller)
+ *   att = [ ca = sigmoid(Wc a + bc) (cin) | fa = sigmoid(Wf a + bf) (cout) |
+ *           sa = sigmoid(Ws a + bs) (9)   | ka = softmax(Wk a + bk) (knum) ]
+ * ------------------------------------------------------------------------------------------ */
+typedef struct savsr_osconv_attn_desc {
+    int32_t cin, cout, hidden /* A */, knum /* 8 */;
+    float   inv_sh, inv_sw;
+    const float* mean;                       /* [cin] */
+    const float* l1_w; const float* l1_b;    /* [2cin][cin+2], [2cin] */
+    const float* l2_w; const float* l2_b;    /* [cin][2cin],   [cin]  */
+    const float* fc_w;                       /* [A][cin] */
+    const float* bn_scale; const float* bn_shift; /* [A] */
+    const float* ch_w; const float* ch_b;    /* [cin][A],  [cin]  */
+    const float* fl_w; const float* fl_b;    /* [cout][A], [cout] */
+    const float* sp_w; const float* sp_b;    /* [9][A],    [9]    */
+    const float* kn_w; const float* kn_b;    /* [knum][A], [knum] */
+    float* att;                              /* [cin + cout + 9 + knum] */
+} savsr_osconv_attn_desc;
+int savsr_osconv_attention(const savsr_osconv_attn_desc* d, void* stream);
+
+/* W''[co][ci][tap] = fa[co] * ca[ci] * sa[tap] * sum_k ka[k] * W[k][co][ci][tap]
+ * (savsr_arch.py:156-163,171 folded, :148-149), produced directly in the packed conv layout.
+ * bank_packed: [knum][savsr_conv_packed_floats(cout,cin,3)], each kernel packed like a conv. */
+int savsr_osconv_aggregate(const float* bank_packed, const float* att, int cin, int cout, int knum,
+                           float* wpacked_out, void* stream);
+
+/* RCAN ChannelAttention gate (savsr_arch.py:514-520): gate = sigmoid(W2 ReLU(W1 mean + b1) + b2) */
+int savsr_se_gate(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2,
+                  int c, int cmid, float* gate, void* stream);
+/* out = r * gate[c] + x   (savsr_arch.py:524,548-549); contiguous [c][n] */
+int savsr_scale_residual(const float* r, const float* gate, const float* x, float* out,
+                         int c, int64_t n, void* stream);
+
+/* nn.AvgPool2d(2) (savsr_arch.py:193): [c][h][w] -> [c][h/2][w/2], h and w even, contiguous. */
+int savsr_avgpool2(const float* in, float* out, int c, int h, int w, void* stream);
+/* nn.Upsample(scale_factor=2, bilinear, align_corners=False) (savsr_arch.py:202). */
+int savsr_upsample2x(const float* in, float* out, int c, int h, int w, void* stream);
+/* SAVSR.pad_spatial (savsr_arch.py:670-690): reflect-pad right/bottom; n planes [h][w]->[hp][wp]. */
+int savsr_reflect_pad(const float* in, float* out, int n, int h, int w, int hp, int wp, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SATU = STAUpsample.forward (savsr_arch.py:315-376), restructured:
+ *   out = G(Wa sta, soff) + G(Wb x, off) + sum_n r_n (Wb E_n) (sum_m r_m C_m G(x, off)) + b
+ * in three launches:
+ *   savsr_satu_phase_table : coordinate MLP (:344-350) on the DISTINCT (coor_h, coor_w) values
+ *   savsr_satu_lr_stage    : kernel_conv + LeakyReLU(0.1) + sta_conv (:226-228,297-313,319-320)
+ *                            and the three LR-side projections -> LRcat [h][w][160]
+ *   savsr_satu_hr_upsample : bilinear gathers (:262-295), expert mixing (:353-370), fusion (:374)
+ * ------------------------------------------------------------------------------------------ */
+#define SAVSR_SATU_C      64
+#define SAVSR_SATU_LRCAT  160
+#define SAVSR_SATU_TABLE  8    /* r0 r1 r2 r3 off_x off_y soff_x soff_y */
+
+typedef struct savsr_satu_weights {      /* all device pointers; packed by the caller */
+    const float* body0_w; const float* body0_b;   /* [64][4], [64]   savsr_arch.py:245 */
+    const float* body2_w; const float* body2_b;   /* [64][64], [64]  :247 */
+    const float* head_w;  const float* head_b;    /* [8][64], [8]: routing(4) | offset(2) | st_offset(2)  :252,256,257 */
+    const float* kconv_w; const float* kconv_b;   /* packed [25][2][32 ks][64 lanes], [25][64]  :227 */
+    const float* proj_w;                          /* packed LR projections (Wa | Wb | C-stack) */
+    const float* wbe_w;                           /* packed (Wb E_n): [2][16][64 lanes]        */
+    const float* fusion_b;                        /* [64] :260 */
+} savsr_satu_weights;
+
+/* table[uh][uw][8] for uh < n_uh, uw < n_uw.  uniq_ch/uniq_cw are the distinct fp32 values of
+ * coor_h/coor_w (savsr_arch.py:331-333) computed by the caller; inv_sw, inv_sh are 1/scale. */
+int savsr_satu_phase_table(const savsr_satu_weights* wt, const float* uniq_ch, int n_uh,
+                           const float* uniq_cw, int n_uw, float inv_sw, float inv_sh,
+                           float* table, void* stream);
+
+/* x, st: [64][h][w] with the given strides (crops of padded tensors, savsr_arch.py:737). */
+int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const float* st,
+                        int64_t plane, int32_t row, int h, int w, float* lrcat, void* stream);
+
+/* gxn[W], gyn[H]: normalised base grid coordinates (savsr_arch.py:270-280) computed by the caller
+ * in fp32; idx_h[H], idx_w[W]: index of each row/column's (coor_h, coor_w) value in the table.
+ * out: [64][H][W] contiguous. */
+int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w,
+                           const float* table, int n_uw, const int32_t* idx_h, const int32_t* idx_w,
+                           const float* gyn, const float* gxn, int H, int W, float* out, void* stream);
+
+/* tail conv 3x3 64->3 + bias at HR plus the bilinear residual of the (unpadded) centre frame
+ * (savsr_arch.py:738-739).  feat: [64][H][W]; center: [3][h][w]; out: [3][H][W]; all contiguous. */
+int savsr_tail_residual(const float* feat, const float* tail_w /* [3][64][3][3] */, const float* tail_b,
+                        const float* center, int h, int w, int H, int W, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAVSR_HIP_H */

@@ -1,0 +1,120 @@
+"""ctypes binding of libsavsr_hip.so (the C ABI declared in include/savsr_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol cannot be
+resolved, importing the kernels raises.  The product path never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsavsr_hip.so")
+
+MAX_SRC = 5
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+SATU_LRCAT = 160
+SATU_TABLE = 8
+
+fptr = C.c_void_p   # raw device pointers travel as integers
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("src", fptr * MAX_SRC),
+        ("src_plane", C.c_int64 * MAX_SRC),
+        ("src_row", C.c_int32 * MAX_SRC),
+        ("nsrc", C.c_int32), ("src_ch", C.c_int32),
+        ("h", C.c_int32), ("w", C.c_int32),
+        ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32),
+        ("wpacked", fptr), ("bias", fptr),
+        ("act", C.c_int32), ("slope", C.c_float),
+        ("mul_px", fptr), ("res1", fptr), ("res2", fptr), ("res2_scale", C.c_float),
+        ("out", fptr), ("out_plane", C.c_int64), ("out_row", C.c_int32),
+    ]
+
+
+class OSConvAttnDesc(C.Structure):
+    _fields_ = [
+        ("cin", C.c_int32), ("cout", C.c_int32), ("hidden", C.c_int32), ("knum", C.c_int32),
+        ("inv_sh", C.c_float), ("inv_sw", C.c_float),
+        ("mean", fptr),
+        ("l1_w", fptr), ("l1_b", fptr), ("l2_w", fptr), ("l2_b", fptr),
+        ("fc_w", fptr), ("bn_scale", fptr), ("bn_shift", fptr),
+        ("ch_w", fptr), ("ch_b", fptr), ("fl_w", fptr), ("fl_b", fptr),
+        ("sp_w", fptr), ("sp_b", fptr), ("kn_w", fptr), ("kn_b", fptr),
+        ("att", fptr),
+    ]
+
+
+class SatuWeights(C.Structure):
+    _fields_ = [
+        ("body0_w", fptr), ("body0_b", fptr), ("body2_w", fptr), ("body2_b", fptr),
+        ("head_w", fptr), ("head_b", fptr), ("kconv_w", fptr), ("kconv_b", fptr),
+        ("proj_w", fptr), ("wbe_w", fptr), ("fusion_b", fptr),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/savsr_hip.h declares
+SIGNATURES = {
+    "savsr_version": (C.c_char_p, []),
+    "savsr_last_error": (C.c_char_p, []),
+    "savsr_abi_version": (C.c_int, []),
+    "savsr_conv_packed_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "savsr_conv_pack_index": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "savsr_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "savsr_channel_mean": (C.c_int, [C.POINTER(fptr), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                     C.c_int, C.c_int, fptr, C.c_void_p]),
+    "savsr_osconv_attention": (C.c_int, [C.POINTER(OSConvAttnDesc), C.c_void_p]),
+    "savsr_osconv_aggregate": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
+    "savsr_se_gate": (C.c_int, [fptr, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, C.c_void_p]),
+    "savsr_scale_residual": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int64, C.c_void_p]),
+    "savsr_avgpool2": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "savsr_upsample2x": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "savsr_reflect_pad": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "savsr_satu_phase_table": (C.c_int, [C.POINTER(SatuWeights), fptr, C.c_int, fptr, C.c_int, C.c_float, C.c_float,
+                                         fptr, C.c_void_p]),
+    "savsr_satu_lr_stage": (C.c_int, [C.POINTER(SatuWeights), fptr, fptr, C.c_int64, C.c_int32, C.c_int, C.c_int,
+                                      fptr, C.c_void_p]),
+    "savsr_satu_hr_upsample": (C.c_int, [C.POINTER(SatuWeights), fptr, C.c_int, C.c_int, fptr, C.c_int, fptr, fptr,
+                                         fptr, fptr, C.c_int, C.c_int, fptr, C.c_void_p]),
+    "savsr_tail_residual": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libsavsr_hip.so and bind every symbol; raises HipLibraryError on any problem."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  savsr_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.savsr_abi_version() != 1:
+        raise HipLibraryError("libsavsr_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().savsr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,396 @@
+// SATU -- Spatio-temporal Adaptive arbitrary-scale Upsampling (STAUpsample.forward,
+// savsr_arch.py:315-376), restructured for gfx950 (derivation in DESIGN.md):
+//
+//   out = G(Wa sta, soff) + G(Wb x, off) + sum_n r_n (Wb E_n) ( sum_m r_m C_m G(x, off) ) + b
+//
+//   * the coordinate MLP only depends on (coor_h[Y], coor_w[X])  -> evaluated once per DISTINCT
+//     pair (phase table), not once per HR pixel;
+//   * the 1x1 `fusion` and the expert `compress` matrices commute with the bilinear gather G
+//     -> applied at LR resolution (LR stage), so the HR stage only gathers 160 LR channels,
+//     mixes 32 numbers and runs a K=32 MFMA per pixel;
+//   * nothing of the reference's 3.5 GB of per-pixel expert weights / 369 MB kernel tensor /
+//     369 MB unfolded features ever exists.
+//
+// Record layout of the LR-side tensor LRcat[h][w][160] (one 640-B record per LR pixel):
+//   half hh in {0,1} (= MFMA lane half) owns floats [80*hh, 80*hh+80):
+//     [ 0,32)  (Wa sta)[co]   at q = 16 t + r  <->  co = 32 t + acc_row(r, hh)
+//     [32,64)  (Wb x)[co]     same q
+//     [64,80)  (C_m x)[j]     at r = 4 m + jj  <->  j = 2 jj + hh
+//   i.e. exactly the 32x32 MFMA accumulator layout of the lane that produced it (LR stage) and
+//   of the lane that consumes it (HR stage): no cross-lane movement on either side.
+#include "common.hpp"
+
+namespace savsr {
+
+constexpr int C = SAVSR_SATU_C;            // 64
+constexpr int REC = SAVSR_SATU_LRCAT;      // 160
+constexpr int HREC = REC / 2;              // 80
+
+// ------------------------------------------------------------------------------------------
+// Phase table: one wave per distinct (coor_h, coor_w) pair; lane j owns hidden unit j.
+// savsr_arch.py:335-350 (body, offset, st_offset, routing).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void satu_phase_table_kernel(const savsr_satu_weights wt, const float* __restrict__ uniq_ch, int n_uh,
+                                                               const float* __restrict__ uniq_cw, int n_uw, float inv_sw, float inv_sh,
+                                                               float* __restrict__ table) {
+    const int lane = threadIdx.x & 63;
+    const long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= (long long)n_uh * n_uw) return;
+    const int uh = (int)(e / n_uw), uw = (int)(e - (long long)uh * n_uw);
+    const float in0 = inv_sw, in1 = inv_sh, in2 = uniq_ch[uh], in3 = uniq_cw[uw];   // :336-339 (w before h)
+    const float* w0 = wt.body0_w + lane * 4;
+    float h1 = wt.body0_b[lane] + w0[0] * in0 + w0[1] * in1 + w0[2] * in2 + w0[3] * in3;
+    h1 = fmaxf(h1, 0.f);
+    float h2 = wt.body2_b[lane];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h1), i));
+        h2 += wt.body2_w[i * 64 + lane] * hi;          // body2_w is stored [in][out]
+    }
+    h2 = fmaxf(h2, 0.f);
+#pragma unroll
+    for (int o = 0; o < SAVSR_SATU_TABLE; ++o) {
+        float v = wave_sum(wt.head_w[o * 64 + lane] * h2) + wt.head_b[o];
+        if (o < 4) v = sigmoidf_(v);                    // routing is sigmoid, not softmax (:253)
+        if (lane == 0) table[e * SAVSR_SATU_TABLE + o] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LR stage.  Block = 4 waves = 4 rows x 32 cols of LR pixels; wave w owns row w.
+//   K[n][px]   = LReLU_0.1( Wk[n][:] . st[:, px] + bk[n] ),  n = 25 c + tap       (:226-228,319)
+//   sta[c][px] = sum_tap K[25c+tap][px] * x_rep[c][y+ky-2][x+kx-2]                (:297-313)
+// as 50 (tap, channel-group) GEMM tiles of 32 rows x 32 px x K=64 on v_mfma_f32_32x32x2_f32;
+// the K tile never leaves the accumulator registers.  Then the three LR-side projections
+// (Wa sta | Wb x | C x) with sta consumed straight from its accumulator registers.
+// ------------------------------------------------------------------------------------------
+struct LrParams {
+    savsr_satu_weights wt;
+    const float* x;
+    const float* st;
+    long long plane;
+    int row, h, w;
+    float* lrcat;
+};
+
+constexpr int LR_TH = 4, LR_TW = 32, LR_HALO = 2;
+constexpr int LR_XR = LR_TH + 2 * LR_HALO;     // 8
+constexpr int LR_XC = LR_TW + 2 * LR_HALO;     // 36
+constexpr int LR_XT = 32 * LR_XR * LR_XC;      // x tile floats per channel group (9216)
+constexpr int LR_SLAB = 32 * 64;               // one (tap, cg) weight slab (2048 floats)
+
+__global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xt = smem;                       // [32][8][36]
+    float* wbuf = smem + LR_XT;             // [2][2048]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
+    const int x0 = blockIdx.x * LR_TW, y0 = blockIdx.y * LR_TH;
+    const int gy = y0 + wave, gx = x0 + px;
+    const bool valid = gy < p.h && gx < p.w;
+    const int cy = gy < p.h ? gy : p.h - 1, cx = gx < p.w ? gx : p.w - 1;
+
+    // B operand of the kernel-prediction GEMM: st[ch = 2s + half][pixel], resident for all 50 tiles
+    float bst[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) bst[s] = p.st[(long long)(2 * s + half) * p.plane + (long long)cy * p.row + cx];
+
+    f32x16 sta[2];
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg) {
+        __syncthreads();                    // previous group's readers are done with xt / wbuf
+        // replicate-padded x tile of this channel group (F.pad replicate, :302)
+        for (int e = tid; e < LR_XT; e += 256) {
+            const int ch = e / (LR_XR * LR_XC);
+            const int rem = e - ch * (LR_XR * LR_XC);
+            const int r = rem / LR_XC, c = rem - r * LR_XC;
+            int sy = y0 - LR_HALO + r, sx = x0 - LR_HALO + c;
+            sy = sy < 0 ? 0 : (sy > p.h - 1 ? p.h - 1 : sy);
+            sx = sx < 0 ? 0 : (sx > p.w - 1 ? p.w - 1 : sx);
+            xt[e] = p.x[(long long)(cg * 32 + ch) * p.plane + (long long)sy * p.row + sx];
+        }
+        {
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.wt.kconv_w + (long long)(0 * 2 + cg) * LR_SLAB);
+            reinterpret_cast<f32x4*>(wbuf)[tid] = src[tid];
+            reinterpret_cast<f32x4*>(wbuf)[tid + 256] = src[tid + 256];
+        }
+        __syncthreads();
+
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+
+        for (int tap = 0; tap < 25; ++tap) {
+            const bool more = tap + 1 < 25;
+            f32x4 nx0 = {0.f, 0.f, 0.f, 0.f}, nx1 = nx0;
+            if (more) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(p.wt.kconv_w + (long long)((tap + 1) * 2 + cg) * LR_SLAB);
+                nx0 = src[tid];
+                nx1 = src[tid + 256];
+            }
+            const float* wl = wbuf + (tap & 1) * LR_SLAB + lane;
+            const float* kb = p.wt.kconv_b + tap * 64 + cg * 32 + 4 * half;
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {            // bias as the initial accumulator
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + 8 * g);
+                acc[4 * g + 0] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
+            }
+#pragma unroll
+            for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[s * 64], bst[s], acc, 0, 0, 0);
+            const int ky = tap / 5, kx = tap - ky * 5;
+            const float* xp = xt + (wave + ky) * LR_XC + px + kx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float k = acc[r];
+                k = k > 0.f ? k : 0.1f * k;           // LeakyReLU(0.1), :228
+                sacc[r] += k * xp[acc_row(r, half) * (LR_XR * LR_XC)];
+            }
+            if (more) {
+                float* dst = wbuf + ((tap + 1) & 1) * LR_SLAB;
+                reinterpret_cast<f32x4*>(dst)[tid] = nx0;
+                reinterpret_cast<f32x4*>(dst)[tid + 256] = nx1;
+            }
+            __syncthreads();
+        }
+        sta[cg] = sacc;
+    }
+
+    // ---- LR-side projections --------------------------------------------------------------
+    f32x16 accA[2], accB[2], accC;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accA[0][r] = 0.f; accA[1][r] = 0.f; accB[0][r] = 0.f; accB[1][r] = 0.f; accC[r] = 0.f; }
+    const float* pa = p.wt.proj_w + lane;                 // [2][32][64]
+    const float* pb = p.wt.proj_w + 2 * 32 * 64 + lane;   // [2][32][64]
+    const float* pc = p.wt.proj_w + 4 * 32 * 64 + lane;   // [32][64]
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kidx = cg * 16 + r;
+            accA[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(0 * 32 + kidx) * 64], sta[cg][r], accA[0], 0, 0, 0);
+            accA[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(1 * 32 + kidx) * 64], sta[cg][r], accA[1], 0, 0, 0);
+        }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const float bx = p.x[(long long)(2 * s + half) * p.plane + (long long)cy * p.row + cx];
+        accB[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[(0 * 32 + s) * 64], bx, accB[0], 0, 0, 0);
+        accB[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[(1 * 32 + s) * 64], bx, accB[1], 0, 0, 0);
+        accC = __builtin_amdgcn_mfma_f32_32x32x2f32(pc[s * 64], bx, accC, 0, 0, 0);
+    }
+    if (!valid) return;
+    f32x4* rec = reinterpret_cast<f32x4*>(p.lrcat + ((long long)gy * p.w + gx) * REC + half * HREC);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 a = {accA[t][4 * g], accA[t][4 * g + 1], accA[t][4 * g + 2], accA[t][4 * g + 3]};
+            f32x4 b = {accB[t][4 * g], accB[t][4 * g + 1], accB[t][4 * g + 2], accB[t][4 * g + 3]};
+            rec[t * 4 + g] = a;
+            rec[8 + t * 4 + g] = b;
+        }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 c = {accC[4 * g], accC[4 * g + 1], accC[4 * g + 2], accC[4 * g + 3]};
+        rec[16 + g] = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// HR stage.  One wave = 32 consecutive HR pixels of one output row x all 64 channels; two lanes
+// (half 0 / half 1) per pixel, each owning 32 of the 64 output channels in MFMA accumulator
+// order.  grid_sample (zeros padding, align_corners=True) semantics of savsr_arch.py:262-295.
+// ------------------------------------------------------------------------------------------
+struct HrParams {
+    savsr_satu_weights wt;
+    const float* lrcat;
+    int h, w;
+    const float* table;
+    int n_uw;
+    const int* idx_h;
+    const int* idx_w;
+    const float* gyn;
+    const float* gxn;
+    int H, W;
+    float* out;
+};
+
+struct Taps {
+    int o[4];        // record offsets (in pixels) of the 4 taps: nw, ne, sw, se
+    float wgt[4];    // bilinear weights, 0 for taps outside the image
+};
+
+__device__ __forceinline__ Taps make_taps(float gxn, float gyn, float offx, float offy, int h, int w) {
+    const float fw1 = (float)(w - 1), fh1 = (float)(h - 1);
+    const float gx = gxn + (offx * 2.f) / fw1;           // :285,287
+    const float gy = gyn + (offy * 2.f) / fh1;           // :286,287
+    float ix = ((gx + 1.f) / 2.f) * fw1;                 // grid_sampler_unnormalize, align_corners=True
+    float iy = ((gy + 1.f) / 2.f) * fh1;
+    ix = fminf(fmaxf(ix, -2.f), (float)w + 1.f);         // keeps every in-range tap intact
+    iy = fminf(fmaxf(iy, -2.f), (float)h + 1.f);
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float lx = ix - xw, ly = iy - yn;
+    const float ex = 1.f - lx, sy = 1.f - ly;
+    const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < w, vx1 = x1 >= 0 && x1 < w;
+    const bool vy0 = y0 >= 0 && y0 < h, vy1 = y1 >= 0 && y1 < h;
+    const int cx0 = vx0 ? x0 : 0, cx1 = vx1 ? x1 : 0, cy0 = vy0 ? y0 : 0, cy1 = vy1 ? y1 : 0;
+    Taps t;
+    t.o[0] = cy0 * w + cx0; t.wgt[0] = (vy0 && vx0) ? sy * ex : 0.f;
+    t.o[1] = cy0 * w + cx1; t.wgt[1] = (vy0 && vx1) ? sy * lx : 0.f;
+    t.o[2] = cy1 * w + cx0; t.wgt[2] = (vy1 && vx0) ? ly * ex : 0.f;
+    t.o[3] = cy1 * w + cx1; t.wgt[3] = (vy1 && vx1) ? ly * lx : 0.f;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void satu_hr_kernel(const HrParams p) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, px = lane & 31;
+    const long long wave_g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * 4;
+    const int ntx = (p.W + 31) / 32;
+    const long long ntiles = (long long)p.H * ntx;
+
+    float wbe[2][16];                        // A operands of the expert MFMA, resident
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wbe[t][s] = p.wt.wbe_w[(t * 16 + s) * 64 + lane];
+    const f32x4* fb4 = reinterpret_cast<const f32x4*>(p.wt.fusion_b + half * 32);   // packed [half][q]
+
+    for (long long T = wave_g; T < ntiles; T += nwaves) {
+        const int Y = (int)(T / ntx);
+        const int X = (int)(T - (long long)Y * ntx) * 32 + px;
+        const bool valid = X < p.W;
+        const int Xc = valid ? X : p.W - 1;
+        const float* te = p.table + ((long long)p.idx_h[Y] * p.n_uw + p.idx_w[Xc]) * SAVSR_SATU_TABLE;
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
+        const f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
+        const float gxn = p.gxn[Xc], gyn = p.gyn[Y];
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = fb4[t * 4 + g];
+                acc[t][4 * g] = b[0]; acc[t][4 * g + 1] = b[1]; acc[t][4 * g + 2] = b[2]; acc[t][4 * g + 3] = b[3];
+            }
+
+        // ---- G(Wb x, off) and the 32 compressed channels G(C x, off) -------------------------
+        float gc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gc[i] = 0.f;
+        {
+            const Taps tp = make_taps(gxn, gyn, oo[0], oo[1], p.h, p.w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4* rec = reinterpret_cast<const f32x4*>(p.lrcat + (long long)tp.o[k] * REC + half * HREC);
+                const float wk = tp.wgt[k];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = rec[8 + t * 4 + g];
+                        acc[t][4 * g] += wk * v[0]; acc[t][4 * g + 1] += wk * v[1];
+                        acc[t][4 * g + 2] += wk * v[2]; acc[t][4 * g + 3] += wk * v[3];
+                    }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = rec[16 + g];
+                    gc[4 * g] += wk * v[0]; gc[4 * g + 1] += wk * v[1]; gc[4 * g + 2] += wk * v[2]; gc[4 * g + 3] += wk * v[3];
+                }
+            }
+        }
+        // ---- expert mixing: t_j = sum_m r_m (C_m f0)_j ; v[(n,j)] = r_n t_j ; acc += (Wb E) v ---
+        float tj[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) tj[jj] = rr[0] * gc[jj] + rr[1] * gc[4 + jj] + rr[2] * gc[8 + jj] + rr[3] * gc[12 + jj];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float v = rr[s >> 2] * tj[s & 3];       // k = 2 s + half  <->  n = s >> 2, j = 2 (s & 3) + half
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbe[0][s], v, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbe[1][s], v, acc[1], 0, 0, 0);
+        }
+        // ---- G(Wa sta, soff) -----------------------------------------------------------------
+        {
+            const Taps tp = make_taps(gxn, gyn, oo[2], oo[3], p.h, p.w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4* rec = reinterpret_cast<const f32x4*>(p.lrcat + (long long)tp.o[k] * REC + half * HREC);
+                const float wk = tp.wgt[k];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = rec[t * 4 + g];
+                        acc[t][4 * g] += wk * v[0]; acc[t][4 * g + 1] += wk * v[1];
+                        acc[t][4 * g + 2] += wk * v[2]; acc[t][4 * g + 3] += wk * v[3];
+                    }
+            }
+        }
+        if (valid) {
+            float* o = p.out + (long long)Y * p.W + X;
+            const long long HW = (long long)p.H * p.W;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(long long)(32 * t + acc_row(r, half)) * HW] = acc[t][r];
+        }
+    }
+}
+
+}  // namespace savsr
+
+using namespace savsr;
+
+static bool satu_weights_ok(const savsr_satu_weights* w) {
+    return w && w->body0_w && w->body0_b && w->body2_w && w->body2_b && w->head_w && w->head_b && w->kconv_w && w->kconv_b &&
+           w->proj_w && w->wbe_w && w->fusion_b;
+}
+
+extern "C" int savsr_satu_phase_table(const savsr_satu_weights* wt, const float* uniq_ch, int n_uh, const float* uniq_cw, int n_uw,
+                                      float inv_sw, float inv_sh, float* table, void* stream) {
+    if (!satu_weights_ok(wt) || !uniq_ch || !uniq_cw || !table) return fail_arg("satu_phase_table: null pointer");
+    if (n_uh < 1 || n_uw < 1) return fail_arg("satu_phase_table: empty table");
+    const long long n = (long long)n_uh * n_uw;
+    hipLaunchKernelGGL(satu_phase_table_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), *wt,
+                       uniq_ch, n_uh, uniq_cw, n_uw, inv_sw, inv_sh, table);
+    return check_launch("satu_phase_table_kernel");
+}
+
+extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const float* st, int64_t plane, int32_t row, int h,
+                                   int w, float* lrcat, void* stream) {
+    if (!satu_weights_ok(wt) || !x || !st || !lrcat) return fail_arg("satu_lr_stage: null pointer");
+    if (h < 1 || w < 1 || row < w || plane < (int64_t)row * h) return fail_arg("satu_lr_stage: shape/strides");
+    if ((reinterpret_cast<uintptr_t>(lrcat) & 15) || (reinterpret_cast<uintptr_t>(wt->kconv_w) & 15) ||
+        (reinterpret_cast<uintptr_t>(wt->kconv_b) & 15)) {
+        set_error("satu_lr_stage: lrcat / kconv_w / kconv_b must be 16-byte aligned");
+        return SAVSR_E_ALIGN;
+    }
+    LrParams p;
+    p.wt = *wt; p.x = x; p.st = st; p.plane = plane; p.row = row; p.h = h; p.w = w; p.lrcat = lrcat;
+    const size_t lds = (LR_XT + 2 * LR_SLAB) * sizeof(float);
+    dim3 grid((w + LR_TW - 1) / LR_TW, (h + LR_TH - 1) / LR_TH);
+    hipLaunchKernelGGL(satu_lr_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
+    return check_launch("satu_lr_kernel");
+}
+
+extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uw,
+                                      const int32_t* idx_h, const int32_t* idx_w, const float* gyn, const float* gxn, int H, int W,
+                                      float* out, void* stream) {
+    if (!satu_weights_ok(wt) || !lrcat || !table || !idx_h || !idx_w || !gyn || !gxn || !out) return fail_arg("satu_hr_upsample: null pointer");
+    if (h < 2 || w < 2 || H < 1 || W < 1 || n_uw < 1) return fail_arg("satu_hr_upsample: shape (h, w >= 2 required)");
+    if ((reinterpret_cast<uintptr_t>(lrcat) & 15) || (reinterpret_cast<uintptr_t>(table) & 15) ||
+        (reinterpret_cast<uintptr_t>(wt->fusion_b) & 15)) {
+        set_error("satu_hr_upsample: lrcat / table / fusion_b must be 16-byte aligned");
+        return SAVSR_E_ALIGN;
+    }
+    HrParams p;
+    p.wt = *wt; p.lrcat = lrcat; p.h = h; p.w = w; p.table = table; p.n_uw = n_uw; p.idx_h = idx_h; p.idx_w = idx_w;
+    p.gyn = gyn; p.gxn = gxn; p.H = H; p.W = W; p.out = out;
+    const long long ntiles = (long long)H * ((W + 31) / 32);
+    long long blocks = (ntiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(satu_hr_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return check_launch("satu_hr_kernel");
+}

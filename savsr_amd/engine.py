@@ -1,0 +1,514 @@
+"""Host-side driver of the HIP kernels for the SAVSR inference path.
+
+`HipEngine` owns (i) the weights re-laid-out once for the kernels (BatchNorm folded, conv
+weights in MFMA lane order, SATU matrices pre-multiplied), (ii) a pool of named device buffers
+per input shape and (iii) the launch sequence that replaces `SAVSR.forward`
+(/root/reference/lbasicsr/archs/savsr_arch.py:692-742).  PyTorch is used for device memory and
+streams only: every arithmetic step below is a call into libsavsr_hip.so through the C ABI of
+include/savsr_hip.h.  There is no CPU / eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvDesc, OSConvAttnDesc, SatuWeights
+
+BN_EPS = 1e-5
+
+
+# ----------------------------------------------------------------------------- host helpers (integer / grid logic)
+def get_hw(h: int, w: int, scale: Sequence[float]) -> Tuple[int, int]:
+    """Output size, savsr_arch.py:745-751 (Python round = half-to-even on the double product)."""
+    return round(h * scale[0]), round(w * scale[1])
+
+
+def satu_axis_tables(n_out: int, n_in: int, s: float):
+    """Per-axis SATU tables, evaluated in fp32 exactly like the reference's torch CPU ops.
+
+    Returns (coor, floor_idx, grid_norm):
+      coor      = (i+.5)/s - floor((i+.5)/s + 1e-3) - .5          savsr_arch.py:331-333
+      floor_idx = floor((i+.5)/s + 1e-3)  (the integer LR index grid, bit-exact contract)
+      grid_norm = ((i+.5)/s - .5) * 2 / (n_in-1) - 1              savsr_arch.py:270-280
+    """
+    f32 = np.float32
+    i = np.arange(n_out, dtype=np.float32)
+    q = (i + f32(0.5)) / f32(s)
+    fl = np.floor(q + f32(1e-3))
+    coor = (q - fl) - f32(0.5)
+    g = (i + f32(0.5)) / f32(s) - f32(0.5)
+    g = (g * f32(2)) / f32(n_in - 1) - f32(1)
+    return coor.astype(np.float32), fl.astype(np.int32), g.astype(np.float32)
+
+
+_PACK_IDX_CACHE: Dict[Tuple[int, int, int], Tuple[np.ndarray, int]] = {}
+
+
+def conv_pack_geometry(cout: int, cin: int, ks: int):
+    ck = 8 if ks == 3 else 32
+    cot = 64 if cout > 32 else 32
+    nchunk = (cin + ck - 1) // ck
+    ncob = (cout + cot - 1) // cot
+    return ck, cot, nchunk, ncob
+
+
+def conv_pack_index(cout: int, cin: int, ks: int):
+    """Index map [cout, cin, ks*ks] -> packed buffer (mirror of savsr_conv_pack_index)."""
+    key = (cout, cin, ks)
+    if key not in _PACK_IDX_CACHE:
+        ck, cot, nchunk, ncob = conv_pack_geometry(cout, cin, ks)
+        taps = ks * ks
+        co = np.arange(cout, dtype=np.int64)[:, None, None]
+        ci = np.arange(cin, dtype=np.int64)[None, :, None]
+        tap = np.arange(taps, dtype=np.int64)[None, None, :]
+        cob, col = co // cot, co % cot
+        chunk, cl = ci // ck, ci % ck
+        cp, hh = cl // 2, cl % 2
+        idx = ((((cob * nchunk + chunk) * taps + tap) * (ck // 2) + cp) * 2 + hh) * cot + col
+        total = ncob * nchunk * taps * ck * cot
+        _PACK_IDX_CACHE[key] = (np.ascontiguousarray(np.broadcast_to(idx, (cout, cin, taps))).reshape(-1), total)
+    return _PACK_IDX_CACHE[key]
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """[cout, cin, k, k] (any device) -> packed fp32 CPU tensor in MFMA lane order."""
+    cout, cin, ks, _ = w.shape
+    idx, total = conv_pack_index(cout, cin, ks)
+    out = np.zeros(total, dtype=np.float32)
+    out[idx] = w.detach().to("cpu", torch.float32).contiguous().numpy().reshape(-1)
+    return torch.from_numpy(out)
+
+
+def acc_row(r: int, half: int) -> int:
+    """Row of register r of a 32x32 MFMA accumulator for lane half `half`."""
+    return (r & 3) + 8 * (r >> 2) + 4 * half
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class _Src:
+    """A conv input: device tensor viewed as [ch][h][w] with explicit strides (in floats)."""
+    __slots__ = ("t", "ptr", "ch", "plane", "row")
+
+    def __init__(self, t: torch.Tensor, ch: int, plane: int, row: int, offset_floats: int = 0):
+        self.t = t
+        self.ptr = t.data_ptr() + 4 * offset_floats
+        self.ch, self.plane, self.row = ch, plane, row
+
+
+class HipEngine:
+    def __init__(self, state: Dict[str, torch.Tensor], cfg: dict, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("savsr_amd runs on an AMD GPU only (device 'cuda' under PyTorch-ROCm); "
+                               "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.dev = device
+        self.cfg = dict(cfg)
+        self.nf = cfg["num_feat"]
+        if self.nf != 64:
+            raise RuntimeError("the HIP SATU kernels are specialised for num_feat == 64")
+        self.pw: Dict[str, tuple] = {}      # conv key -> (wpacked, bias, cout, cin, ks)
+        self.osc: Dict[str, dict] = {}      # osconv key -> tensors
+        self.se: Dict[str, tuple] = {}
+        self._keep: List[torch.Tensor] = []
+        self._bufs: Dict[tuple, torch.Tensor] = {}
+        self._satu_axes: Dict[tuple, dict] = {}
+        self.satu_events: Optional[list] = None     # bench.py: (start, end) HIP events around SATU
+        self._pack_all({k: v.detach() for k, v in state.items()})
+
+    # ------------------------------------------------------------------ weight preparation
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        d = t.to(self.dev, torch.float32).contiguous()
+        self._keep.append(d)
+        return d
+
+    def _add_conv(self, sd, key: str, bn: Optional[str] = None):
+        w = sd[key + ".weight"].to("cpu", torch.float32)
+        b = sd.get(key + ".bias")
+        b = None if b is None else b.to("cpu", torch.float32)
+        if bn is not None:      # eval BatchNorm folded into the conv (savsr_arch.py:191,196,199,204)
+            s = sd[bn + ".weight"].cpu() / torch.sqrt(sd[bn + ".running_var"].cpu() + BN_EPS)
+            w = w * s.view(-1, 1, 1, 1)
+            b0 = b if b is not None else torch.zeros_like(s)
+            b = (b0 - sd[bn + ".running_mean"].cpu()) * s + sd[bn + ".bias"].cpu()
+        cout, cin, ks, _ = w.shape
+        self.pw[key] = (self._dev(pack_conv_weight(w)), None if b is None else self._dev(b), cout, cin, ks)
+
+    def _add_osconv(self, sd, key: str):
+        bank = sd[key + ".weight"].to("cpu", torch.float32)       # [K, cout, cin, 3, 3]
+        knum, cout, cin = bank.shape[:3]
+        packed = torch.stack([pack_conv_weight(bank[k]) for k in range(knum)], 0)
+        a = key + ".attention"
+        bn_s = sd[a + ".bn.weight"].cpu() / torch.sqrt(sd[a + ".bn.running_var"].cpu() + BN_EPS)
+        bn_b = sd[a + ".bn.bias"].cpu() - sd[a + ".bn.running_mean"].cpu() * bn_s
+        hidden = sd[a + ".fc.weight"].shape[0]
+        g = lambda k: self._dev(sd[k].reshape(sd[k].shape[0], -1) if sd[k].dim() > 1 else sd[k])
+        ent = dict(cin=cin, cout=cout, knum=knum, hidden=hidden, bank=self._dev(packed),
+                   l1_w=g(key + ".scale_routing.0.weight"), l1_b=g(key + ".scale_routing.0.bias"),
+                   l2_w=g(key + ".scale_routing.2.weight"), l2_b=g(key + ".scale_routing.2.bias"),
+                   fc_w=g(a + ".fc.weight"), bn_scale=self._dev(bn_s), bn_shift=self._dev(bn_b),
+                   ch_w=g(a + ".channel_fc.weight"), ch_b=g(a + ".channel_fc.bias"),
+                   fl_w=g(a + ".filter_fc.weight"), fl_b=g(a + ".filter_fc.bias"),
+                   sp_w=g(a + ".spatial_fc.weight"), sp_b=g(a + ".spatial_fc.bias"),
+                   kn_w=g(a + ".kernel_fc.weight"), kn_b=g(a + ".kernel_fc.bias"),
+                   mean=torch.empty(cin, device=self.dev), att=torch.empty(cin + cout + 9 + knum, device=self.dev),
+                   wdyn=torch.empty(packed.shape[1], device=self.dev))
+        self.osc[key] = ent
+
+    def _pack_satu(self, sd):
+        p = "upsample."
+        c = self.nf
+        f32 = torch.float32
+        wk = sd[p + "kernel_conv.0.weight"].to("cpu", f32).reshape(25 * c, c)     # [n = 25 ch + tap][k]
+        bk = sd[p + "kernel_conv.0.bias"].to("cpu", f32)
+        lane = np.arange(64)
+        li, lh = lane & 31, lane >> 5
+        # kconv_w[tap][cg][s][lane] = Wk[25 (32 cg + (lane & 31)) + tap][2 s + (lane >> 5)]
+        tap = np.arange(25)[:, None, None, None]
+        cg = np.arange(2)[None, :, None, None]
+        s = np.arange(32)[None, None, :, None]
+        n_idx = 25 * (32 * cg + li[None, None, None, :]) + tap
+        k_idx = 2 * s + lh[None, None, None, :]
+        kconv_w = wk.numpy()[n_idx, k_idx].astype(np.float32)                       # [25,2,32,64]
+        kconv_b = bk.numpy().reshape(c, 25).T.copy()                                  # [tap][ch]
+        fus = sd[p + "fusion.weight"].to("cpu", f32).reshape(c, 2 * c)
+        wa, wb = fus[:, :c].numpy(), fus[:, c:].numpy()                              # cat((sta, fea)), :374
+        comp = sd[p + "weight_compress"].to("cpu", f32).reshape(4, 8, c).numpy()     # C_m[j][c]
+        expd = sd[p + "weight_expand"].to("cpu", f32).reshape(4, c, 8).numpy()       # E_n[c][j]
+        rows = np.array([acc_row(r, 0) for r in range(16)]), np.array([acc_row(r, 1) for r in range(16)])
+        proj = np.zeros((5, 32, 64), dtype=np.float32)
+        for t in range(2):
+            for kidx in range(32):
+                cgi, r = kidx // 16, kidx % 16
+                ch = 32 * cgi + np.where(lh == 0, rows[0][r], rows[1][r])
+                proj[t, kidx, :] = wa[32 * t + li, ch]                               # Wa . sta  (k order = accumulator order)
+            for si in range(32):
+                proj[2 + t, si, :] = wb[32 * t + li, 2 * si + lh]                    # Wb . x
+        cstack = comp.reshape(32, c)                                                  # row m*8 + j
+        r_of_i = (li & 3) + 4 * (li >> 3)
+        hh_of_i = (li >> 2) & 1
+        ch_of_i = 8 * (r_of_i >> 2) + 2 * (r_of_i & 3) + hh_of_i                     # record slot r = 4m+jj <-> j = 2jj+hh
+        for si in range(32):
+            proj[4, si, :] = cstack[ch_of_i, 2 * si + lh]
+        wbe = np.einsum("oc,ncj->noj", wb.astype(np.float64), expd.astype(np.float64)).astype(np.float32)   # (Wb E_n)[co][j]
+        wbe_p = np.zeros((2, 16, 64), dtype=np.float32)
+        for t in range(2):
+            for si in range(16):
+                k = 2 * si + lh
+                wbe_p[t, si, :] = wbe[k // 8, 32 * t + li, k % 8]
+        fb = sd[p + "fusion.bias"].to("cpu", f32).numpy()
+        fb_p = np.zeros((2, 32), dtype=np.float32)
+        for hh in range(2):
+            for t in range(2):
+                for r in range(16):
+                    fb_p[hh, 16 * t + r] = fb[32 * t + acc_row(r, hh)]
+        head_w = torch.cat([sd[p + "routing.0.weight"], sd[p + "offset.weight"], sd[p + "st_offset.weight"]], 0)
+        head_b = torch.cat([sd[p + "routing.0.bias"], sd[p + "offset.bias"], sd[p + "st_offset.bias"]], 0)
+        t_ = lambda a: self._dev(torch.from_numpy(np.ascontiguousarray(a)))
+        self.satu_t = dict(
+            body0_w=self._dev(sd[p + "body.0.weight"].reshape(64, 4)), body0_b=self._dev(sd[p + "body.0.bias"]),
+            body2_w=self._dev(sd[p + "body.2.weight"].reshape(64, 64).t()), body2_b=self._dev(sd[p + "body.2.bias"]),
+            head_w=self._dev(head_w.reshape(8, 64)), head_b=self._dev(head_b),
+            kconv_w=t_(kconv_w), kconv_b=t_(kconv_b), proj_w=t_(proj), wbe_w=t_(wbe_p), fusion_b=t_(fb_p))
+        sw = SatuWeights()
+        for k, v in self.satu_t.items():
+            setattr(sw, k, v.data_ptr())
+        self.satu_w = sw
+        self.tail_w = self._dev(sd["tail.weight"].reshape(3, 64 * 9))
+        self.tail_b = self._dev(sd["tail.bias"])
+
+    def _pack_all(self, sd):
+        cfg = self.cfg
+        for d in ("f2p_win", "p2f_win"):
+            self._add_conv(sd, d + ".conv_c")
+            self._add_conv(sd, d + ".conv_sup")
+            for k in range(cfg["w1_num_block"]):
+                b = f"{d}.blocks.{k}"
+                for i in range(3):
+                    self._add_conv(sd, f"{b}.conv0.{i}")
+                    self._add_conv(sd, f"{b}.conv2.{i}")
+                if k >= 1:
+                    self._add_osconv(sd, b + ".osconv")
+                else:
+                    self._add_conv(sd, b + ".conv1")
+            self._add_conv(sd, d + ".merge")
+        steps = cfg["num_frame"] - cfg["slid_win"] + 1
+        self.n_l2 = (cfg["num_frame"] - cfg["fusion_win"] + 1) // 2
+        for i in range(self.n_l2):
+            u = f"h_win.{i}"
+            for j in range(steps - 2 * i):
+                self._add_conv(sd, f"{u}.conv_h.{j}")
+            for k in range(cfg["w2_num_block"]):
+                b = f"{u}.blocks.{k}"
+                for j in range(cfg["fusion_win"]):
+                    self._add_conv(sd, f"{b}.conv0.{j}")
+                    self._add_conv(sd, f"{b}.conv2.{j}")
+                self._add_osconv(sd, b + ".osconv")
+            self._add_conv(sd, u + ".merge")
+        self._add_conv(sd, "h_win_conv_h")
+        for g in range(cfg["n_resgroups"]):
+            for k in range(cfg["n_resblocks"]):
+                r = f"RG.{g}.residual_group.{k}.rcab"
+                self._add_conv(sd, r + ".0")
+                self._add_conv(sd, r + ".2")
+                a = r + ".3.attention"
+                cm = sd[a + ".1.weight"].shape[0]
+                self.se[r] = (self._dev(sd[a + ".1.weight"].reshape(cm, -1)), self._dev(sd[a + ".1.bias"]),
+                              self._dev(sd[a + ".3.weight"].reshape(-1, cm)), self._dev(sd[a + ".3.bias"]), cm)
+            self._add_conv(sd, f"RG.{g}.conv")
+            m = f"adapt.{g}.mask"
+            self._add_conv(sd, m + ".0", bn=m + ".1")
+            self._add_conv(sd, m + ".4", bn=m + ".5")
+            self._add_conv(sd, m + ".7", bn=m + ".8")
+            self._add_conv(sd, m + ".11", bn=m + ".12")
+            self._add_osconv(sd, f"adapt.{g}.adapt")
+        self._add_conv(sd, "conv_last")
+        self.gamma = float(sd["gamma"].reshape(-1)[0])
+        self._pack_satu(sd)
+        self.se_mean = torch.empty(self.nf, device=self.dev)
+        self.se_gate = torch.empty(self.nf, device=self.dev)
+
+    # ------------------------------------------------------------------ buffers / launch helpers
+    def buf(self, name: str, *shape: int) -> torch.Tensor:
+        key = (name,) + tuple(shape)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.empty(shape, device=self.dev, dtype=torch.float32)
+            self._bufs[key] = t
+        return t
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def full(self, t: torch.Tensor, ch: int, hp: int, wp: int) -> _Src:
+        return _Src(t, ch, hp * wp, wp)
+
+    def conv(self, key, srcs: List[_Src], out: torch.Tensor, h: int, w: int, act=ACT_NONE, slope=0.0,
+             mul_px=None, res1=None, res2=None, res2_scale=0.0, weights=None):
+        wpk, bias, cout, cin, ks = weights if weights is not None else self.pw[key]
+        d = ConvDesc()
+        assert len(srcs) <= _lib.MAX_SRC and all(s.ch == srcs[0].ch for s in srcs)
+        assert cin == len(srcs) * srcs[0].ch, (key, cin, len(srcs), srcs[0].ch)
+        for i, s in enumerate(srcs):
+            d.src[i] = s.ptr
+            d.src_plane[i] = s.plane
+            d.src_row[i] = s.row
+        d.nsrc, d.src_ch, d.h, d.w, d.cin, d.cout, d.ksize = len(srcs), srcs[0].ch, h, w, cin, cout, ks
+        d.wpacked, d.bias, d.act, d.slope = wpk.data_ptr(), _ptr(bias), act, slope
+        d.mul_px, d.res1, d.res2, d.res2_scale = _ptr(mul_px), _ptr(res1), _ptr(res2), res2_scale
+        d.out, d.out_plane, d.out_row = out.data_ptr(), h * w, w
+        _lib.check(self.lib.savsr_conv2d(C.byref(d), self._stream()), f"savsr_conv2d[{key}]")
+        return out
+
+    def channel_mean(self, srcs: List[_Src], h: int, w: int, mean: torch.Tensor):
+        n = len(srcs)
+        ptrs = (_lib.fptr * n)(*[s.ptr for s in srcs])
+        planes = (C.c_int64 * n)(*[s.plane for s in srcs])
+        rows = (C.c_int32 * n)(*[s.row for s in srcs])
+        _lib.check(self.lib.savsr_channel_mean(ptrs, planes, rows, n, srcs[0].ch, h, w, mean.data_ptr(), self._stream()),
+                   "savsr_channel_mean")
+
+    def osconv_weights(self, key: str, srcs: List[_Src], h: int, w: int, scale):
+        """Pool -> routing/attention -> aggregated packed weight (savsr_arch.py:143-163)."""
+        e = self.osc[key]
+        self.channel_mean(srcs, h, w, e["mean"])
+        d = OSConvAttnDesc()
+        d.cin, d.cout, d.hidden, d.knum = e["cin"], e["cout"], e["hidden"], e["knum"]
+        d.inv_sh, d.inv_sw = 1.0 / scale[0], 1.0 / scale[1]
+        for k in ("mean", "l1_w", "l1_b", "l2_w", "l2_b", "fc_w", "bn_scale", "bn_shift", "ch_w", "ch_b", "fl_w", "fl_b",
+                  "sp_w", "sp_b", "kn_w", "kn_b", "att"):
+            setattr(d, k, e[k].data_ptr())
+        st = self._stream()
+        _lib.check(self.lib.savsr_osconv_attention(C.byref(d), st), f"savsr_osconv_attention[{key}]")
+        _lib.check(self.lib.savsr_osconv_aggregate(e["bank"].data_ptr(), e["att"].data_ptr(), e["cin"], e["cout"], e["knum"],
+                                                   e["wdyn"].data_ptr(), st), f"savsr_osconv_aggregate[{key}]")
+        return (e["wdyn"], None, e["cout"], e["cin"], 3)
+
+    # ------------------------------------------------------------------ network pieces
+    def residual_block(self, pfx: str, xs: List[torch.Tensor], hp: int, wp: int, scale, use_osconv: bool, tag: str):
+        """savsr_arch.py:399-415, cat-free."""
+        n = len(xs)
+        nf = self.nf
+        x1 = [self.conv(f"{pfx}.conv0.{i}", [self.full(xs[i], nf, hp, wp)], self.buf(f"{tag}.x1.{i}", nf, hp, wp), hp, wp,
+                        ACT_LRELU, 0.2) for i in range(n)]
+        x1s = [self.full(t, nf, hp, wp) for t in x1]
+        base = self.buf(f"{tag}.base", nf, hp, wp)
+        if use_osconv:
+            wd = self.osconv_weights(pfx + ".osconv", x1s, hp, wp, scale)
+            self.conv(pfx + ".osconv", x1s, base, hp, wp, ACT_LRELU, 0.2, weights=wd)
+        else:
+            self.conv(pfx + ".conv1", x1s, base, hp, wp, ACT_LRELU, 0.2)
+        bs = self.full(base, nf, hp, wp)
+        return [self.conv(f"{pfx}.conv2.{i}", [bs, x1s[i]], self.buf(f"{tag}.out.{i}", nf, hp, wp), hp, wp, ACT_LRELU, 0.2,
+                          res1=xs[i]) for i in range(n)]
+
+    def window_l1(self, pfx: str, frames: torch.Tensor, t: int, h_past: torch.Tensor, hp: int, wp: int, scale, tag: str):
+        """savsr_arch.py:444-464.  frames: padded clip [T][3][hp][wp]; window (t-1, t, t+1)."""
+        nf = self.nf
+        fr = lambda k: _Src(frames, 3, hp * wp, wp, offset_floats=k * 3 * hp * wp)
+        h_sup = self.conv(pfx + ".conv_sup", [fr(t - 1), fr(t + 1)], self.buf(f"{tag}.hsup", nf, hp, wp), hp, wp, ACT_LRELU, 0.2)
+        h_c = self.conv(pfx + ".conv_c", [fr(t)], self.buf(f"{tag}.hc", nf, hp, wp), hp, wp, ACT_LRELU, 0.2)
+        feats = [h_c, h_sup, h_past]
+        for k in range(self.cfg["w1_num_block"]):
+            feats = self.residual_block(f"{pfx}.blocks.{k}", feats, hp, wp, scale, k >= 1, f"{tag}.b{k}")
+        return feats
+
+    def rcab(self, pfx: str, x: torch.Tensor, out: torch.Tensor, hp: int, wp: int, tag: str):
+        """savsr_arch.py:527-549."""
+        nf = self.nf
+        r1 = self.conv(pfx + ".0", [self.full(x, nf, hp, wp)], self.buf(f"{tag}.t1", nf, hp, wp), hp, wp, ACT_RELU)
+        r2 = self.conv(pfx + ".2", [self.full(r1, nf, hp, wp)], self.buf(f"{tag}.t2", nf, hp, wp), hp, wp, ACT_NONE)
+        self.channel_mean([self.full(r2, nf, hp, wp)], hp, wp, self.se_mean)
+        w1, b1, w2, b2, cm = self.se[pfx]
+        st = self._stream()
+        _lib.check(self.lib.savsr_se_gate(self.se_mean.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                          nf, cm, self.se_gate.data_ptr(), st), "savsr_se_gate")
+        _lib.check(self.lib.savsr_scale_residual(r2.data_ptr(), self.se_gate.data_ptr(), x.data_ptr(), out.data_ptr(), nf,
+                                                 hp * wp, st), "savsr_scale_residual")
+        return out
+
+    def osadapt(self, g: int, x: torch.Tensor, share: torch.Tensor, out: torch.Tensor, hp: int, wp: int, scale):
+        """savsr_arch.py:186-214 fused with `+ gamma * share` of :732."""
+        nf = self.nf
+        m = f"adapt.{g}.mask"
+        st = self._stream()
+        c4 = self.pw[m + ".0"][2]
+        m1 = self.conv(m + ".0", [self.full(x, nf, hp, wp)], self.buf("ad.m1", c4, hp, wp), hp, wp, ACT_RELU)
+        m2 = self.buf("ad.m2", c4, hp // 2, wp // 2)
+        _lib.check(self.lib.savsr_avgpool2(m1.data_ptr(), m2.data_ptr(), c4, hp, wp, st), "savsr_avgpool2")
+        m3 = self.conv(m + ".4", [self.full(m2, c4, hp // 2, wp // 2)], self.buf("ad.m3", c4, hp // 2, wp // 2), hp // 2, wp // 2, ACT_RELU)
+        m4 = self.conv(m + ".7", [self.full(m3, c4, hp // 2, wp // 2)], self.buf("ad.m4", c4, hp // 2, wp // 2), hp // 2, wp // 2, ACT_RELU)
+        m5 = self.buf("ad.m5", c4, hp, wp)
+        _lib.check(self.lib.savsr_upsample2x(m4.data_ptr(), m5.data_ptr(), c4, hp // 2, wp // 2, st), "savsr_upsample2x")
+        mask = self.conv(m + ".11", [self.full(m5, c4, hp, wp)], self.buf("ad.mask", 1, hp, wp), hp, wp, ACT_SIGMOID)
+        xs = [self.full(x, nf, hp, wp)]
+        wd = self.osconv_weights(f"adapt.{g}.adapt", xs, hp, wp, scale)
+        return self.conv(f"adapt.{g}.adapt", xs, out, hp, wp, ACT_NONE, mul_px=mask, res1=x, res2=share,
+                         res2_scale=self.gamma, weights=wd)
+
+    # ------------------------------------------------------------------ SATU
+    def satu_axes(self, h: int, w: int, scale):
+        key = (h, w, float(scale[0]), float(scale[1]))
+        ent = self._satu_axes.get(key)
+        if ent is None:
+            H, W = get_hw(h, w, scale)
+            ch, _, gyn = satu_axis_tables(H, h, scale[0])
+            cw, _, gxn = satu_axis_tables(W, w, scale[1])
+            uh, ih = np.unique(ch, return_inverse=True)
+            uw, iw = np.unique(cw, return_inverse=True)
+            up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(self.dev)
+            ent = dict(H=H, W=W, n_uh=len(uh), n_uw=len(uw), uh=up(uh, np.float32), uw=up(uw, np.float32),
+                       ih=up(ih.reshape(-1), np.int32), iw=up(iw.reshape(-1), np.int32), gyn=up(gyn, np.float32), gxn=up(gxn, np.float32),
+                       table=torch.empty(len(uh) * len(uw) * _lib.SATU_TABLE, device=self.dev))
+            self._satu_axes[key] = ent
+        return ent
+
+    def satu(self, x: _Src, st: _Src, h: int, w: int, scale, out: torch.Tensor):
+        """STAUpsample.forward (savsr_arch.py:315-376).  x, st: strided [64][h][w] views."""
+        ax = self.satu_axes(h, w, scale)
+        s = self._stream()
+        sw = C.byref(self.satu_w)
+        if self.satu_events is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        _lib.check(self.lib.savsr_satu_phase_table(sw, ax["uh"].data_ptr(), ax["n_uh"], ax["uw"].data_ptr(), ax["n_uw"],
+                                                   1.0 / scale[1], 1.0 / scale[0], ax["table"].data_ptr(), s), "savsr_satu_phase_table")
+        assert x.plane == st.plane and x.row == st.row
+        lrcat = self.buf("satu.lrcat", h, w, _lib.SATU_LRCAT)
+        _lib.check(self.lib.savsr_satu_lr_stage(sw, x.ptr, st.ptr, x.plane, x.row, h, w, lrcat.data_ptr(), s), "savsr_satu_lr_stage")
+        _lib.check(self.lib.savsr_satu_hr_upsample(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(),
+                                                   ax["iw"].data_ptr(), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"],
+                                                   out.data_ptr(), s), "savsr_satu_hr_upsample")
+        if self.satu_events is not None:
+            ev1.record()
+            self.satu_events.append((ev0, ev1))
+        return out
+
+    # ------------------------------------------------------------------ whole frame
+    def forward_one(self, lq: torch.Tensor, scale, out: torch.Tensor, taps: Optional[dict] = None):
+        """lq: [T, 3, h, w] fp32 contiguous on device; out: [3, H, W]."""
+        cfg, nf = self.cfg, self.nf
+        T, cin, h_in, w_in = lq.shape
+        assert T == cfg["num_frame"] and cin == cfg["num_in_ch"] == 3 and cfg["interval"] == 0
+        if h_in < 2 or w_in < 2:
+            raise ValueError("SAVSR needs h, w >= 2")
+        center = T // 2 if cfg["center_frame_idx"] is None else cfg["center_frame_idx"]
+        H, W = get_hw(h_in, w_in, scale)
+        hp, wp = h_in + (h_in & 1), w_in + (w_in & 1)
+        st = self._stream()
+        if (hp, wp) != (h_in, w_in):
+            frames = self.buf("frames", T, 3, hp, wp)
+            _lib.check(self.lib.savsr_reflect_pad(lq.data_ptr(), frames.data_ptr(), T * 3, h_in, w_in, hp, wp, st), "savsr_reflect_pad")
+        else:
+            frames = lq
+        sw, fw = cfg["slid_win"], cfg["fusion_win"]
+        steps = T - sw + 1
+        zero = self.buf("zero", nf, hp, wp)
+        zero.zero_()          # hidden state restarts from zero every window (savsr_arch.py:705-706)
+        hb, hf = zero, zero
+        lb: List[Optional[torch.Tensor]] = [None] * steps
+        lf: List[Optional[torch.Tensor]] = [None] * steps
+        for idx in range(steps):                                                    # :708-719
+            cur = T - 1 - sw // 2 - idx
+            feats = self.window_l1("f2p_win", frames, cur, hb, hp, wp, scale, "f2p")
+            hb = self.conv("f2p_win.merge", [self.full(t, nf, hp, wp) for t in feats], self.buf(f"f2p.h{idx}", nf, hp, wp), hp, wp)
+            lb[steps - 1 - idx] = hb
+            cur = idx + sw // 2
+            feats = self.window_l1("p2f_win", frames, cur, hf, hp, wp, scale, "p2f")
+            hf = self.conv("p2f_win.merge", [self.full(t, nf, hp, wp) for t in feats], self.buf(f"p2f.h{idx}", nf, hp, wp), hp, wp)
+            lf[idx] = hf
+        # pyramid fusion (:616-618, :485-501, :721-722): inputs as source lists, never concatenated
+        level: List[List[_Src]] = [[self.full(lb[i], nf, hp, wp), self.full(lf[i], nf, hp, wp)] for i in range(steps)]
+        for i in range(self.n_l2):
+            u = f"h_win.{i}"
+            ws = steps - 2 * i
+            hfs = [self.conv(f"{u}.conv_h.{j}", level[j], self.buf(f"l2.{i}.hf{j}", nf, hp, wp), hp, wp, ACT_LRELU, 0.2) for j in range(ws)]
+            nxt: List[List[_Src]] = []
+            for j in range(ws - fw + 1):
+                swf = hfs[j:j + fw]
+                for k in range(cfg["w2_num_block"]):
+                    swf = self.residual_block(f"{u}.blocks.{k}", swf, hp, wp, scale, True, f"l2.{i}.{j}.b{k}")
+                o = self.conv(u + ".merge", [self.full(t, nf, hp, wp) for t in swf], self.buf(f"l2.{i}.o{j}", 2 * nf, hp, wp), hp, wp)
+                nxt.append([self.full(o, 2 * nf, hp, wp)])
+            level = nxt
+        align = self.conv("h_win_conv_h", level[0], self.buf("align", nf, hp, wp), hp, wp, ACT_LRELU, 0.2)   # :723
+        share = align
+        hcur = align
+        for g in range(cfg["n_resgroups"]):                                         # :728-732
+            xin = hcur
+            r = xin
+            for k in range(cfg["n_resblocks"]):
+                r = self.rcab(f"RG.{g}.residual_group.{k}.rcab", r, self.buf(f"rg.r{k & 1}", nf, hp, wp), hp, wp, "rg")
+            rg = self.conv(f"RG.{g}.conv", [self.full(r, nf, hp, wp)], self.buf("rg.out", nf, hp, wp), hp, wp, res1=xin)
+            hcur = self.osadapt(g, rg, share, self.buf(f"rg.h{g & 1}", nf, hp, wp), hp, wp, scale)
+        hfeat = self.conv("conv_last", [self.full(hcur, nf, hp, wp)], self.buf("hfeat", nf, hp, wp), hp, wp, res1=share)   # :733-734
+        if taps is not None:
+            taps["align_feat"] = align
+            taps["h_feat"] = hfeat
+        satu_out = self.buf("satu.out", nf, H, W)
+        self.satu(_Src(hfeat, nf, hp * wp, wp), _Src(align, nf, hp * wp, wp), h_in, w_in, scale, satu_out)   # crops of :737
+        if taps is not None:
+            taps["satu"] = satu_out
+        cptr = lq.data_ptr() + 4 * center * 3 * h_in * w_in                         # unpadded centre frame (:696)
+        _lib.check(self.lib.savsr_tail_residual(satu_out.data_ptr(), self.tail_w.data_ptr(), self.tail_b.data_ptr(), cptr,
+                                                h_in, w_in, H, W, out.data_ptr(), st), "savsr_tail_residual")
+        return out
+
+    def forward(self, lq: torch.Tensor, scale, taps: Optional[dict] = None) -> torch.Tensor:
+        """lq: [b, T, 3, h, w] -> [b, 3, H, W] (savsr_arch.py:692-742)."""
+        if lq.device != self.dev:
+            raise RuntimeError(f"input on {lq.device}, engine on {self.dev}")
+        lq = lq.to(torch.float32).contiguous()
+        b, _, _, h, w = lq.shape
+        H, W = get_hw(h, w, scale)
+        out = torch.empty(b, 3, H, W, device=self.dev, dtype=torch.float32)
+        for i in range(b):      # samples are independent (OSConv groups=b, savsr_arch.py:166-167)
+            self.forward_one(lq[i], scale, out[i], taps if i == 0 else None)
+        return out

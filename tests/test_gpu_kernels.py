@@ -1,0 +1,209 @@
+"""Parity of each HIP kernel family (through the C ABI) against the CPU oracle / ATen CPU ops.
+
+Run on the GPU box with `pytest -m gpu`.  Tolerances: fp32 re-association only, so 1e-4 absolute
+on O(1) values unless a test states otherwise (north_star: 1e-3 dB PSNR / 1e-4 SSIM end to end).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import savsr_oracle as O
+from savsr_amd.utils import synth
+from tests.golden_cases import OSCONV_CASES, OSCONV_SCALES, SATU_CASES, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(synth_sd):
+    from savsr_amd.engine import HipEngine
+    from savsr_amd.archs.savsr_arch import SAVSR
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return HipEngine(synth_sd, SAVSR().cfg, torch.device("cuda:0"))
+
+
+def _dev(t):
+    return t.to("cuda:0").contiguous()
+
+
+def _maxerr(a, b):
+    return float((a.detach().cpu().float() - b.detach().cpu().float()).abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,ks,nsrc,h,w", [
+    (64, 64, 3, 1, 10, 12), (192, 64, 3, 3, 9, 40), (128, 64, 3, 2, 12, 33), (320, 128, 3, 5, 8, 35),
+    (192, 64, 1, 3, 7, 50), (3, 64, 3, 1, 13, 31), (6, 64, 3, 2, 6, 70), (64, 16, 3, 1, 10, 12),
+    (16, 16, 3, 1, 5, 6), (16, 1, 3, 1, 10, 12), (128, 64, 3, 1, 9, 11)])
+def test_conv2d(eng, cin, cout, ks, nsrc, h, w):
+    from savsr_amd import engine as E
+    from savsr_amd._lib import ACT_LRELU
+    g = np.random.RandomState(cin * 7 + cout)
+    wt = torch.from_numpy(g.standard_normal((cout, cin, ks, ks)).astype(np.float32) / np.sqrt(cin * ks * ks))
+    bias = torch.from_numpy(g.standard_normal(cout).astype(np.float32))
+    x = torch.from_numpy(g.standard_normal((cin, h, w)).astype(np.float32))
+    res = torch.from_numpy(g.standard_normal((cout, h, w)).astype(np.float32))
+    res2 = torch.from_numpy(g.standard_normal((cout, h, w)).astype(np.float32))
+    mul = torch.from_numpy(g.uniform(0, 1, (h, w)).astype(np.float32))
+    ref = F.leaky_relu(F.conv2d(x[None], wt, bias, padding=ks // 2), 0.2)[0] * mul + res + 0.9 * res2
+    sch = cin // nsrc
+    xs = [_dev(x[i * sch:(i + 1) * sch]) for i in range(nsrc)]
+    out = torch.full((cout, h, w), float("nan"), device="cuda:0")
+    weights = (_dev(E.pack_conv_weight(wt)), _dev(bias), cout, cin, ks)
+    eng.conv("test", [eng.full(t, sch, h, w) for t in xs], out, h, w, ACT_LRELU, 0.2, mul_px=_dev(mul), res1=_dev(res),
+             res2=_dev(res2), res2_scale=0.9, weights=weights)
+    torch.cuda.synchronize()
+    assert _maxerr(out, ref) < 1e-4
+
+
+def test_conv2d_rejects_bad_args(eng):
+    from savsr_amd._lib import ConvDesc
+    d = ConvDesc()
+    d.ksize = 5
+    assert eng.lib.savsr_conv2d(C.byref(d), None) < 0
+    assert b"ksize" in eng.lib.savsr_last_error()
+
+
+@pytest.mark.parametrize("tag,pfx,cin", OSCONV_CASES)
+def test_osconv_vs_golden(eng, golden, synth_sd, tag, pfx, cin):
+    """OSConv2d (savsr_arch.py:139-172): pool -> routing -> attention -> aggregate -> conv."""
+    for sc in OSCONV_SCALES:
+        x = rnd((1, cin, 10, 12), 11 + cin, 0.7)
+        nsrc = cin // 64
+        xs = [_dev(x[0, i * 64:(i + 1) * 64]) for i in range(nsrc)]
+        srcs = [eng.full(t, 64, 10, 12) for t in xs]
+        wd = eng.osconv_weights(pfx, srcs, 10, 12, sc)
+        out = torch.empty(64, 10, 12, device="cuda:0")
+        eng.conv(pfx, srcs, out, 10, 12, weights=wd)
+        torch.cuda.synchronize()
+        gold = torch.from_numpy(golden[f"osconv/{tag}/{sc[0]}_{sc[1]}"])[0]
+        assert _maxerr(out, gold) < 1e-4
+        # attention vector itself against the oracle
+        with torch.no_grad():
+            b = 1
+            s = torch.tensor([[1.0 / sc[0], 1.0 / sc[1]]])
+            v = torch.cat([s, x.mean(dim=(2, 3))], 1)
+            v = F.relu(F.linear(v, synth_sd[pfx + ".scale_routing.0.weight"], synth_sd[pfx + ".scale_routing.0.bias"]))
+            v = F.relu(F.linear(v, synth_sd[pfx + ".scale_routing.2.weight"], synth_sd[pfx + ".scale_routing.2.bias"]))
+            ca, fa, sa, ka = O.scale_attention(synth_sd, pfx + ".attention", v.view(b, cin, 1, 1))
+        att = eng.osc[pfx]["att"].cpu()
+        ref_att = torch.cat([ca.reshape(-1), fa.reshape(-1), sa.reshape(-1), ka.reshape(-1)])
+        assert _maxerr(att, ref_att) < 1e-5
+
+
+def test_osadapt_vs_golden(eng, golden):
+    x = rnd((1, 64, 10, 12), 5, 0.8)
+    share = torch.zeros(64, 10, 12)
+    out = torch.empty(64, 10, 12, device="cuda:0")
+    g0 = eng.gamma
+    eng.gamma = 0.0          # the golden is OSAdapt alone (no + gamma*share)
+    try:
+        eng.osadapt(1, _dev(x[0]), _dev(share), out, 10, 12, (2.5, 2.5))
+        torch.cuda.synchronize()
+    finally:
+        eng.gamma = g0
+    assert _maxerr(out, torch.from_numpy(golden["osadapt/a1/2.5_2.5"])[0]) < 1e-4
+
+
+def _run_satu(eng, x, st, sc):
+    from savsr_amd.engine import _Src, get_hw
+    h, w = x.shape[-2:]
+    H, W = get_hw(h, w, sc)
+    xd, sd_ = _dev(x[0]), _dev(st[0])
+    out = torch.full((64, H, W), float("nan"), device="cuda:0")
+    eng.satu(_Src(xd, 64, h * w, w), _Src(sd_, 64, h * w, w), h, w, sc, out)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("tag,h,w,sc", SATU_CASES)
+def test_satu_vs_golden(eng, golden, tag, h, w, sc):
+    x = rnd((1, 64, h, w), 21, 1.0)
+    st = rnd((1, 64, h, w), 22, 0.6)
+    out = _run_satu(eng, x, st, sc)
+    assert _maxerr(out, torch.from_numpy(golden[f"satu/{tag}/out"])[0]) < 1e-4
+
+
+def test_satu_phase_table_and_integer_grid(eng, synth_sd):
+    """Table entries equal the oracle's per-pixel heads; index tables are exact integers."""
+    from savsr_amd.engine import satu_axis_tables
+    for (h, w, sc) in [(9, 11, (4, 4)), (10, 7, (1.5, 4)), (8, 9, (3.9, 3.9))]:
+        x = rnd((1, 64, h, w), 3, 1.0)
+        _run_satu(eng, x, x, sc)
+        ax = eng.satu_axes(h, w, sc)
+        H, W = ax["H"], ax["W"]
+        tab = ax["table"].cpu().view(ax["n_uh"], ax["n_uw"], 8)
+        per_px = tab[ax["ih"].cpu().long()][:, ax["iw"].cpu().long()]        # [H, W, 8]
+        with torch.no_grad():
+            off, soff, r = O.satu_heads(synth_sd, "upsample", h, w, sc)
+        ref = torch.cat([r[0], off[0], soff[0]], 0).permute(1, 2, 0)
+        assert float((per_px - ref).abs().max()) < 2e-5
+        _, _, _, _, fh, fw = O.satu_coords(h, w, sc)
+        assert np.array_equal(satu_axis_tables(H, h, sc[0])[1], fh.numpy().astype(np.int32))
+        assert np.array_equal(satu_axis_tables(W, w, sc[1])[1], fw.numpy().astype(np.int32))
+
+
+def test_satu_large_offsets_and_borders(eng, synth_sd):
+    """Offsets of several pixels push taps outside the image: zeros padding must match."""
+    from savsr_amd.engine import HipEngine
+    from savsr_amd.archs.savsr_arch import SAVSR
+    sd = dict(synth_sd)
+    for k in ("upsample.offset.weight", "upsample.st_offset.weight"):
+        sd[k] = sd[k] * 6.0
+    e2 = HipEngine(sd, SAVSR().cfg, torch.device("cuda:0"))
+    x = rnd((1, 64, 9, 8), 31, 1.0)
+    st = rnd((1, 64, 9, 8), 32, 0.6)
+    for sc in [(4, 4), (2.5, 1.3)]:
+        out = _run_satu(e2, x, st, sc)
+        with torch.no_grad():
+            ref = O.sta_upsample(sd, "upsample", x, sc, st)[0]
+        assert _maxerr(out, ref) < 2e-4
+
+
+def test_satu_strided_crop(eng, synth_sd):
+    """SATU reads crops of padded tensors through strides (savsr_arch.py:737)."""
+    from savsr_amd.engine import _Src, get_hw
+    hp, wp, h, w, sc = 10, 12, 9, 11, (2, 2)
+    xf = rnd((1, 64, hp, wp), 41, 1.0)
+    sf = rnd((1, 64, hp, wp), 42, 0.6)
+    H, W = get_hw(h, w, sc)
+    out = torch.empty(64, H, W, device="cuda:0")
+    xd, sd_ = _dev(xf[0]), _dev(sf[0])
+    eng.satu(_Src(xd, 64, hp * wp, wp), _Src(sd_, 64, hp * wp, wp), h, w, sc, out)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.sta_upsample(synth_sd, "upsample", xf[..., :h, :w], sc, sf[..., :h, :w])[0]
+    assert _maxerr(out, ref) < 1e-4
+
+
+def test_tail_residual(eng, synth_sd):
+    h, w, sc = 7, 9, (3.5, 2)
+    H, W = O.get_hw(h, w, sc)
+    feat = rnd((1, 64, H, W), 51, 1.0)
+    center = torch.from_numpy(np.random.RandomState(52).uniform(0, 1, (1, 3, h, w)).astype(np.float32))
+    out = torch.empty(3, H, W, device="cuda:0")
+    from savsr_amd import _lib
+    _lib.check(eng.lib.savsr_tail_residual(_dev(feat[0]).data_ptr(), eng.tail_w.data_ptr(), eng.tail_b.data_ptr(),
+                                           (cd := _dev(center[0])).data_ptr(), h, w, H, W, out.data_ptr(), None), "tail")
+    torch.cuda.synchronize()
+    ref = F.conv2d(feat, synth_sd["tail.weight"], synth_sd["tail.bias"], padding=1) + \
+        F.interpolate(center, size=(H, W), mode="bilinear", align_corners=False)
+    assert _maxerr(out, ref[0]) < 1e-4
+
+
+def test_small_elementwise(eng):
+    from savsr_amd import _lib
+    x = rnd((5, 8, 10), 61)
+    xd = _dev(x)
+    o = torch.empty(5, 4, 5, device="cuda:0")
+    _lib.check(eng.lib.savsr_avgpool2(xd.data_ptr(), o.data_ptr(), 5, 8, 10, None), "avgpool2")
+    assert _maxerr(o, F.avg_pool2d(x[None], 2)[0]) < 1e-6
+    o = torch.empty(5, 16, 20, device="cuda:0")
+    _lib.check(eng.lib.savsr_upsample2x(xd.data_ptr(), o.data_ptr(), 5, 8, 10, None), "upsample2x")
+    assert _maxerr(o, F.interpolate(x[None], scale_factor=2, mode="bilinear", align_corners=False)[0]) < 1e-6
+    x = rnd((6, 7, 9), 62)
+    o = torch.empty(6, 8, 10, device="cuda:0")
+    _lib.check(eng.lib.savsr_reflect_pad(_dev(x).data_ptr(), o.data_ptr(), 6, 7, 9, 8, 10, None), "reflect_pad")
+    assert _maxerr(o, F.pad(x[None], [0, 1, 0, 1], mode="reflect")[0]) == 0.0

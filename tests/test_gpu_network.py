@@ -1,0 +1,124 @@
+"""End-to-end parity of the HIP path (through the ARCH_REGISTRY surface) with the reference
+goldens and the CPU oracle.  `pytest -m gpu` on the MI355X box."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import savsr_oracle as O
+from savsr_amd.utils import synth
+from tests.golden_cases import NET_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net(synth_sd):
+    import savsr_amd
+    assert torch.cuda.is_available()
+    n = savsr_amd.build_network(dict(type="SAVSR", num_in_ch=3, num_feat=64, num_frame=7, slid_win=3, fusion_win=5,
+                                     interval=0, w1_num_block=4, w2_num_block=2, n_resgroups=4, n_resblocks=8,
+                                     center_frame_idx=None)).eval()
+    n.load_state_dict(synth_sd, strict=True)
+    return n.to("cuda:0")
+
+
+@pytest.mark.parametrize("name,h,w,sc", NET_CASES)
+def test_network_vs_reference_golden(net, golden, name, h, w, sc):
+    """fp32 output within 2e-4 max-abs of the REFERENCE's own output (tests/golden)."""
+    lq = synth.synth_clip(7, 3, h, w, seed=0)
+    net.set_scale(sc)
+    taps = {}
+    out = net(lq.to("cuda:0"), taps=taps)
+    torch.cuda.synchronize()
+    gold = torch.from_numpy(golden[f"net/{name}/sr"])
+    assert tuple(out.shape) == tuple(gold.shape)
+    err = float((out.cpu() - gold).abs().max())
+    satu_err = float((taps["satu"].cpu()[::4, ::3, ::3] - torch.from_numpy(golden[f"net/{name}/satu_s"])[0]).abs().max())
+    print(name, "max-abs", err, "satu", satu_err)
+    assert satu_err < 5e-4 and err < 2e-4
+
+
+def test_stage_taps_vs_oracle(net, synth_sd):
+    """Intermediate tensors (propagation output, trunk output, SATU) against the oracle."""
+    h, w, sc = 15, 18, (2.5, 3.5)
+    lq = synth.synth_clip(7, 3, h, w, seed=9)
+    net.set_scale(sc)
+    taps, otaps = {}, {}
+    out = net(lq.to("cuda:0"), taps=taps)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.forward(synth_sd, lq, sc, taps=otaps)
+    for k in ("align_feat", "h_feat", "satu"):
+        e = float((taps[k].cpu() - otaps[k][0]).abs().max())
+        print(k, e)
+        assert e < 5e-4, (k, e)
+    assert float((out.cpu() - ref).abs().max()) < 2e-4
+
+
+def test_batch_and_determinism(net, synth_sd):
+    lq = torch.cat([synth.synth_clip(7, 3, 12, 14, seed=1), synth.synth_clip(7, 3, 12, 14, seed=2)], 0)
+    net.set_scale((2, 2))
+    a = net(lq.to("cuda:0")).cpu()
+    b = net(lq.to("cuda:0")).cpu()
+    assert torch.equal(a, b), "kernels are deterministic: bitwise identical reruns"
+    with torch.no_grad():
+        ref = O.forward(synth_sd, lq[1:], (2, 2))
+    assert float((a[1:] - ref).abs().max()) < 2e-4
+
+
+def test_psnr_ssim_tolerance(net, synth_sd):
+    """north_star tolerance: |dPSNR-Y| <= 1e-3 dB and |dSSIM-Y| <= 1e-4 vs the oracle, same GT."""
+    from savsr_amd.metrics import calculate_psnr, calculate_ssim, tensor2img
+    h, w, sc = 32, 40, (4, 4)
+    lq = synth.synth_clip(7, 3, h, w, seed=3)
+    gt = synth.synth_gt(3, 128, 160, seed=3)
+    net.set_scale(sc)
+    out = net(lq.to("cuda:0")).cpu()
+    with torch.no_grad():
+        ref = O.forward(synth_sd, lq, sc)
+    gi = tensor2img(gt)
+    p1, p2 = calculate_psnr(tensor2img(out[0]), gi, 0, test_y_channel=True), calculate_psnr(tensor2img(ref[0]), gi, 0, test_y_channel=True)
+    s1, s2 = calculate_ssim(tensor2img(out[0]), gi, 0, test_y_channel=True), calculate_ssim(tensor2img(ref[0]), gi, 0, test_y_channel=True)
+    print("psnr", p1, p2, "ssim", s1, s2)
+    assert abs(p1 - p2) <= 1e-3 and abs(s1 - s2) <= 1e-4
+
+
+def test_full_size_config2(net, synth_sd):
+    """BASELINE config 2 (7x3x180x320, x4 -> 720x1280): shape, finiteness, bitwise rerun
+    determinism, and parity with the CPU oracle on the same clip (max-abs, PSNR-Y, SSIM-Y)."""
+    from savsr_amd.metrics import calculate_psnr, calculate_ssim, tensor2img
+    lq = synth.synth_clip(7, 3, 180, 320, seed=0)
+    net.set_scale((4, 4))
+    a = net(lq.to("cuda:0"))
+    assert tuple(a.shape) == (1, 3, 720, 1280) and bool(torch.isfinite(a).all())
+    b = net(lq.to("cuda:0"))
+    assert torch.equal(a, b)
+    with torch.no_grad():
+        ref = O.forward(synth_sd, lq, (4, 4))
+    err = float((a.cpu() - ref).abs().max())
+    gt = tensor2img(synth.synth_gt(3, 720, 1280, seed=0))
+    dp = abs(calculate_psnr(tensor2img(a[0].cpu()), gt, 0, test_y_channel=True) - calculate_psnr(tensor2img(ref[0]), gt, 0, test_y_channel=True))
+    ds = abs(calculate_ssim(tensor2img(a[0].cpu()), gt, 0, test_y_channel=True) - calculate_ssim(tensor2img(ref[0]), gt, 0, test_y_channel=True))
+    print("config2 max-abs", err, "dPSNR", dp, "dSSIM", ds)
+    assert err < 5e-4 and dp <= 1e-3 and ds <= 1e-4
+
+
+def test_full_size_satu_linearity(net):
+    """Size-independent property at 180x320 -> 720x1280: for fixed st_feat, SATU is affine in x
+    (dynamic filters depend on st only, offsets/routing on coordinates only)."""
+    from savsr_amd.engine import _Src
+    eng = net.engine()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x1, x2, st = (torch.randn(64, 180, 320, generator=g).to("cuda:0") for _ in range(3))
+    z = torch.zeros_like(x1)
+    outs = []
+    for x in (x1, x2, 0.5 * x1 - 2.0 * x2, z):
+        o = torch.empty(64, 720, 1280, device="cuda:0")
+        eng.satu(_Src(x, 64, 180 * 320, 320), _Src(st, 64, 180 * 320, 320), 180, 320, (4, 4), o)
+        outs.append(o)
+    torch.cuda.synchronize()
+    y1, y2, y3, y0 = outs
+    lin = 0.5 * (y1 - y0) - 2.0 * (y2 - y0) + y0
+    rel = float((y3 - lin).abs().max() / y3.abs().max())
+    print("satu linearity rel err", rel)
+    assert rel < 1e-5

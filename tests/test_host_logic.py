@@ -1,0 +1,106 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/savsr_hip.h,
+host-side integer/grid logic is bit-exact against the reference goldens, registry / build_network /
+state_dict surface match the reference contract, the product refuses to run without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import savsr_amd
+from savsr_amd import _lib, engine as E
+from savsr_amd.utils import synth
+from tests.golden_cases import GRID_SIZES, YAML_SCALES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "savsr_hip.h")).read()
+    declared = set(re.findall(r"\b(savsr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "header parse failed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.savsr_abi_version() == 1
+    assert b"gfx950" in lib.savsr_version()
+
+
+def test_pack_index_matches_c_abi():
+    lib = _lib.load()
+    rng = np.random.RandomState(0)
+    for (co, ci, ks) in [(64, 64, 3), (64, 192, 3), (128, 320, 3), (16, 64, 3), (1, 16, 3), (64, 192, 1), (64, 3, 3), (64, 6, 3)]:
+        idx, total = E.conv_pack_index(co, ci, ks)
+        assert total == lib.savsr_conv_packed_floats(co, ci, ks)
+        assert len(np.unique(idx)) == len(idx) and idx.max() < total
+        view = idx.reshape(co, ci, ks * ks)
+        for _ in range(40):
+            a, b, c = rng.randint(co), rng.randint(ci), rng.randint(ks * ks)
+            assert view[a, b, c] == lib.savsr_conv_pack_index(co, ci, ks, a, b, c)
+
+
+def test_invalid_arguments_are_rejected_without_gpu():
+    lib = _lib.load()
+    assert lib.savsr_conv2d(None, None) == -1
+    assert b"null" in lib.savsr_last_error()
+    assert lib.savsr_avgpool2(1, 2, 4, 3, 4, None) == -1      # odd height
+    assert lib.savsr_conv_packed_floats(64, 64, 5) == -1
+
+
+def test_integer_grids_bit_exact_vs_reference(golden):
+    """get_HW (a1) + the floor term of the SATU coordinates (a12), product host code vs reference."""
+    for sc in YAML_SCALES:
+        for (h, w) in GRID_SIZES:
+            key = f"grid/{sc[0]}_{sc[1]}/{h}x{w}"
+            H, W = E.get_hw(h, w, sc)
+            assert [H, W] == golden[key + "/HW"].tolist()
+            assert np.array_equal(E.satu_axis_tables(H, h, sc[0])[1].astype(np.int16), golden[key + "/fh"])
+            assert np.array_equal(E.satu_axis_tables(W, w, sc[1])[1].astype(np.int16), golden[key + "/fw"])
+
+
+def test_axis_tables_match_oracle_bitwise():
+    from oracle import savsr_oracle as O
+    for sc in [(4, 4), (1.5, 4), (3.9, 3.9), (2.95, 3.75), (1.1, 1.1)]:
+        h, w = 45, 64
+        H, W, ch, cw, _, _ = O.satu_coords(h, w, sc)
+        a = E.satu_axis_tables(H, h, sc[0])
+        b = E.satu_axis_tables(W, w, sc[1])
+        assert np.array_equal(a[0], ch.numpy()) and np.array_equal(b[0], cw.numpy())
+        # normalised base grid of grid_sample (savsr_arch.py:270-280)
+        g = torch.Tensor(np.arange(W, dtype=np.float64))
+        g = (g + 0.5) / sc[1] - 0.5
+        g = g * 2 / (w - 1) - 1
+        assert np.array_equal(b[2], g.numpy())
+
+
+def test_registry_and_state_dict_surface():
+    net = savsr_amd.build_network(dict(type="SAVSR", num_in_ch=3, num_feat=64, num_frame=7, slid_win=3, fusion_win=5,
+                                       interval=0, w1_num_block=4, w2_num_block=2, n_resgroups=4, n_resblocks=8,
+                                       center_frame_idx=None))
+    assert type(net).__name__ == "SAVSR" and "SAVSR" in savsr_amd.ARCH_REGISTRY
+    assert synth.manifest_of(net.state_dict()) == synth.load_manifest()        # 791 keys, shapes, order
+    assert sum(p.numel() for p in net.parameters()) == 18890044
+    net.load_state_dict(synth.synth_state_dict(), strict=True)
+    net.set_scale(3)
+    assert net.scale == (3, 3)
+    with pytest.raises(KeyError):
+        savsr_amd.ARCH_REGISTRY.get("NoSuchArch")
+    assert "OSConv2d" in str(net)
+
+
+def test_no_cpu_fallback():
+    net = savsr_amd.SAVSR().eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 7, 3, 8, 8))
+    with pytest.raises(RuntimeError, match="inference path only"):
+        savsr_amd.SAVSR().train()(torch.zeros(1, 7, 3, 8, 8))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "savsr_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f
