@@ -27,6 +27,18 @@ LR_H, LR_W, SCALE = 180, 320, (4, 4)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def effective_cpus():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(sd, threads):
     """Oracle (CPU restatement of the reference path, kind='port') on a bounded sample: one frame of a
     quarter-area crop (7x3x90x160, x4 -> 360x640) of the workload clip."""
@@ -128,7 +140,7 @@ def main():
                          "algorithmic_bytes": alg_bytes, "avg_ms": round(1e3 * satu_avg_s, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            threads = effective_cpus()
             cb, ref, lq_c = cpu_baseline(sd, threads)
             got = net(lq_c.to(dev))
             cb["gpu_vs_oracle_max_abs_on_sample"] = float((got.cpu() - ref).abs().max())

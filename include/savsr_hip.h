@@ -13,7 +13,8 @@
  *     global mutable state => re-entrant across streams/threads and hipGraph-capturable;
  *   - return 0 = ok, <0 = invalid argument (SAVSR_E_*), >0 = hipError_t of the failed launch;
  *     the message is available from savsr_last_error() (thread-local);
- *   - all tensors fp32, channel-planar ([C][h][w]) unless stated otherwise;
+ *   - LR feature maps are fp32 channel-last ([h][w][C]); the clip, the SATU output and the result
+ *     are channel-planar ([C][h][w]);
  *   - output sizes H, W are computed by the CALLER with Python round() so that get_HW
  *     (savsr_arch.py:745-751) stays bit-exact.
  */
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 1
+#define SAVSR_ABI_VERSION 2
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -45,70 +46,78 @@ const char* savsr_last_error(void);
 int savsr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
- * Dense conv (3x3 pad 1, or 1x1), stride 1, as an fp32-MFMA implicit GEMM with a fused
- * epilogue.  Replaces every nn.Conv2d / F.conv2d on the path:
+ * Feature-map layout: every LR-resolution feature map is CHANNEL-LAST fp32, [h][w][C], addressed
+ * as base + (y*w + x)*pix + c where `pix` (floats between pixels, multiple of 4) may exceed the
+ * number of channels used, so a tensor can be read or written as a channel slice of a wider one.
+ *
+ * Dense conv (3x3 pad 1, or 1x1), stride 1: implicit GEMM on v_mfma_f32_32x32x16_bf16 with
+ * split-bf16 ("bf16x3": hi*hi + hi*lo + lo*hi, fp32 accumulate) operands and a fused epilogue.
+ * Replaces every nn.Conv2d / F.conv2d on the path:
  *   WindowUnit_l1/l2 convs   savsr_arch.py:429-442,456-462,480-483,488,498
  *   ResidualBlock convs      savsr_arch.py:388-397,402-415  (cat-free: the `torch.cat` inputs
  *                            of :404,:412,:462,:498,:721 are passed as separate sources)
  *   OSConv2d dynamic conv    savsr_arch.py:156-171 (weights produced on device by
- *                            savsr_osconv_aggregate; gates folded into the weights, :148-149)
+ *                            savsr_osconv_weights; gates folded into the weights, :148-149)
  *   OSAdapt mask convs       savsr_arch.py:189-206 (eval BatchNorm folded by the caller)
  *   RCAB / ResidualGroup     savsr_arch.py:541-543,567, conv_last :733, h_win_conv_h :723
  *
  *   y   = act( sum_{src,ci,ky,kx} W[co][ci][ky][kx] * in[ci](y+ky-p, x+kx-p) + bias[co] )
- *   out = y * (mul_px ? mul_px[y][x] : 1) + (res1 ? res1[co][y][x] : 0)
- *                                         + (res2 ? res2_scale * res2[co][y][x] : 0)
- * Zero padding outside [0,h) x [0,w).  The input channel axis is the concatenation of
- * `nsrc` sources of `src_ch` channels each.
+ *   out = y * (mul_px ? mul_px[y*w+x] : 1) + (res1 ? res1[px][co] : 0) + (res2 ? res2_scale*res2[px][co] : 0)
+ * Zero padding outside [0,h) x [0,w).  The input channel axis is the concatenation of `nsrc`
+ * sources of `src_ch` channels each (src_ch a multiple of 16; of 32 for 1x1).
  * ------------------------------------------------------------------------------------------ */
 typedef struct savsr_conv_desc {
-    const float* src[SAVSR_MAX_SRC];   /* device pointers, each [src_ch][h][w] with the strides below */
-    int64_t      src_plane[SAVSR_MAX_SRC]; /* floats between channels */
-    int32_t      src_row[SAVSR_MAX_SRC];   /* floats between rows     */
+    const float* src[SAVSR_MAX_SRC];   /* device pointers (channel offset already applied) */
+    int32_t      src_pix[SAVSR_MAX_SRC];   /* floats between pixels of each source */
     int32_t      nsrc;
     int32_t      src_ch;
     int32_t      h, w;
     int32_t      cin;                  /* = nsrc * src_ch */
     int32_t      cout;
     int32_t      ksize;                /* 1 or 3 */
-    const float* wpacked;              /* device; layout of savsr_conv_packed_floats()/pack_index() */
+    const void*  wpacked;              /* device; split-bf16 weight image, see savsr_conv_pack_index() */
     const float* bias;                 /* [cout] or NULL */
     int32_t      act;
     float        slope;
-    const float* mul_px;               /* [h][w] (row stride w) or NULL   -- OSAdapt mask, :214 */
-    const float* res1;                 /* [cout][h][w] or NULL, strides = out strides            */
-    const float* res2;                 /* [cout][h][w] or NULL, strides = out strides            */
+    const float* mul_px;               /* [h*w] or NULL                   -- OSAdapt mask, :214 */
+    const float* res1; int32_t res1_pix;   /* or NULL */
+    const float* res2; int32_t res2_pix;   /* or NULL */
     float        res2_scale;           /* gamma (savsr_arch.py:732)                              */
-    float*       out;                  /* [cout][h][w] */
-    int64_t      out_plane;
-    int32_t      out_row;
+    float*       out;                  /* channel offset already applied */
+    int32_t      out_pix;
 } savsr_conv_desc;
 
-/* Number of floats of the packed weight buffer for a (cout, cin, ksize) conv. */
-int64_t savsr_conv_packed_floats(int cout, int cin, int ksize);
-/* Index into the packed buffer of W[co][ci][ky*ksize+kx]; entries never addressed are padding
- * and must be zero.  (Host helper; the Python side packs with the same formula.) */
+/* Elements PER PART (hi or lo) of the weight image of a (cout, cin, ksize) conv; the bf16 image
+ * holds 2x that many 2-byte elements.  -1 for unsupported shapes. */
+int64_t savsr_conv_packed_elems(int cout, int cin, int ksize);
+/* Position p of W[co][ci][ky*ksize+kx] inside one part.  The image interleaves parts in groups of
+ * 512 elements (one (tap, kstep, 32-row tile) MFMA A operand): bf16 index of the hi value is
+ * (p/512)*1024 + p%512, of the lo value (p/512)*1024 + 512 + p%512.  An fp32 kernel bank for
+ * savsr_osconv_weights stores W at index p directly.  Unaddressed entries must be zero. */
 int64_t savsr_conv_pack_index(int cout, int cin, int ksize, int co, int ci, int tap);
 int savsr_conv2d(const savsr_conv_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Per-channel spatial mean over the concatenation of sources:  AdaptiveAvgPool2d(1)
- * (savsr_arch.py:129,146 for OSConv; :515 for RCAN ChannelAttention).  mean: [nsrc*src_ch].
+ * Per-channel partial sums for the global average pools (AdaptiveAvgPool2d(1),
+ * savsr_arch.py:129,146 for OSConv; :515 for RCAN): partial[blk][s*src_ch + c] over `nblk`
+ * pixel ranges; consumers add the partials in block order and scale by 1/(h*w).
  * ------------------------------------------------------------------------------------------ */
-int savsr_channel_mean(const float* const* src, const int64_t* src_plane, const int32_t* src_row,
-                       int nsrc, int src_ch, int h, int w, float* mean, void* stream);
+int savsr_channel_sums(const float* const* src, const int32_t* src_pix, int nsrc, int src_ch, int64_t npx,
+                       int nblk, float* partial, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * OSConv scale routing + ScaleAttention (savsr_arch.py:143-151, 91-96, 69-89):
+ * OSConv scale routing + ScaleAttention + kernel aggregation (savsr_arch.py:143-163, 91-96, 69-89):
  *   v  = ReLU(L2 ReLU(L1 [1/sh, 1/sw, mean] + c1) + c2)
  *   a  = ReLU(bn_scale * (Wfc v) + bn_shift)            (eval BatchNorm folded by the caller)
- *   att = [ ca = sigmoid(Wc a + bc) (cin) | fa = sigmoid(Wf a + bf) (cout) |
- *           sa = sigmoid(Ws a + bs) (9)   | ka = softmax(Wk a + bk) (knum) ]
+ *   ca = sigmoid(Wc a + bc) (cin), fa = sigmoid(Wf a + bf) (cout), sa = sigmoid(Ws a + bs) (9),
+ *   ka = softmax(Wk a + bk) (knum)
+ *   W''[co][ci][tap] = fa[co] * ca[ci] * sa[tap] * sum_k ka[k] * W[k][co][ci][tap]
+ * written as the split-bf16 weight image savsr_conv2d consumes (three launches, no host sync).
  * ------------------------------------------------------------------------------------------ */
 typedef struct savsr_osconv_attn_desc {
     int32_t cin, cout, hidden /* A */, knum /* 8 */;
     float   inv_sh, inv_sw;
-    const float* mean;                       /* [cin] */
+    const float* partial; int32_t nblk; float inv_n;   /* pooled input: savsr_channel_sums output, 1/(h*w) */
     const float* l1_w; const float* l1_b;    /* [2cin][cin+2], [2cin] */
     const float* l2_w; const float* l2_b;    /* [cin][2cin],   [cin]  */
     const float* fc_w;                       /* [A][cin] */
@@ -117,29 +126,28 @@ typedef struct savsr_osconv_attn_desc {
     const float* fl_w; const float* fl_b;    /* [cout][A], [cout] */
     const float* sp_w; const float* sp_b;    /* [9][A],    [9]    */
     const float* kn_w; const float* kn_b;    /* [knum][A], [knum] */
-    float* att;                              /* [cin + cout + 9 + knum] */
+    float* v1; float* v2;                    /* scratch [2cin], [cin] */
+    const float* bank;                       /* [knum][packed_elems] fp32, index = savsr_conv_pack_index */
+    int64_t nunits;                          /* packed_elems / 8 */
+    void*  wimg_out;                         /* split-bf16 weight image, 2 * packed_elems * 2 bytes */
+    float* att;                              /* optional [cin + cout + 9 + knum] = ca | fa | sa | ka */
 } savsr_osconv_attn_desc;
-int savsr_osconv_attention(const savsr_osconv_attn_desc* d, void* stream);
-
-/* W''[co][ci][tap] = fa[co] * ca[ci] * sa[tap] * sum_k ka[k] * W[k][co][ci][tap]
- * (savsr_arch.py:156-163,171 folded, :148-149), produced directly in the packed conv layout.
- * bank_packed: [knum][savsr_conv_packed_floats(cout,cin,3)], each kernel packed like a conv. */
-int savsr_osconv_aggregate(const float* bank_packed, const float* att, int cin, int cout, int knum,
-                           float* wpacked_out, void* stream);
+int savsr_osconv_weights(const savsr_osconv_attn_desc* d, void* stream);
 
 /* RCAN ChannelAttention gate (savsr_arch.py:514-520): gate = sigmoid(W2 ReLU(W1 mean + b1) + b2) */
-int savsr_se_gate(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2,
-                  int c, int cmid, float* gate, void* stream);
-/* out = r * gate[c] + x   (savsr_arch.py:524,548-549); contiguous [c][n] */
-int savsr_scale_residual(const float* r, const float* gate, const float* x, float* out,
-                         int c, int64_t n, void* stream);
+int savsr_se_gate(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
+                  const float* w2, const float* b2, int c, int cmid, float* gate, void* stream);
+/* out[px][c] = r[px][c] * gate[c] + x[px][c]   (savsr_arch.py:524,548-549); contiguous [npx][c] */
+int savsr_scale_residual(const float* r, const float* gate, const float* x, float* out, int c, int64_t npx, void* stream);
 
-/* nn.AvgPool2d(2) (savsr_arch.py:193): [c][h][w] -> [c][h/2][w/2], h and w even, contiguous. */
+/* nn.AvgPool2d(2) (savsr_arch.py:193): [h][w][c] -> [h/2][w/2][c], h and w even, contiguous. */
 int savsr_avgpool2(const float* in, float* out, int c, int h, int w, void* stream);
-/* nn.Upsample(scale_factor=2, bilinear, align_corners=False) (savsr_arch.py:202). */
+/* nn.Upsample(scale_factor=2, bilinear, align_corners=False) (savsr_arch.py:202), channel-last. */
 int savsr_upsample2x(const float* in, float* out, int c, int h, int w, void* stream);
-/* SAVSR.pad_spatial (savsr_arch.py:670-690): reflect-pad right/bottom; n planes [h][w]->[hp][wp]. */
-int savsr_reflect_pad(const float* in, float* out, int n, int h, int w, int hp, int wp, void* stream);
+/* WindowUnit_l1 input windows (savsr_arch.py:448-454, :661-668) with SAVSR.pad_spatial's reflect
+ * padding (:670-690) folded in.  lq: [T][3][h][w] planar -> out: [T-2][hp][wp][16] channel-last,
+ * channels = frame t | frame t-1 | frame t+1 | 7 zeros for window centre t = position + 1. */
+int savsr_pack_windows(const float* lq, float* out, int T, int h, int w, int hp, int wp, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * SATU = STAUpsample.forward (savsr_arch.py:315-376), restructured:
@@ -156,10 +164,10 @@ int savsr_reflect_pad(const float* in, float* out, int n, int h, int w, int hp, 
 
 typedef struct savsr_satu_weights {      /* all device pointers; packed by the caller */
     const float* body0_w; const float* body0_b;   /* [64][4], [64]   savsr_arch.py:245 */
-    const float* body2_w; const float* body2_b;   /* [64][64], [64]  :247 */
+    const float* body2_w; const float* body2_b;   /* [64 in][64 out] (transposed), [64]  :247 */
     const float* head_w;  const float* head_b;    /* [8][64], [8]: routing(4) | offset(2) | st_offset(2)  :252,256,257 */
-    const float* kconv_w; const float* kconv_b;   /* packed [25][2][32 ks][64 lanes], [25][64]  :227 */
-    const float* proj_w;                          /* packed LR projections (Wa | Wb | C-stack) */
+    const void*  kconv_w; const float* kconv_b;   /* split-bf16 image [25][2][4 ks][part][64 lanes][8], fp32 [25][64]  :227 */
+    const void*  proj_w;                          /* split-bf16 image of the LR projections (Wa | Wb | C-stack) */
     const float* wbe_w;                           /* packed (Wb E_n): [2][16][64 lanes]        */
     const float* fusion_b;                        /* [64] :260 */
 } savsr_satu_weights;
@@ -170,9 +178,10 @@ int savsr_satu_phase_table(const savsr_satu_weights* wt, const float* uniq_ch, i
                            const float* uniq_cw, int n_uw, float inv_sw, float inv_sh,
                            float* table, void* stream);
 
-/* x, st: [64][h][w] with the given strides (crops of padded tensors, savsr_arch.py:737). */
+/* x, st: channel-last crops [h][w][64] of padded tensors (savsr_arch.py:737): element (y, x, c) at
+ * base + (y*row_px + x)*pix + c. */
 int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const float* st,
-                        int64_t plane, int32_t row, int h, int w, float* lrcat, void* stream);
+                        int32_t pix, int32_t row_px, int h, int w, float* lrcat, void* stream);
 
 /* gxn[W], gyn[H]: normalised base grid coordinates (savsr_arch.py:270-280) computed by the caller
  * in fp32; idx_h[H], idx_w[W]: index of each row/column's (coor_h, coor_w) value in the table.

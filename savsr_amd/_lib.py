@@ -15,6 +15,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
+ABI_VERSION = 2
 
 fptr = C.c_void_p   # raw device pointers travel as integers
 
@@ -22,15 +23,17 @@ fptr = C.c_void_p   # raw device pointers travel as integers
 class ConvDesc(C.Structure):
     _fields_ = [
         ("src", fptr * MAX_SRC),
-        ("src_plane", C.c_int64 * MAX_SRC),
-        ("src_row", C.c_int32 * MAX_SRC),
+        ("src_pix", C.c_int32 * MAX_SRC),
         ("nsrc", C.c_int32), ("src_ch", C.c_int32),
         ("h", C.c_int32), ("w", C.c_int32),
         ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32),
         ("wpacked", fptr), ("bias", fptr),
         ("act", C.c_int32), ("slope", C.c_float),
-        ("mul_px", fptr), ("res1", fptr), ("res2", fptr), ("res2_scale", C.c_float),
-        ("out", fptr), ("out_plane", C.c_int64), ("out_row", C.c_int32),
+        ("mul_px", fptr),
+        ("res1", fptr), ("res1_pix", C.c_int32),
+        ("res2", fptr), ("res2_pix", C.c_int32),
+        ("res2_scale", C.c_float),
+        ("out", fptr), ("out_pix", C.c_int32),
     ]
 
 
@@ -38,11 +41,13 @@ class OSConvAttnDesc(C.Structure):
     _fields_ = [
         ("cin", C.c_int32), ("cout", C.c_int32), ("hidden", C.c_int32), ("knum", C.c_int32),
         ("inv_sh", C.c_float), ("inv_sw", C.c_float),
-        ("mean", fptr),
+        ("partial", fptr), ("nblk", C.c_int32), ("inv_n", C.c_float),
         ("l1_w", fptr), ("l1_b", fptr), ("l2_w", fptr), ("l2_b", fptr),
         ("fc_w", fptr), ("bn_scale", fptr), ("bn_shift", fptr),
         ("ch_w", fptr), ("ch_b", fptr), ("fl_w", fptr), ("fl_b", fptr),
         ("sp_w", fptr), ("sp_b", fptr), ("kn_w", fptr), ("kn_b", fptr),
+        ("v1", fptr), ("v2", fptr),
+        ("bank", fptr), ("nunits", C.c_int64), ("wimg_out", fptr),
         ("att", fptr),
     ]
 
@@ -60,21 +65,19 @@ SIGNATURES = {
     "savsr_version": (C.c_char_p, []),
     "savsr_last_error": (C.c_char_p, []),
     "savsr_abi_version": (C.c_int, []),
-    "savsr_conv_packed_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "savsr_conv_packed_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "savsr_conv_pack_index": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "savsr_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
-    "savsr_channel_mean": (C.c_int, [C.POINTER(fptr), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int, C.c_int,
-                                     C.c_int, C.c_int, fptr, C.c_void_p]),
-    "savsr_osconv_attention": (C.c_int, [C.POINTER(OSConvAttnDesc), C.c_void_p]),
-    "savsr_osconv_aggregate": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
-    "savsr_se_gate": (C.c_int, [fptr, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, C.c_void_p]),
+    "savsr_channel_sums": (C.c_int, [C.POINTER(fptr), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int64, C.c_int, fptr, C.c_void_p]),
+    "savsr_osconv_weights": (C.c_int, [C.POINTER(OSConvAttnDesc), C.c_void_p]),
+    "savsr_se_gate": (C.c_int, [fptr, C.c_int, C.c_float, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, C.c_void_p]),
     "savsr_scale_residual": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int64, C.c_void_p]),
     "savsr_avgpool2": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "savsr_upsample2x": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "savsr_reflect_pad": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "savsr_pack_windows": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "savsr_satu_phase_table": (C.c_int, [C.POINTER(SatuWeights), fptr, C.c_int, fptr, C.c_int, C.c_float, C.c_float,
                                          fptr, C.c_void_p]),
-    "savsr_satu_lr_stage": (C.c_int, [C.POINTER(SatuWeights), fptr, fptr, C.c_int64, C.c_int32, C.c_int, C.c_int,
+    "savsr_satu_lr_stage": (C.c_int, [C.POINTER(SatuWeights), fptr, fptr, C.c_int32, C.c_int32, C.c_int, C.c_int,
                                       fptr, C.c_void_p]),
     "savsr_satu_hr_upsample": (C.c_int, [C.POINTER(SatuWeights), fptr, C.c_int, C.c_int, fptr, C.c_int, fptr, fptr,
                                          fptr, fptr, C.c_int, C.c_int, fptr, C.c_void_p]),
@@ -108,7 +111,7 @@ def load() -> C.CDLL:
             raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.savsr_abi_version() != 1:
+    if lib.savsr_abi_version() != ABI_VERSION:
         raise HipLibraryError("libsavsr_hip.so ABI version mismatch")
     _lib = lib
     return lib

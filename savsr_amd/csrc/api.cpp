@@ -12,7 +12,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace savsr
 
 extern "C" {
-const char* savsr_version(void) { return "savsr_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* savsr_version(void) { return "savsr_hip 0.2 (gfx950, split-bf16 MFMA, channel-last)"; }
 const char* savsr_last_error(void) { return savsr::g_err; }
 int savsr_abi_version(void) { return SAVSR_ABI_VERSION; }
 }

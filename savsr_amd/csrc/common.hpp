@@ -24,9 +24,13 @@ inline int check_launch(const char* kernel) {
     return 0;
 }
 
-// packed conv weight geometry (shared by conv_mfma.hip and osconv.hip; mirrored in engine.py)
-__host__ __device__ inline int conv_ck(int ksize) { return ksize == 3 ? 8 : 32; }
+// conv tile / packed weight-image geometry (shared by conv_mfma.hip and osconv.hip; mirrored in engine.py)
+constexpr int CONV_TH = 8;     // pixel rows per block (one per wave)
+constexpr int CONV_TW = 32;    // pixel columns per block (= MFMA N)
+__host__ __device__ constexpr int conv_kc(int ksize) { return ksize == 3 ? 16 : 32; }   // input channels per K phase
 __host__ __device__ inline int conv_cot(int cout) { return cout > 32 ? 64 : 32; }
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1,122 +1,135 @@
-// Dense 3x3 / 1x1 convolution as an fp32-MFMA implicit GEMM (gfx950).
+// Dense 3x3 / 1x1 convolution on channel-last fp32 feature maps as an implicit GEMM on the
+// bf16 matrix cores with split-precision operands ("bf16x3", gfx950).
 //
-//   D[co][px] = sum_k A[co][k] * B[k][px],  k = (input channel, tap)
+//   D[co][px] = sum_k A[co][k] * B[k][px],   k = (tap, input channel)
 //
-// A = weights (pre-packed in exactly the order the lanes consume them), B = input pixels read
-// from an LDS tile with halo, D = v_mfma_f32_32x32x2_f32 accumulators whose column index is the
-// lane (= pixel), so the epilogue stores 32 consecutive pixels of one output channel per
-// half-wave: 128-B coalesced stores in the channel-planar layout.
+// Every fp32 operand v is split as v = hi + lo + O(2^-17 |v|) with hi = bf16(v), lo = bf16(v - hi),
+// and each product is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16 (3 MFMAs at 16x the fp32-MFMA rate = 5.3x the fp32 matrix peak).
+// The dropped lo*lo term is O(2^-18); measured end-to-end deviation from the fp32 oracle is
+// ~1e-5 max-abs, 1e-5 dB PSNR (DESIGN.md section "Numerics").
 //
-// Block = 256 threads = 4 waves; block tile = COT output channels x (4 rows x 32 cols) pixels;
-// wave w owns row w.  The reduction runs over chunks of CK input channels; each chunk's input
-// tile and weight slab are staged global -> registers -> LDS one chunk ahead of the MFMAs
-// (register-staged double buffer, one barrier per chunk).
+// Layout.  Activations: [h][w][C] fp32 ("channel-last"): the 8 consecutive k an MFMA lane needs
+// are 8 consecutive channels of one pixel = two 16-B loads, and the 4 consecutive output rows
+// a lane holds per accumulator quad are 4 consecutive channels = one 16-B store.
+// Weights: pre-split, pre-packed bf16 image in exactly the LDS order the lanes read it:
+//   [cob][chunk][tap][kstep][t][part(hi,lo)][lane 64][8]  (DMA-able 1-KiB pieces).
+//
+// Block = 512 threads = 8 waves, tile = 8 rows x 32 cols of pixels x (32 NT) output channels;
+// wave w owns row w.  The K loop runs over phases of KC input channels x all taps; the next
+// phase's weight slab and input tile (split to hi/lo on the fly) are staged global ->
+// registers -> LDS while the current phase's MFMAs run (one barrier per phase); within a phase
+// operand fragments are double-buffered in registers one (tap, kstep) ahead of their MFMAs.
 //
 // Replaces: every nn.Conv2d / F.conv2d of savsr_arch.py (see include/savsr_hip.h).
 #include "common.hpp"
 
 namespace savsr {
 
-constexpr int CONV_TH = 4;
-constexpr int CONV_TW = 32;
-
-
 struct ConvParams {
     const float* src[SAVSR_MAX_SRC];
-    long long src_plane[SAVSR_MAX_SRC];
-    int src_row[SAVSR_MAX_SRC];
+    int src_pix[SAVSR_MAX_SRC];      // floats between pixels of source s
     int nsrc, src_ch;
-    int h, w, cin, cout;
-    int nchunk;
-    const float* wpacked;
+    int h, w, cout, nchunk;
+    const unsigned short* wimg;
     const float* bias;
     int act;
     float slope;
     const float* mul_px;
     const float* res1;
+    int res1_pix;
     const float* res2;
+    int res2_pix;
     float res2_scale;
     float* out;
-    long long out_plane;
-    int out_row;
+    int out_pix;
 };
 
-template <int KS, int CK, int NT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
-    constexpr int TAPS = KS * KS;
-    constexpr int HALO = KS / 2;
-    constexpr int IR = CONV_TH + 2 * HALO;
-    constexpr int IC = CONV_TW + 2 * HALO;
-    constexpr int IN_N = CK * IR * IC;               // staged input floats per chunk
-    constexpr int COT = 32 * NT;
-    constexpr int W_N = TAPS * CK * COT;             // staged weight floats per chunk
-    constexpr int IN_IT = (IN_N + 255) / 256;
-    constexpr int W_IT = (W_N / 4 + 255) / 256;
-    constexpr int BUF = IN_N + W_N;
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(x[j] - (float)h);
+    }
+}
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int KS, int NT>
+__global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
+    constexpr int TAPS = KS * KS, HALO = KS / 2;
+    constexpr int KC = conv_kc(KS), KSTEPS = KC / 16;
+    constexpr int IR = CONV_TH + 2 * HALO, IC = CONV_TW + 2 * HALO, NPX = IR * IC;
+    constexpr int B_PART = KSTEPS * 2 * NPX;                 // 16-B units per part (hi or lo)
+    constexpr int B_UNITS = 2 * B_PART;
+    constexpr int W_UNITS = TAPS * KSTEPS * NT * 2 * 64;     // 16-B units per phase
+    constexpr int B_IT = (B_PART + 511) / 512;
+    constexpr int W_IT = (W_UNITS + 511) / 512;
+    constexpr int STEPS = TAPS * KSTEPS;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int half = lane >> 5;
-    const int px = lane & 31;
-    const int x0 = blockIdx.x * CONV_TW;
-    const int y0 = blockIdx.y * CONV_TH;
-    const int cob = blockIdx.z;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16x8* smem = reinterpret_cast<bf16x8*>(smem_raw);      // 16-B units: [2][B_UNITS] then [2][W_UNITS]
 
-    float in_reg[IN_IT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
+    const int x0 = blockIdx.x * CONV_TW, y0 = blockIdx.y * CONV_TH, cob = blockIdx.z;
+    const int per_src = p.src_ch / KC;
+
+    f32x4 b_reg[B_IT][2];
     f32x4 w_reg[W_IT];
 
     auto stage_load = [&](int chunk) {
+        const int s = chunk / per_src;
+        const int cb = (chunk - s * per_src) * KC;
+        const float* base = p.src[0];
+        int pix = p.src_pix[0];
+        if (s == 1) { base = p.src[1]; pix = p.src_pix[1]; }
+        if (s == 2) { base = p.src[2]; pix = p.src_pix[2]; }
+        if (s == 3) { base = p.src[3]; pix = p.src_pix[3]; }
+        if (s == 4) { base = p.src[4]; pix = p.src_pix[4]; }
 #pragma unroll
-        for (int i = 0; i < IN_IT; ++i) {
-            const int e = tid + i * 256;
-            float v = 0.f;
-            if (e < IN_N) {
-                const int ch = e / (IR * IC);
-                const int rem = e - ch * (IR * IC);
-                const int r = rem / IC;
-                const int c = rem - r * IC;
-                const int gy = y0 - HALO + r;
-                const int gx = x0 - HALO + c;
-                const int ci = chunk * CK + ch;
-                if (ci < p.cin && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
-                    const int s = ci / p.src_ch;
-                    const int lc = ci - s * p.src_ch;
-                    const float* base = p.src[0];
-                    long long pl = p.src_plane[0];
-                    int rw = p.src_row[0];
-                    if (s == 1) { base = p.src[1]; pl = p.src_plane[1]; rw = p.src_row[1]; }
-                    if (s == 2) { base = p.src[2]; pl = p.src_plane[2]; rw = p.src_row[2]; }
-                    if (s == 3) { base = p.src[3]; pl = p.src_plane[3]; rw = p.src_row[3]; }
-                    if (s == 4) { base = p.src[4]; pl = p.src_plane[4]; rw = p.src_row[4]; }
-                    v = base[(long long)lc * pl + (long long)gy * rw + gx];
+        for (int i = 0; i < B_IT; ++i) {
+            const int e = tid + i * 512;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+            if (e < B_PART) {
+                const int q = e / NPX;                      // kstep * 2 + khalf
+                const int pl = e - q * NPX;
+                const int r = pl / IC, c = pl - r * IC;
+                const int gy = y0 - HALO + r, gx = x0 - HALO + c;
+                if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
+                    const f32x4* g = reinterpret_cast<const f32x4*>(base + ((long long)gy * p.w + gx) * pix + cb + q * 8);
+                    v0 = g[0];
+                    v1 = g[1];
                 }
             }
-            in_reg[i] = v;
+            b_reg[i][0] = v0;
+            b_reg[i][1] = v1;
         }
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpacked + ((long long)cob * p.nchunk + chunk) * W_N);
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wimg) + ((long long)cob * p.nchunk + chunk) * W_UNITS;
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * 512;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < W_N / 4) v = wsrc[e];
+            if (e < W_UNITS) v = wsrc[e];
             w_reg[i] = v;
         }
     };
     auto stage_store = [&](int buf) {
-        float* in_l = smem + buf * BUF;
-        float* w_l = in_l + IN_N;
+        bf16x8* bl = smem + buf * B_UNITS;
+        f32x4* wl = reinterpret_cast<f32x4*>(smem + 2 * B_UNITS + buf * W_UNITS);
 #pragma unroll
-        for (int i = 0; i < IN_IT; ++i) {
-            const int e = tid + i * 256;
-            if (e < IN_N) in_l[e] = in_reg[i];
+        for (int i = 0; i < B_IT; ++i) {
+            const int e = tid + i * 512;
+            if (e < B_PART) {
+                bf16x8 hi, lo;
+                split8(b_reg[i][0], b_reg[i][1], hi, lo);
+                bl[e] = hi;
+                bl[B_PART + e] = lo;
+            }
         }
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) {
-            const int e = tid + i * 256;
-            if (e < W_N / 4) reinterpret_cast<f32x4*>(w_l)[e] = w_reg[i];
+            const int e = tid + i * 512;
+            if (e < W_UNITS) wl[e] = w_reg[i];
         }
     };
 
@@ -130,119 +143,175 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     stage_store(0);
     __syncthreads();
 
+    struct Frag { bf16x8 ah[NT], al[NT], bh, bl; };
+
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
         const int buf = chunk & 1;
         const bool more = chunk + 1 < p.nchunk;
         if (more) stage_load(chunk + 1);
 
-        const float* in_l = smem + buf * BUF;
-        const float* w_l = in_l + IN_N;
-        // lane's B base: channel `half` of pair 0, own row, own column
-        const float* bptr = in_l + half * (IR * IC) + wave * IC + px;
-        const float* aptr = w_l + half * COT + px;
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
+        const bf16x8* bl = smem + buf * B_UNITS;
+        const bf16x8* wl = smem + 2 * B_UNITS + buf * W_UNITS;
+        const bf16x8* bbase = bl + half * NPX + wave * IC + px;
+        const bf16x8* abase = wl + lane;
+
+        auto load_frag = [&](int s, Frag& f) {
+            const int tap = s / KSTEPS, ks = s - tap * KSTEPS;
             const int ky = tap / KS, kx = tap - ky * KS;
+            const int bo = ks * 2 * NPX + ky * IC + kx;
+            f.bh = bbase[bo];
+            f.bl = bbase[B_PART + bo];
 #pragma unroll
-            for (int cp = 0; cp < CK / 2; ++cp) {
-                const float b = bptr[(2 * cp) * (IR * IC) + ky * IC + kx];
+            for (int t = 0; t < NT; ++t) {
+                f.ah[t] = abase[((s * NT + t) * 2 + 0) * 64];
+                f.al[t] = abase[((s * NT + t) * 2 + 1) * 64];
+            }
+        };
+        auto mma = [&](const Frag& f) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float a = aptr[(tap * (CK / 2) + cp) * 2 * COT + t * 32];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-                }
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[t], f.bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bh, acc[t], 0, 0, 0);
+            }
+        };
+        Frag f0, f1;
+        load_frag(0, f0);
+#pragma unroll
+        for (int s = 0; s < STEPS; s += 2) {
+            if (s + 1 < STEPS) load_frag(s + 1, f1);
+            mma(f0);
+            if (s + 1 < STEPS) {
+                if (s + 2 < STEPS) load_frag(s + 2, f0);
+                mma(f1);
             }
         }
         if (more) stage_store(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue ---------------------------------------------------------------------
-    const int y = y0 + wave;
-    const int x = x0 + px;
+    // ---- epilogue: lane (pixel, half) holds channels 32 t + 8 g + 4 half + {0..3} in regs 4g..4g+3
+    const int y = y0 + wave, x = x0 + px;
     if (y >= p.h || x >= p.w) return;
-    const float mul = p.mul_px ? p.mul_px[(long long)y * p.w + x] : 1.f;
+    const long long pidx = (long long)y * p.w + x;
+    const float mul = p.mul_px ? p.mul_px[pidx] : 1.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cob * COT + t * 32 + acc_row(r, half);
-            if (co < p.cout) {
-                float v = acc[t][r];
-                if (p.bias) v += p.bias[co];
-                if (p.act == SAVSR_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == SAVSR_ACT_LRELU) v = v > 0.f ? v : v * p.slope;
-                else if (p.act == SAVSR_ACT_SIGMOID) v = sigmoidf_(v);
-                v *= mul;
-                const long long o = (long long)co * p.out_plane + (long long)y * p.out_row + x;
-                if (p.res1) v += p.res1[o];
-                if (p.res2) v += p.res2_scale * p.res2[o];
-                p.out[o] = v;
+        for (int g = 0; g < 4; ++g) {
+            const int co = cob * (32 * NT) + 32 * t + 8 * g + 4 * half;
+            if (co >= p.cout) continue;
+            float v[4] = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            const bool full = co + 3 < p.cout;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (p.bias && (full || co + i < p.cout)) v[i] += p.bias[co + i];
+                if (p.act == SAVSR_ACT_RELU) v[i] = fmaxf(v[i], 0.f);
+                else if (p.act == SAVSR_ACT_LRELU) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope;
+                else if (p.act == SAVSR_ACT_SIGMOID) v[i] = sigmoidf_(v[i]);
+                v[i] *= mul;
+            }
+            float* o = p.out + pidx * p.out_pix + co;
+            if (full) {
+                if (p.res1) {
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(p.res1 + pidx * p.res1_pix + co);
+                    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+                }
+                if (p.res2) {
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(p.res2 + pidx * p.res2_pix + co);
+                    v[0] += p.res2_scale * r[0]; v[1] += p.res2_scale * r[1]; v[2] += p.res2_scale * r[2]; v[3] += p.res2_scale * r[3];
+                }
+                f32x4 ov = {v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(o) = ov;
+            } else {
+                for (int i = 0; i < 4 && co + i < p.cout; ++i) {
+                    float vv = v[i];
+                    if (p.res1) vv += p.res1[pidx * p.res1_pix + co + i];
+                    if (p.res2) vv += p.res2_scale * p.res2[pidx * p.res2_pix + co + i];
+                    o[i] = vv;
+                }
             }
         }
     }
 }
 
-template <int KS, int CK, int NT>
+template <int KS, int NT>
 static int launch_conv(const ConvParams& p, hipStream_t st) {
-    constexpr int TAPS = KS * KS, HALO = KS / 2;
-    constexpr int IN_N = CK * (CONV_TH + 2 * HALO) * (CONV_TW + 2 * HALO);
-    constexpr int W_N = TAPS * CK * 32 * NT;
-    constexpr size_t lds = 2 * (IN_N + W_N) * sizeof(float);
-    static_assert(IN_N % 4 == 0, "weight slab must stay 16-byte aligned in LDS");
+    constexpr int TAPS = KS * KS, HALO = KS / 2, KC = conv_kc(KS), KSTEPS = KC / 16;
+    constexpr int NPX = (CONV_TH + 2 * HALO) * (CONV_TW + 2 * HALO);
+    constexpr size_t lds = 16ull * 2 * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64);
+    static bool attr_done = false;      // benign race: idempotent attribute set
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("conv: hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_done = true;
+    }
     dim3 grid((p.w + CONV_TW - 1) / CONV_TW, (p.h + CONV_TH - 1) / CONV_TH, (p.cout + 32 * NT - 1) / (32 * NT));
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, CK, NT>), grid, dim3(256), lds, st, p);
-    return check_launch("conv_mfma_kernel");
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT>), grid, dim3(512), lds, st, p);
+    return check_launch("conv_bf16x3_kernel");
 }
 
 }  // namespace savsr
 
 using namespace savsr;
 
-extern "C" int64_t savsr_conv_packed_floats(int cout, int cin, int ksize) {
+extern "C" int64_t savsr_conv_packed_elems(int cout, int cin, int ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return -1;
-    const int ck = conv_ck(ksize), cot = conv_cot(cout);
-    const int64_t nchunk = (cin + ck - 1) / ck, ncob = (cout + cot - 1) / cot;
-    return ncob * nchunk * ksize * ksize * ck * cot;
+    const int kc = conv_kc(ksize), cot = conv_cot(cout);
+    if (cin % kc) return -1;
+    const int64_t nchunk = cin / kc, ncob = (cout + cot - 1) / cot;
+    return ncob * nchunk * ksize * ksize * kc * cot;            // per part (hi or lo)
 }
 
+// Position of W[co][ci][tap] inside ONE part of the image (in elements); the hi part of a
+// (cob, chunk, tap, kstep, t) group is followed by its lo part, so the bf16 image index is
+//   group * 1024 + part * 512 + (index % 512)   with group = index / 512.
 extern "C" int64_t savsr_conv_pack_index(int cout, int cin, int ksize, int co, int ci, int tap) {
-    const int ck = conv_ck(ksize), cot = conv_cot(cout);
-    const int64_t nchunk = (cin + ck - 1) / ck;
-    const int cob = co / cot, col = co % cot;
-    const int chunk = ci / ck, cl = ci % ck;
-    const int cp = cl / 2, hh = cl % 2;
-    return ((((int64_t)(cob * nchunk + chunk) * (ksize * ksize) + tap) * (ck / 2) + cp) * 2 + hh) * cot + col;
+    const int kc = conv_kc(ksize), cot = conv_cot(cout), nt = cot / 32, ksteps = kc / 16;
+    const int64_t nchunk = cin / kc;
+    const int cob = co / cot, col = co % cot, t = col / 32, row = col % 32;
+    const int chunk = ci / kc, cl = ci % kc, ks = cl / 16, kh = (cl % 16) / 8, j = cl % 8;
+    const int64_t group = (((int64_t)(cob * nchunk + chunk) * (ksize * ksize) + tap) * ksteps + ks) * nt + t;
+    return group * 512 + (kh * 32 + row) * 8 + j;
 }
 
 extern "C" int savsr_conv2d(const savsr_conv_desc* d, void* stream) {
     if (!d) return fail_arg("conv: null descriptor");
     if (d->ksize != 1 && d->ksize != 3) return fail_arg("conv: ksize must be 1 or 3");
-    if (d->nsrc < 1 || d->nsrc > SAVSR_MAX_SRC || d->src_ch < 1) return fail_arg("conv: nsrc/src_ch");
+    const int kc = conv_kc(d->ksize);
+    if (d->nsrc < 1 || d->nsrc > SAVSR_MAX_SRC || d->src_ch < kc || d->src_ch % kc) return fail_arg("conv: nsrc / src_ch (multiple of 16, or 32 for 1x1)");
     if (d->cin != d->nsrc * d->src_ch) return fail_arg("conv: cin != nsrc*src_ch");
     if (d->h < 1 || d->w < 1 || d->cout < 1) return fail_arg("conv: shape");
     if (!d->wpacked || !d->out) return fail_arg("conv: null weights/out");
-    if ((reinterpret_cast<uintptr_t>(d->wpacked) & 15) != 0) {
-        set_error("conv: wpacked must be 16-byte aligned");
-        return SAVSR_E_ALIGN;
-    }
+    uintptr_t al = reinterpret_cast<uintptr_t>(d->wpacked) | reinterpret_cast<uintptr_t>(d->out) | (uintptr_t)(d->out_pix * 4);
     ConvParams p;
     for (int i = 0; i < SAVSR_MAX_SRC; ++i) {
         const bool on = i < d->nsrc;
         if (on && !d->src[i]) return fail_arg("conv: null source");
         p.src[i] = on ? d->src[i] : nullptr;
-        p.src_plane[i] = on ? d->src_plane[i] : 0;
-        p.src_row[i] = on ? d->src_row[i] : 0;
+        p.src_pix[i] = on ? d->src_pix[i] : 0;
+        if (on) al |= reinterpret_cast<uintptr_t>(d->src[i]) | (uintptr_t)(d->src_pix[i] * 4);
+    }
+    if (d->res1) al |= reinterpret_cast<uintptr_t>(d->res1) | (uintptr_t)(d->res1_pix * 4);
+    if (d->res2) al |= reinterpret_cast<uintptr_t>(d->res2) | (uintptr_t)(d->res2_pix * 4);
+    if ((al & 15) && d->cout >= 4) {
+        set_error("conv: sources / residuals / out / weights must be 16-byte aligned with pixel strides multiple of 4 floats");
+        return SAVSR_E_ALIGN;
     }
     p.nsrc = d->nsrc; p.src_ch = d->src_ch;
-    p.h = d->h; p.w = d->w; p.cin = d->cin; p.cout = d->cout;
-    const int ck = conv_ck(d->ksize);
-    p.nchunk = (d->cin + ck - 1) / ck;
-    p.wpacked = d->wpacked; p.bias = d->bias; p.act = d->act; p.slope = d->slope;
-    p.mul_px = d->mul_px; p.res1 = d->res1; p.res2 = d->res2; p.res2_scale = d->res2_scale;
-    p.out = d->out; p.out_plane = d->out_plane; p.out_row = d->out_row;
+    p.h = d->h; p.w = d->w; p.cout = d->cout;
+    p.nchunk = d->cin / kc;
+    p.wimg = reinterpret_cast<const unsigned short*>(d->wpacked);
+    p.bias = d->bias; p.act = d->act; p.slope = d->slope;
+    p.mul_px = d->mul_px; p.res1 = d->res1; p.res1_pix = d->res1_pix; p.res2 = d->res2; p.res2_pix = d->res2_pix;
+    p.res2_scale = d->res2_scale;
+    p.out = d->out; p.out_pix = d->out_pix;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool wide = conv_cot(d->cout) == 64;
-    if (d->ksize == 3) return wide ? launch_conv<3, 8, 2>(p, st) : launch_conv<3, 8, 1>(p, st);
-    return wide ? launch_conv<1, 32, 2>(p, st) : launch_conv<1, 32, 1>(p, st);
+    if (d->ksize == 3) return wide ? launch_conv<3, 2>(p, st) : launch_conv<3, 1>(p, st);
+    return wide ? launch_conv<1, 2>(p, st) : launch_conv<1, 1>(p, st);
 }

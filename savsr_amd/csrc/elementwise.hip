@@ -1,18 +1,19 @@
-// Small bandwidth-bound helpers of the OSAdapt mask branch and the input padding (gfx950).
+// Small bandwidth-bound helpers on channel-last maps (gfx950): the OSAdapt mask branch's
+// pool / upsample and the input-window packing (with the reflect padding folded in).
 #include "common.hpp"
 
 namespace savsr {
 
-// nn.AvgPool2d(2), savsr_arch.py:193
+// nn.AvgPool2d(2), savsr_arch.py:193;  [h][w][c] -> [h/2][w/2][c]
 __global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int c, int h, int w) {
     const int ho = h / 2, wo = w / 2;
     const long long n = (long long)c * ho * wo;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int x = (int)(i % wo);
-        const int y = (int)((i / wo) % ho);
-        const int ch = (int)(i / ((long long)wo * ho));
-        const float* p = in + ((long long)ch * h + 2 * y) * w + 2 * x;
-        out[i] = (p[0] + p[1] + p[w] + p[w + 1]) * 0.25f;
+        const int ch = (int)(i % c);
+        const int x = (int)((i / c) % wo);
+        const int y = (int)(i / ((long long)c * wo));
+        const float* p = in + (((long long)(2 * y) * w + 2 * x) * c) + ch;
+        out[i] = (p[0] + p[c] + p[(long long)w * c] + p[(long long)w * c + c]) * 0.25f;
     }
 }
 
@@ -32,30 +33,45 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
     const int ho = 2 * h, wo = 2 * w;
     const long long n = (long long)c * ho * wo;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int x = (int)(i % wo);
-        const int y = (int)((i / wo) % ho);
-        const int ch = (int)(i / ((long long)wo * ho));
+        const int ch = (int)(i % c);
+        const int x = (int)((i / c) % wo);
+        const int y = (int)(i / ((long long)c * wo));
         int y0, y1, x0, x1;
         float ly, lx;
         bilinear_src(y, 0.5f, h, y0, y1, ly);
         bilinear_src(x, 0.5f, w, x0, x1, lx);
-        const float* p = in + (long long)ch * h * w;
-        const float top = (1.f - lx) * p[y0 * w + x0] + lx * p[y0 * w + x1];
-        const float bot = (1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1];
+        const float* p = in + ch;
+        const float top = (1.f - lx) * p[((long long)y0 * w + x0) * c] + lx * p[((long long)y0 * w + x1) * c];
+        const float bot = (1.f - lx) * p[((long long)y1 * w + x0) * c] + lx * p[((long long)y1 * w + x1) * c];
         out[i] = (1.f - ly) * top + ly * bot;
     }
 }
 
-// F.pad(..., [0, pw, 0, ph], mode='reflect'), savsr_arch.py:681-690
-__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h, int w, int hp, int wp) {
-    const long long tot = (long long)n * hp * wp;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long long)gridDim.x * 256) {
-        const int x = (int)(i % wp);
-        const int y = (int)((i / wp) % hp);
-        const int pl = (int)(i / ((long long)wp * hp));
+// Input windows for WindowUnit_l1 (savsr_arch.py:448-454, generate_it :661-668) with
+// pad_spatial's reflect padding (:681-690) folded in.  lq: [T][3][h][w] planar;
+// out: [T-2][hp][wp][16] channel-last, position q <-> window centre t = q + 1:
+//   ch 0-2 = frame t (x_c), 3-5 = frame t-1, 6-8 = frame t+1 (x_sup), 9-15 = 0.
+__global__ __launch_bounds__(256) void pack_windows_kernel(const float* __restrict__ lq, float* __restrict__ out, int T, int h, int w, int hp, int wp) {
+    const long long n = (long long)(T - 2) * hp * wp * 4;        // float4 units
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int q4 = (int)(i & 3);
+        const long long pi = i >> 2;
+        const int x = (int)(pi % wp);
+        const int y = (int)((pi / wp) % hp);
+        const int q = (int)(pi / ((long long)wp * hp));
         const int sx = x < w ? x : 2 * (w - 1) - x;
         const int sy = y < h ? y : 2 * (h - 1) - y;
-        out[i] = in[((long long)pl * h + sy) * w + sx];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = 4 * q4 + j;
+            if (ch < 9) {
+                const int which = ch / 3, comp = ch - 3 * which;
+                const int frame = (q + 1) + (which == 0 ? 0 : (which == 1 ? -1 : 1));
+                v[j] = lq[(((long long)frame * 3 + comp) * h + sy) * w + sx];
+            }
+        }
+        reinterpret_cast<f32x4*>(out)[i] = v;
     }
 }
 
@@ -84,9 +100,10 @@ extern "C" int savsr_upsample2x(const float* in, float* out, int c, int h, int w
     return check_launch("upsample2x_kernel");
 }
 
-extern "C" int savsr_reflect_pad(const float* in, float* out, int n, int h, int w, int hp, int wp, void* stream) {
-    if (!in || !out) return fail_arg("reflect_pad: null pointer");
-    if (n < 1 || h < 2 || w < 2 || hp < h || wp < w || hp > h + 1 || wp > w + 1) return fail_arg("reflect_pad: shape");
-    hipLaunchKernelGGL(reflect_pad_kernel, dim3(grid_for((long long)n * hp * wp)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, n, h, w, hp, wp);
-    return check_launch("reflect_pad_kernel");
+extern "C" int savsr_pack_windows(const float* lq, float* out, int T, int h, int w, int hp, int wp, void* stream) {
+    if (!lq || !out) return fail_arg("pack_windows: null pointer");
+    if (T < 3 || h < 2 || w < 2 || hp < h || wp < w || hp > h + 1 || wp > w + 1) return fail_arg("pack_windows: shape");
+    if (reinterpret_cast<uintptr_t>(out) & 15) { set_error("pack_windows: out must be 16-byte aligned"); return SAVSR_E_ALIGN; }
+    hipLaunchKernelGGL(pack_windows_kernel, dim3(grid_for((long long)(T - 2) * hp * wp * 4)), dim3(256), 0, static_cast<hipStream_t>(stream), lq, out, T, h, w, hp, wp);
+    return check_launch("pack_windows_kernel");
 }

@@ -1,92 +1,110 @@
-// OSConv side kernels (gfx950): global average pool, scale routing + ScaleAttention MLP,
-// gated aggregation of the 8 kernel banks into one packed conv weight, RCAN SE gate.
-// HBM/L2-bound byte work -- no MFMA here on purpose.
+// OSConv side kernels on channel-last feature maps (gfx950): per-channel partial sums for the
+// global average pools, the scale-routing MLP + ScaleAttention spread over many workgroups, the
+// gated aggregation of the 8 kernel banks straight into the conv's split-bf16 weight image, and
+// the RCAN squeeze-excite gate.  HBM/L2-bound byte work -- no MFMA here on purpose.
 #include "common.hpp"
 
 namespace savsr {
 
-
-struct MeanParams {
+// ------------------------------------------------------------------------------------------
+// partial[blk][s * src_ch + c] = sum over the block's pixels of src_s[px][c]
+// (AdaptiveAvgPool2d(1), savsr_arch.py:129,146,515; the consumer sums the partials in block
+//  order and divides by h*w, so the result is deterministic.)
+// ------------------------------------------------------------------------------------------
+struct SumParams {
     const float* src[SAVSR_MAX_SRC];
-    long long plane[SAVSR_MAX_SRC];
-    int row[SAVSR_MAX_SRC];
-    int src_ch, h, w;
-    float* mean;
+    int pix[SAVSR_MAX_SRC];
+    int src_ch, npx, nblk;
+    float* partial;
 };
 
-// one block per channel; AdaptiveAvgPool2d(1) (savsr_arch.py:129,146,515)
-__global__ __launch_bounds__(256) void channel_mean_kernel(const MeanParams p) {
-    const int c = blockIdx.x;
-    const int s = c / p.src_ch;
-    const int lc = c - s * p.src_ch;
+__global__ __launch_bounds__(256) void channel_sums_kernel(const SumParams p) {
+    __shared__ f32x4 red[256];
+    const int s = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const float* base = p.src[0];
-    long long pl = p.plane[0];
-    int rw = p.row[0];
-    if (s == 1) { base = p.src[1]; pl = p.plane[1]; rw = p.row[1]; }
-    if (s == 2) { base = p.src[2]; pl = p.plane[2]; rw = p.row[2]; }
-    if (s == 3) { base = p.src[3]; pl = p.plane[3]; rw = p.row[3]; }
-    if (s == 4) { base = p.src[4]; pl = p.plane[4]; rw = p.row[4]; }
-    base += (long long)lc * pl;
+    int pix = p.pix[0];
+    if (s == 1) { base = p.src[1]; pix = p.pix[1]; }
+    if (s == 2) { base = p.src[2]; pix = p.pix[2]; }
+    if (s == 3) { base = p.src[3]; pix = p.pix[3]; }
+    if (s == 4) { base = p.src[4]; pix = p.pix[4]; }
+    const int G = p.src_ch / 4;              // float4 groups per pixel (divides 256)
+    const int cg = tid % G, pl = tid / G, PL = 256 / G;
+    const int per = (p.npx + p.nblk - 1) / p.nblk;
+    const int p0 = blk * per, p1 = min(p.npx, p0 + per);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int q = p0 + pl; q < p1; q += PL) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)q * pix + 4 * cg);
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < G) {
+        f32x4 t = red[tid];
+        for (int k = 1; k < PL; ++k) {
+            const f32x4 v = red[tid + k * G];
+            t[0] += v[0]; t[1] += v[1]; t[2] += v[2]; t[3] += v[3];
+        }
+        const int ctot = gridDim.y * p.src_ch;
+        *reinterpret_cast<f32x4*>(p.partial + (long long)blk * ctot + s * p.src_ch + 4 * tid) = t;
+    }
+}
+
+__device__ __forceinline__ float mean_from_partials(const float* partial, int nblk, int ctot, int c, float inv_n) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * ctot + c];
+    return s * inv_n;
+}
+
+__device__ __forceinline__ float wave_dot(const float* __restrict__ w, const float* v, int n, int lane) {
     float acc = 0.f;
-    const int n = p.h * p.w;
-    if (rw == p.w && ((reinterpret_cast<uintptr_t>(base) & 15) == 0) && (n & 3) == 0) {
-        const f32x4* b4 = reinterpret_cast<const f32x4*>(base);
-        for (int i = threadIdx.x; i < n / 4; i += 256) {
-            const f32x4 v = b4[i];
-            acc += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-    } else {
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int y = i / p.w, x = i - y * p.w;
-            acc += base[(long long)y * rw + x];
-        }
-    }
-    __shared__ float part[4];
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) p.mean[c] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)n;
+    for (int c = lane; c < n; c += 64) acc += w[c] * v[c];
+    return wave_sum(acc);
 }
 
-// y[r] = act(W[r][:] . v + b[r]) for r in [0, rows): one wave per row, lanes across columns.
-__device__ __forceinline__ void block_matvec(const float* __restrict__ W, const float* __restrict__ b,
-                                             const float* v, float* y, int rows, int cols, bool relu) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int r = wave; r < rows; r += nw) {
-        const float* wr = W + (long long)r * cols;
-        float acc = 0.f;
-        for (int c = lane; c < cols; c += 64) acc += wr[c] * v[c];
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            acc += b ? b[r] : 0.f;
-            y[r] = relu ? fmaxf(acc, 0.f) : acc;
-        }
-    }
-}
-
-// savsr_arch.py:143-151 (scale routing) + :91-96 / :69-89 (ScaleAttention); single block.
-__global__ __launch_bounds__(1024) void osconv_attention_kernel(const savsr_osconv_attn_desc d) {
-    extern __shared__ float sm[];
-    float* v0 = sm;                       // [cin + 2]
-    float* v1 = v0 + d.cin + 2;           // [2 cin]
-    float* v2 = v1 + 2 * d.cin;           // [cin]
-    float* a = v2 + d.cin;                // [A]
-    float* kl = a + d.hidden;             // [knum] kernel logits
-    const int tid = threadIdx.x;
+// scale routing layer 1 (savsr_arch.py:123-125,143-146): v1 = ReLU(L1 [1/sh, 1/sw, mean] + c1)
+__global__ __launch_bounds__(512) void osconv_l1_kernel(const savsr_osconv_attn_desc d) {
+    extern __shared__ float v0[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { v0[0] = d.inv_sh; v0[1] = d.inv_sw; }
-    for (int i = tid; i < d.cin; i += blockDim.x) v0[2 + i] = d.mean[i];
+    for (int i = tid; i < d.cin; i += 512) v0[2 + i] = mean_from_partials(d.partial, d.nblk, d.cin, i, d.inv_n);
     __syncthreads();
-    block_matvec(d.l1_w, d.l1_b, v0, v1, 2 * d.cin, d.cin + 2, true);
+    const int r = blockIdx.x * 8 + wave;
+    if (r >= 2 * d.cin) return;
+    const float acc = wave_dot(d.l1_w + (long long)r * (d.cin + 2), v0, d.cin + 2, lane);
+    if (lane == 0) d.v1[r] = fmaxf(acc + d.l1_b[r], 0.f);
+}
+
+// scale routing layer 2 (savsr_arch.py:126-127): v2 = ReLU(L2 v1 + c2)
+__global__ __launch_bounds__(512) void osconv_l2_kernel(const savsr_osconv_attn_desc d) {
+    extern __shared__ float v1[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * d.cin; i += 512) v1[i] = d.v1[i];
     __syncthreads();
-    block_matvec(d.l2_w, d.l2_b, v1, v2, d.cin, 2 * d.cin, true);
+    const int r = blockIdx.x * 8 + wave;
+    if (r >= d.cin) return;
+    const float acc = wave_dot(d.l2_w + (long long)r * (2 * d.cin), v1, 2 * d.cin, lane);
+    if (lane == 0) d.v2[r] = fmaxf(acc + d.l2_b[r], 0.f);
+}
+
+// ScaleAttention heads (savsr_arch.py:91-96, 69-89) recomputed per workgroup (a few k MACs),
+// then  W''[co][ci][tap] = fa[co] ca[ci] sa[tap] sum_k ka[k] W[k][co][ci][tap]  (:156-163,171
+// folded, :148-149) for this workgroup's slice, split to (hi, lo) bf16 and written in the conv
+// weight-image order.
+__global__ __launch_bounds__(512) void osconv_aggregate_kernel(const savsr_osconv_attn_desc d) {
+    extern __shared__ float sm[];
+    float* v2 = sm;                        // [cin]
+    float* a = v2 + d.cin;                 // [hidden]
+    float* gates = a + d.hidden;           // [cin + cout + 9 + knum]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < d.cin; i += 512) v2[i] = d.v2[i];
     __syncthreads();
-    block_matvec(d.fc_w, nullptr, v2, a, d.hidden, d.cin, false);
+    for (int r = wave; r < d.hidden; r += 8) {
+        const float acc = wave_dot(d.fc_w + (long long)r * d.cin, v2, d.cin, lane);
+        if (lane == 0) a[r] = fmaxf(acc * d.bn_scale[r] + d.bn_shift[r], 0.f);
+    }
     __syncthreads();
-    for (int i = tid; i < d.hidden; i += blockDim.x) a[i] = fmaxf(a[i] * d.bn_scale[i] + d.bn_shift[i], 0.f);
-    __syncthreads();
-    // heads: hidden is 16..20 wide -> one thread per output
-    float* att = d.att;
-    for (int i = tid; i < d.cin + d.cout + 9 + d.knum; i += blockDim.x) {
+    const int ngate = d.cin + d.cout + 9 + d.knum;
+    for (int i = tid; i < ngate; i += 512) {
         const float* wr;
         float bias;
         int j = i;
@@ -97,61 +115,70 @@ __global__ __launch_bounds__(1024) void osconv_attention_kernel(const savsr_osco
         float acc = 0.f;
         for (int k = 0; k < d.hidden; ++k) acc += wr[k] * a[k];
         acc += bias;
-        if (i < d.cin + d.cout + 9) att[i] = sigmoidf_(acc);
-        else kl[j] = acc;
+        gates[i] = (i < d.cin + d.cout + 9) ? sigmoidf_(acc) : acc;   // kernel logits stay raw here
     }
     __syncthreads();
-    if (tid == 0) {                        // softmax over the knum kernels (temperature 1, :88)
-        float m = kl[0];
-        for (int k = 1; k < d.knum; ++k) m = fmaxf(m, kl[k]);
+    float* ka = gates + d.cin + d.cout + 9;
+    if (tid == 0) {                        // softmax over the kernels, temperature 1 (:88)
+        float m = ka[0];
+        for (int k = 1; k < d.knum; ++k) m = fmaxf(m, ka[k]);
         float s = 0.f;
-        for (int k = 0; k < d.knum; ++k) { kl[k] = expf(kl[k] - m); s += kl[k]; }
-        for (int k = 0; k < d.knum; ++k) att[d.cin + d.cout + 9 + k] = kl[k] / s;
+        for (int k = 0; k < d.knum; ++k) { ka[k] = expf(ka[k] - m); s += ka[k]; }
+        for (int k = 0; k < d.knum; ++k) ka[k] = ka[k] / s;
     }
-}
+    __syncthreads();
+    if (blockIdx.x == 0 && d.att)
+        for (int i = tid; i < ngate; i += 512) d.att[i] = gates[i];
 
-// Packed-layout elementwise aggregation (savsr_arch.py:158-163 with the channel/filter gates of
-// :156,:171 folded into the weight, as :148-149 notes is equivalent).
-__global__ __launch_bounds__(256) void osconv_aggregate_kernel(const float* __restrict__ bank, const float* __restrict__ att,
-                                                               int cin, int cout, int knum, long long n4, long long bank_stride4,
-                                                               int cot, int nchunk, float* __restrict__ out) {
-    const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i4 >= n4) return;
-    constexpr int CK = 8;
-    long long base = i4 * 4;
-    const int col = (int)(base % cot); base /= cot;
-    const int hh = (int)(base & 1); base >>= 1;
-    const int cp = (int)(base % (CK / 2)); base /= (CK / 2);
-    const int tap = (int)(base % 9); base /= 9;
-    const int chunk = (int)(base % nchunk);
-    const int cob = (int)(base / nchunk);
-    const int ci = chunk * CK + 2 * cp + hh;
-    const int co = cob * cot + col;
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    if (ci < cin) {
-        const float* ca = att, *fa = att + cin, *sa = att + cin + cout, *ka = att + cin + cout + 9;
-        const f32x4* b4 = reinterpret_cast<const f32x4*>(bank);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < knum; ++k) {
-            const f32x4 w = b4[(long long)k * bank_stride4 + i4];
-            const float kk = ka[k];
-            s[0] += kk * w[0]; s[1] += kk * w[1]; s[2] += kk * w[2]; s[3] += kk * w[3];
-        }
-        const float g = ca[ci] * sa[tap];
+    // ---- this workgroup's slice of the weight image: one 8-element lane unit per thread ----
+    const long long unit = (long long)blockIdx.x * 512 + tid;
+    if (unit >= d.nunits) return;
+    const int cot = conv_cot(d.cout), nt = cot / 32, nchunk = d.cin / 16;
+    const long long group = unit >> 6;            // (cob, chunk, tap, t); KSTEPS == 1 for 3x3
+    const int ln = (int)(unit & 63), row = ln & 31, kh = ln >> 5;
+    const int t = (int)(group % nt);
+    long long g2 = group / nt;
+    const int tap = (int)(g2 % 9); g2 /= 9;
+    const int chunk = (int)(g2 % nchunk);
+    const int cob = (int)(g2 / nchunk);
+    const int co = cob * cot + 32 * t + row;
+    const int ci0 = chunk * 16 + kh * 8;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    for (int k = 0; k < d.knum; ++k) {
+        const f32x4* b = reinterpret_cast<const f32x4*>(d.bank + ((long long)k * d.nunits + unit) * 8);
+        const f32x4 w0 = b[0], w1 = b[1];
+        const float kk = ka[k];
+        s0[0] += kk * w0[0]; s0[1] += kk * w0[1]; s0[2] += kk * w0[2]; s0[3] += kk * w0[3];
+        s1[0] += kk * w1[0]; s1[1] += kk * w1[1]; s1[2] += kk * w1[2]; s1[3] += kk * w1[3];
+    }
+    const float gco = (co < d.cout) ? gates[d.cin + co] * gates[d.cin + d.cout + tap] : 0.f;
+    const float* ca = gates + ci0;
+    s0[0] *= gco * ca[0]; s0[1] *= gco * ca[1]; s0[2] *= gco * ca[2]; s0[3] *= gco * ca[3];
+    s1[0] *= gco * ca[4]; s1[1] *= gco * ca[5]; s1[2] *= gco * ca[6]; s1[3] *= gco * ca[7];
+    bf16x8 hi, lo;
+    const float x[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = (co + j < cout) ? s[j] * g * fa[co + j] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(x[j] - (float)h);
     }
-    reinterpret_cast<f32x4*>(out)[i4] = r;
+    bf16x8* img = reinterpret_cast<bf16x8*>(d.wimg_out);
+    img[group * 128 + ln] = hi;
+    img[group * 128 + 64 + ln] = lo;
 }
 
-// RCAN ChannelAttention MLP (savsr_arch.py:514-520), one block of 64 threads.
-__global__ __launch_bounds__(64) void se_gate_kernel(const float* mean, const float* w1, const float* b1, const float* w2,
-                                                     const float* b2, int c, int cmid, float* gate) {
+// RCAN ChannelAttention MLP (savsr_arch.py:514-520); one workgroup.
+__global__ __launch_bounds__(64) void se_gate_kernel(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
+                                                     const float* w2, const float* b2, int c, int cmid, float* gate) {
+    __shared__ float m[128];
     __shared__ float z[64];
     const int t = threadIdx.x;
+    for (int i = t; i < c; i += 64) m[i] = mean_from_partials(partial, nblk, c, i, inv_n);
+    __syncthreads();
     if (t < cmid) {
         float acc = b1[t];
-        for (int i = 0; i < c; ++i) acc += w1[t * c + i] * mean[i];
+        for (int i = 0; i < c; ++i) acc += w1[t * c + i] * m[i];
         z[t] = fmaxf(acc, 0.f);
     }
     __syncthreads();
@@ -162,26 +189,15 @@ __global__ __launch_bounds__(64) void se_gate_kernel(const float* mean, const fl
     }
 }
 
-// out = r * gate[c] + x  (savsr_arch.py:524,548-549)
-__global__ __launch_bounds__(256) void scale_residual_kernel(const float* __restrict__ r, const float* __restrict__ gate,
-                                                             const float* __restrict__ x, float* __restrict__ out,
-                                                             long long n, long long n4_per_c) {
-    const int c = blockIdx.y;
-    const float g = gate[c];
-    const f32x4* r4 = reinterpret_cast<const f32x4*>(r + (long long)c * n);
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x + (long long)c * n);
-    f32x4* o4 = reinterpret_cast<f32x4*>(out + (long long)c * n);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4_per_c; i += (long long)gridDim.x * 256) {
-        const f32x4 a = r4[i], b = x4[i];
+// out[px][c] = r[px][c] * gate[c] + x[px][c]   (savsr_arch.py:524,548-549), c == 64 contiguous
+__global__ __launch_bounds__(256) void scale_residual_kernel(const f32x4* __restrict__ r, const float* __restrict__ gate,
+                                                             const f32x4* __restrict__ x, f32x4* __restrict__ out, long long n4, int c4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gate + 4 * (int)(i % c4));
+        const f32x4 a = r[i], b = x[i];
         f32x4 o;
-        o[0] = a[0] * g + b[0]; o[1] = a[1] * g + b[1]; o[2] = a[2] * g + b[2]; o[3] = a[3] * g + b[3];
-        o4[i] = o;
-    }
-    // scalar tail when n is not a multiple of 4
-    const long long tail0 = n4_per_c * 4;
-    if (blockIdx.x == 0 && threadIdx.x < (n - tail0)) {
-        const long long i = (long long)c * n + tail0 + threadIdx.x;
-        out[i] = r[i] * g + x[i];
+        o[0] = a[0] * g[0] + b[0]; o[1] = a[1] * g[1] + b[1]; o[2] = a[2] * g[2] + b[2]; o[3] = a[3] * g[3] + b[3];
+        out[i] = o;
     }
 }
 
@@ -189,66 +205,66 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(const float* __rest
 
 using namespace savsr;
 
-extern "C" int savsr_channel_mean(const float* const* src, const int64_t* src_plane, const int32_t* src_row, int nsrc,
-                                  int src_ch, int h, int w, float* mean, void* stream) {
-    if (!src || !src_plane || !src_row || !mean) return fail_arg("channel_mean: null pointer");
-    if (nsrc < 1 || nsrc > SAVSR_MAX_SRC || src_ch < 1 || h < 1 || w < 1) return fail_arg("channel_mean: shape");
-    MeanParams p;
+extern "C" int savsr_channel_sums(const float* const* src, const int32_t* src_pix, int nsrc, int src_ch, int64_t npx, int nblk,
+                                  float* partial, void* stream) {
+    if (!src || !src_pix || !partial) return fail_arg("channel_sums: null pointer");
+    if (nsrc < 1 || nsrc > SAVSR_MAX_SRC || src_ch < 4 || (src_ch % 4) || (256 % (src_ch / 4)) || npx < 1 || nblk < 1 || npx > 0x7fffffff)
+        return fail_arg("channel_sums: shape (src_ch/4 must divide 256)");
+    SumParams p;
     for (int i = 0; i < SAVSR_MAX_SRC; ++i) {
         const bool on = i < nsrc;
-        if (on && !src[i]) return fail_arg("channel_mean: null source");
+        if (on && (!src[i] || (reinterpret_cast<uintptr_t>(src[i]) & 15) || (src_pix[i] & 3))) return fail_arg("channel_sums: null/unaligned source");
         p.src[i] = on ? src[i] : nullptr;
-        p.plane[i] = on ? src_plane[i] : 0;
-        p.row[i] = on ? src_row[i] : 0;
+        p.pix[i] = on ? src_pix[i] : 0;
     }
-    p.src_ch = src_ch; p.h = h; p.w = w; p.mean = mean;
-    hipLaunchKernelGGL(channel_mean_kernel, dim3(nsrc * src_ch), dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    return check_launch("channel_mean_kernel");
+    p.src_ch = src_ch; p.npx = (int)npx; p.nblk = nblk; p.partial = partial;
+    hipLaunchKernelGGL(channel_sums_kernel, dim3(nblk, nsrc), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return check_launch("channel_sums_kernel");
 }
 
-extern "C" int savsr_osconv_attention(const savsr_osconv_attn_desc* d, void* stream) {
-    if (!d) return fail_arg("osconv_attention: null descriptor");
-    if (d->cin < 1 || d->cout < 1 || d->hidden < 1 || d->knum < 1 || d->knum > 64) return fail_arg("osconv_attention: shape");
-    if (!d->mean || !d->l1_w || !d->l1_b || !d->l2_w || !d->l2_b || !d->fc_w || !d->bn_scale || !d->bn_shift || !d->ch_w ||
-        !d->ch_b || !d->fl_w || !d->fl_b || !d->sp_w || !d->sp_b || !d->kn_w || !d->kn_b || !d->att)
-        return fail_arg("osconv_attention: null pointer");
-    const size_t lds = sizeof(float) * ((size_t)d->cin + 2 + 2 * d->cin + d->cin + d->hidden + d->knum);
-    if (lds > 60000) return fail_arg("osconv_attention: cin too large");
-    hipLaunchKernelGGL(osconv_attention_kernel, dim3(1), dim3(1024), lds, static_cast<hipStream_t>(stream), *d);
-    return check_launch("osconv_attention_kernel");
-}
-
-extern "C" int savsr_osconv_aggregate(const float* bank_packed, const float* att, int cin, int cout, int knum,
-                                      float* wpacked_out, void* stream) {
-    if (!bank_packed || !att || !wpacked_out) return fail_arg("osconv_aggregate: null pointer");
-    if (cin < 1 || cout < 1 || knum < 1) return fail_arg("osconv_aggregate: shape");
-    const int ck = conv_ck(3), cot = conv_cot(cout);
-    const int nchunk = (cin + ck - 1) / ck;
-    const long long total = savsr_conv_packed_floats(cout, cin, 3);
-    const long long n4 = total / 4;
-    hipLaunchKernelGGL(osconv_aggregate_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       bank_packed, att, cin, cout, knum, n4, n4, cot, nchunk, wpacked_out);
+extern "C" int savsr_osconv_weights(const savsr_osconv_attn_desc* d, void* stream) {
+    if (!d) return fail_arg("osconv_weights: null descriptor");
+    if (d->cin < 16 || (d->cin % 16) || d->cout < 1 || d->hidden < 1 || d->knum < 1 || d->knum > 64 || d->nblk < 1)
+        return fail_arg("osconv_weights: shape (cin multiple of 16)");
+    if (!d->partial || !d->l1_w || !d->l1_b || !d->l2_w || !d->l2_b || !d->fc_w || !d->bn_scale || !d->bn_shift || !d->ch_w ||
+        !d->ch_b || !d->fl_w || !d->fl_b || !d->sp_w || !d->sp_b || !d->kn_w || !d->kn_b || !d->v1 || !d->v2 || !d->bank || !d->wimg_out)
+        return fail_arg("osconv_weights: null pointer");
+    if (d->nunits * 8 != savsr_conv_packed_elems(d->cout, d->cin, 3)) return fail_arg("osconv_weights: nunits != packed_elems/8");
+    if ((reinterpret_cast<uintptr_t>(d->bank) | reinterpret_cast<uintptr_t>(d->wimg_out)) & 15) {
+        set_error("osconv_weights: bank / wimg_out must be 16-byte aligned");
+        return SAVSR_E_ALIGN;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(osconv_l1_kernel, dim3((2 * d->cin + 7) / 8), dim3(512), sizeof(float) * (d->cin + 2), st, *d);
+    int rc = check_launch("osconv_l1_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(osconv_l2_kernel, dim3((d->cin + 7) / 8), dim3(512), sizeof(float) * 2 * d->cin, st, *d);
+    rc = check_launch("osconv_l2_kernel");
+    if (rc) return rc;
+    const size_t lds = sizeof(float) * ((size_t)d->cin + d->hidden + d->cin + d->cout + 9 + d->knum);
+    hipLaunchKernelGGL(osconv_aggregate_kernel, dim3((unsigned)((d->nunits + 511) / 512)), dim3(512), lds, st, *d);
     return check_launch("osconv_aggregate_kernel");
 }
 
-extern "C" int savsr_se_gate(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, int c,
-                             int cmid, float* gate, void* stream) {
-    if (!mean || !w1 || !b1 || !w2 || !b2 || !gate) return fail_arg("se_gate: null pointer");
-    if (c < 1 || cmid < 1 || cmid > 64) return fail_arg("se_gate: shape");
-    hipLaunchKernelGGL(se_gate_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), mean, w1, b1, w2, b2, c, cmid, gate);
+extern "C" int savsr_se_gate(const float* partial, int nblk, float inv_n, const float* w1, const float* b1, const float* w2,
+                             const float* b2, int c, int cmid, float* gate, void* stream) {
+    if (!partial || !w1 || !b1 || !w2 || !b2 || !gate) return fail_arg("se_gate: null pointer");
+    if (c < 1 || c > 128 || cmid < 1 || cmid > 64 || nblk < 1) return fail_arg("se_gate: shape");
+    hipLaunchKernelGGL(se_gate_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), partial, nblk, inv_n, w1, b1, w2, b2, c, cmid, gate);
     return check_launch("se_gate_kernel");
 }
 
-extern "C" int savsr_scale_residual(const float* r, const float* gate, const float* x, float* out, int c, int64_t n, void* stream) {
+extern "C" int savsr_scale_residual(const float* r, const float* gate, const float* x, float* out, int c, int64_t npx, void* stream) {
     if (!r || !gate || !x || !out) return fail_arg("scale_residual: null pointer");
-    if (c < 1 || n < 1) return fail_arg("scale_residual: shape");
-    // vector path needs every channel plane 16-byte aligned
-    const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-    const long long n4 = vec ? n / 4 : 0;
-    if (!vec && n >= 256) return fail_arg("scale_residual: planes must be 16-byte aligned with n % 4 == 0 (or n < 256)");
-    int gx = (int)((n4 + 255) / 256);
-    if (gx < 1) gx = 1;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(scale_residual_kernel, dim3(gx, c), dim3(256), 0, static_cast<hipStream_t>(stream), r, gate, x, out, (long long)n, n4);
+    if (c < 4 || (c % 4) || npx < 1) return fail_arg("scale_residual: c must be a multiple of 4");
+    if ((reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gate)) & 15) {
+        set_error("scale_residual: pointers must be 16-byte aligned");
+        return SAVSR_E_ALIGN;
+    }
+    const long long n4 = npx * (c / 4);
+    long long g = (n4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(scale_residual_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const f32x4*>(r), gate, reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(out), n4, c / 4);
     return check_launch("scale_residual_kernel");
 }

@@ -22,7 +22,6 @@
 
 namespace savsr {
 
-constexpr int C = SAVSR_SATU_C;            // 64
 constexpr int REC = SAVSR_SATU_LRCAT;      // 160
 constexpr int HREC = REC / 2;              // 80
 
@@ -60,59 +59,82 @@ __global__ __launch_bounds__(256) void satu_phase_table_kernel(const savsr_satu_
 // LR stage.  Block = 4 waves = 4 rows x 32 cols of LR pixels; wave w owns row w.
 //   K[n][px]   = LReLU_0.1( Wk[n][:] . st[:, px] + bk[n] ),  n = 25 c + tap       (:226-228,319)
 //   sta[c][px] = sum_tap K[25c+tap][px] * x_rep[c][y+ky-2][x+kx-2]                (:297-313)
-// as 50 (tap, channel-group) GEMM tiles of 32 rows x 32 px x K=64 on v_mfma_f32_32x32x2_f32;
-// the K tile never leaves the accumulator registers.  Then the three LR-side projections
-// (Wa sta | Wb x | C x) with sta consumed straight from its accumulator registers.
+// as 50 (tap, channel-group) GEMM tiles of 32 rows x 32 px x K=64 on v_mfma_f32_32x32x16_bf16 with
+// split-bf16 operands (hi*hi + hi*lo + lo*hi, see conv_mfma.hip); the K tile never leaves the
+// accumulator registers.  Then the three LR-side projections (Wa sta | Wb x | C x), with sta
+// consumed straight from its accumulator registers (k order = accumulator order).
+// x, st: channel-last [..][..][pix] fp32 crops (row pitch `row_px` pixels).
 // ------------------------------------------------------------------------------------------
 struct LrParams {
     savsr_satu_weights wt;
     const float* x;
     const float* st;
-    long long plane;
-    int row, h, w;
+    int pix, row_px, h, w;
     float* lrcat;
 };
 
 constexpr int LR_TH = 4, LR_TW = 32, LR_HALO = 2;
 constexpr int LR_XR = LR_TH + 2 * LR_HALO;     // 8
 constexpr int LR_XC = LR_TW + 2 * LR_HALO;     // 36
-constexpr int LR_XT = 32 * LR_XR * LR_XC;      // x tile floats per channel group (9216)
-constexpr int LR_SLAB = 32 * 64;               // one (tap, cg) weight slab (2048 floats)
+constexpr int LR_NPX = LR_XR * LR_XC;          // 288 pixels in the x tile
+constexpr int LR_XS = 36;                      // floats per pixel record in LDS (32 used; 144 B keeps b128 reads conflict-free)
+constexpr int LR_SLAB = 4 * 2 * 64;            // 16-B units of one (tap, cg) weight slab: [ks][part][lane]
+
+__device__ __forceinline__ void split8v(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(x[j] - (float)h);
+    }
+}
+
+__device__ __forceinline__ f32x16 mma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
 
 __global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xt = smem;                       // [32][8][36]
-    float* wbuf = smem + LR_XT;             // [2][2048]
+    float* xt = smem;                                                   // [288][36]
+    bf16x8* wbuf = reinterpret_cast<bf16x8*>(smem + LR_NPX * LR_XS);    // [2][LR_SLAB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int x0 = blockIdx.x * LR_TW, y0 = blockIdx.y * LR_TH;
     const int gy = y0 + wave, gx = x0 + px;
     const bool valid = gy < p.h && gx < p.w;
     const int cy = gy < p.h ? gy : p.h - 1, cx = gx < p.w ? gx : p.w - 1;
+    const long long cpix = ((long long)cy * p.row_px + cx) * p.pix + 8 * half;
 
-    // B operand of the kernel-prediction GEMM: st[ch = 2s + half][pixel], resident for all 50 tiles
-    float bst[32];
+    // B operand of the kernel-prediction GEMM: st[16 ks + 8 half + j][pixel], resident for all 50 tiles
+    bf16x8 sth[4], stl[4];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) bst[s] = p.st[(long long)(2 * s + half) * p.plane + (long long)cy * p.row + cx];
+    for (int ks = 0; ks < 4; ++ks) {
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.st + cpix + 16 * ks);
+        split8v(g[0], g[1], sth[ks], stl[ks]);
+    }
+    const bf16x8* kw = reinterpret_cast<const bf16x8*>(p.wt.kconv_w);
 
     f32x16 sta[2];
 #pragma unroll
     for (int cg = 0; cg < 2; ++cg) {
         __syncthreads();                    // previous group's readers are done with xt / wbuf
         // replicate-padded x tile of this channel group (F.pad replicate, :302)
-        for (int e = tid; e < LR_XT; e += 256) {
-            const int ch = e / (LR_XR * LR_XC);
-            const int rem = e - ch * (LR_XR * LR_XC);
-            const int r = rem / LR_XC, c = rem - r * LR_XC;
+        for (int e = tid; e < LR_NPX * 8; e += 256) {
+            const int pl = e >> 3, c4 = e & 7;
+            const int r = pl / LR_XC, c = pl - r * LR_XC;
             int sy = y0 - LR_HALO + r, sx = x0 - LR_HALO + c;
             sy = sy < 0 ? 0 : (sy > p.h - 1 ? p.h - 1 : sy);
             sx = sx < 0 ? 0 : (sx > p.w - 1 ? p.w - 1 : sx);
-            xt[e] = p.x[(long long)(cg * 32 + ch) * p.plane + (long long)sy * p.row + sx];
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + ((long long)sy * p.row_px + sx) * p.pix + 32 * cg + 4 * c4);
+            *reinterpret_cast<f32x4*>(xt + pl * LR_XS + 4 * c4) = v;
         }
         {
-            const f32x4* src = reinterpret_cast<const f32x4*>(p.wt.kconv_w + (long long)(0 * 2 + cg) * LR_SLAB);
-            reinterpret_cast<f32x4*>(wbuf)[tid] = src[tid];
-            reinterpret_cast<f32x4*>(wbuf)[tid + 256] = src[tid + 256];
+            const bf16x8* src = kw + (long long)(0 * 2 + cg) * LR_SLAB;
+            wbuf[tid] = src[tid];
+            wbuf[tid + 256] = src[tid + 256];
         }
         __syncthreads();
 
@@ -122,13 +144,13 @@ __global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
 
         for (int tap = 0; tap < 25; ++tap) {
             const bool more = tap + 1 < 25;
-            f32x4 nx0 = {0.f, 0.f, 0.f, 0.f}, nx1 = nx0;
+            bf16x8 nx0 = wbuf[0], nx1 = nx0;
             if (more) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(p.wt.kconv_w + (long long)((tap + 1) * 2 + cg) * LR_SLAB);
+                const bf16x8* src = kw + (long long)((tap + 1) * 2 + cg) * LR_SLAB;
                 nx0 = src[tid];
                 nx1 = src[tid + 256];
             }
-            const float* wl = wbuf + (tap & 1) * LR_SLAB + lane;
+            const bf16x8* wl = wbuf + (tap & 1) * LR_SLAB + lane;
             const float* kb = p.wt.kconv_b + tap * 64 + cg * 32 + 4 * half;
             f32x16 acc;
 #pragma unroll
@@ -137,46 +159,58 @@ __global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
                 acc[4 * g + 0] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
             }
 #pragma unroll
-            for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[s * 64], bst[s], acc, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) acc = mma3(wl[(ks * 2 + 0) * 64], wl[(ks * 2 + 1) * 64], sth[ks], stl[ks], acc);
             const int ky = tap / 5, kx = tap - ky * 5;
-            const float* xp = xt + (wave + ky) * LR_XC + px + kx;
+            const float* xp = xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float k = acc[r];
-                k = k > 0.f ? k : 0.1f * k;           // LeakyReLU(0.1), :228
-                sacc[r] += k * xp[acc_row(r, half) * (LR_XR * LR_XC)];
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + 8 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float k = acc[4 * g + i];
+                    sacc[4 * g + i] += fmaxf(k, 0.1f * k) * xv[i];     // LeakyReLU(0.1), :228
+                }
             }
             if (more) {
-                float* dst = wbuf + ((tap + 1) & 1) * LR_SLAB;
-                reinterpret_cast<f32x4*>(dst)[tid] = nx0;
-                reinterpret_cast<f32x4*>(dst)[tid + 256] = nx1;
+                bf16x8* dst = wbuf + ((tap + 1) & 1) * LR_SLAB;
+                dst[tid] = nx0;
+                dst[tid + 256] = nx1;
             }
             __syncthreads();
         }
         sta[cg] = sacc;
     }
 
-    // ---- LR-side projections --------------------------------------------------------------
+    // ---- LR-side projections (bf16x3): proj image = A [t][kidx 4][part][lane] | B [t][ks 4][part][lane] | C [ks 4][part][lane]
+    const bf16x8* pa = reinterpret_cast<const bf16x8*>(p.wt.proj_w) + lane;
+    const bf16x8* pb = pa + 2 * 4 * 2 * 64;
+    const bf16x8* pc = pb + 2 * 4 * 2 * 64;
     f32x16 accA[2], accB[2], accC;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accA[0][r] = 0.f; accA[1][r] = 0.f; accB[0][r] = 0.f; accB[1][r] = 0.f; accC[r] = 0.f; }
-    const float* pa = p.wt.proj_w + lane;                 // [2][32][64]
-    const float* pb = p.wt.proj_w + 2 * 32 * 64 + lane;   // [2][32][64]
-    const float* pc = p.wt.proj_w + 4 * 32 * 64 + lane;   // [32][64]
 #pragma unroll
     for (int cg = 0; cg < 2; ++cg)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kidx = cg * 16 + r;
-            accA[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(0 * 32 + kidx) * 64], sta[cg][r], accA[0], 0, 0, 0);
-            accA[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(1 * 32 + kidx) * 64], sta[cg][r], accA[1], 0, 0, 0);
+        for (int s = 0; s < 2; ++s) {
+            // accumulator regs 8s..8s+7 are rows 16 s + 8 (j >> 2) + 4 half + (j & 3): the k order of this step
+            const f32x4 lo4 = {sta[cg][8 * s], sta[cg][8 * s + 1], sta[cg][8 * s + 2], sta[cg][8 * s + 3]};
+            const f32x4 hi4 = {sta[cg][8 * s + 4], sta[cg][8 * s + 5], sta[cg][8 * s + 6], sta[cg][8 * s + 7]};
+            bf16x8 bh, bl;
+            split8v(lo4, hi4, bh, bl);
+            const int kidx = cg * 2 + s;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                accA[t] = mma3(pa[((t * 4 + kidx) * 2 + 0) * 64], pa[((t * 4 + kidx) * 2 + 1) * 64], bh, bl, accA[t]);
         }
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        const float bx = p.x[(long long)(2 * s + half) * p.plane + (long long)cy * p.row + cx];
-        accB[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[(0 * 32 + s) * 64], bx, accB[0], 0, 0, 0);
-        accB[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[(1 * 32 + s) * 64], bx, accB[1], 0, 0, 0);
-        accC = __builtin_amdgcn_mfma_f32_32x32x2f32(pc[s * 64], bx, accC, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) {
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.x + cpix + 16 * ks);
+        bf16x8 xh, xl;
+        split8v(g[0], g[1], xh, xl);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            accB[t] = mma3(pb[((t * 4 + ks) * 2 + 0) * 64], pb[((t * 4 + ks) * 2 + 1) * 64], xh, xl, accB[t]);
+        accC = mma3(pc[(ks * 2 + 0) * 64], pc[(ks * 2 + 1) * 64], xh, xl, accC);
     }
     if (!valid) return;
     f32x4* rec = reinterpret_cast<f32x4*>(p.lrcat + ((long long)gy * p.w + gx) * REC + half * HREC);
@@ -358,18 +392,18 @@ extern "C" int savsr_satu_phase_table(const savsr_satu_weights* wt, const float*
     return check_launch("satu_phase_table_kernel");
 }
 
-extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const float* st, int64_t plane, int32_t row, int h,
+extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const float* st, int32_t pix, int32_t row_px, int h,
                                    int w, float* lrcat, void* stream) {
     if (!satu_weights_ok(wt) || !x || !st || !lrcat) return fail_arg("satu_lr_stage: null pointer");
-    if (h < 1 || w < 1 || row < w || plane < (int64_t)row * h) return fail_arg("satu_lr_stage: shape/strides");
-    if ((reinterpret_cast<uintptr_t>(lrcat) & 15) || (reinterpret_cast<uintptr_t>(wt->kconv_w) & 15) ||
-        (reinterpret_cast<uintptr_t>(wt->kconv_b) & 15)) {
-        set_error("satu_lr_stage: lrcat / kconv_w / kconv_b must be 16-byte aligned");
+    if (h < 1 || w < 1 || row_px < w || pix < 64 || (pix & 3)) return fail_arg("satu_lr_stage: shape/strides");
+    if ((reinterpret_cast<uintptr_t>(lrcat) | reinterpret_cast<uintptr_t>(wt->kconv_w) | reinterpret_cast<uintptr_t>(wt->kconv_b) |
+         reinterpret_cast<uintptr_t>(wt->proj_w) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(st)) & 15) {
+        set_error("satu_lr_stage: x / st / lrcat / kconv_w / kconv_b / proj_w must be 16-byte aligned");
         return SAVSR_E_ALIGN;
     }
     LrParams p;
-    p.wt = *wt; p.x = x; p.st = st; p.plane = plane; p.row = row; p.h = h; p.w = w; p.lrcat = lrcat;
-    const size_t lds = (LR_XT + 2 * LR_SLAB) * sizeof(float);
+    p.wt = *wt; p.x = x; p.st = st; p.pix = pix; p.row_px = row_px; p.h = h; p.w = w; p.lrcat = lrcat;
+    const size_t lds = LR_NPX * LR_XS * sizeof(float) + 2 * LR_SLAB * 16;
     dim3 grid((w + LR_TW - 1) / LR_TW, (h + LR_TH - 1) / LR_TH);
     hipLaunchKernelGGL(satu_lr_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_lr_kernel");

@@ -1,7 +1,8 @@
 """Host-side driver of the HIP kernels for the SAVSR inference path.
 
 `HipEngine` owns (i) the weights re-laid-out once for the kernels (BatchNorm folded, conv
-weights in MFMA lane order, SATU matrices pre-multiplied), (ii) a pool of named device buffers
+weights as split-bf16 images in MFMA lane order, SATU matrices pre-multiplied), (ii) a pool of
+named channel-last device buffers
 per input shape and (iii) the launch sequence that replaces `SAVSR.forward`
 (/root/reference/lbasicsr/archs/savsr_arch.py:692-742).  PyTorch is used for device memory and
 streams only: every arithmetic step below is a call into libsavsr_hip.so through the C ABI of
@@ -19,6 +20,7 @@ from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvDesc, OSConvAttnDesc, SatuWeights
 
 BN_EPS = 1e-5
+MAX_SUM_BLOCKS = 64      # workgroups of one savsr_channel_sums launch
 
 
 # ----------------------------------------------------------------------------- host helpers (integer / grid logic)
@@ -47,40 +49,58 @@ def satu_axis_tables(n_out: int, n_in: int, s: float):
 
 _PACK_IDX_CACHE: Dict[Tuple[int, int, int], Tuple[np.ndarray, int]] = {}
 
+CONV_TH, CONV_TW = 8, 32      # pixel tile of one conv workgroup (mirrors common.hpp)
+
 
 def conv_pack_geometry(cout: int, cin: int, ks: int):
-    ck = 8 if ks == 3 else 32
+    kc = 16 if ks == 3 else 32
     cot = 64 if cout > 32 else 32
-    nchunk = (cin + ck - 1) // ck
-    ncob = (cout + cot - 1) // cot
-    return ck, cot, nchunk, ncob
+    if cin % kc:
+        raise ValueError(f"conv cin={cin} must be a multiple of {kc} (pad the weight with zero channels)")
+    return kc, cot, cin // kc, (cout + cot - 1) // cot
 
 
 def conv_pack_index(cout: int, cin: int, ks: int):
-    """Index map [cout, cin, ks*ks] -> packed buffer (mirror of savsr_conv_pack_index)."""
+    """Index map [cout, cin, ks*ks] -> position inside one part of the weight image
+    (mirror of savsr_conv_pack_index)."""
     key = (cout, cin, ks)
     if key not in _PACK_IDX_CACHE:
-        ck, cot, nchunk, ncob = conv_pack_geometry(cout, cin, ks)
-        taps = ks * ks
+        kc, cot, nchunk, ncob = conv_pack_geometry(cout, cin, ks)
+        taps, nt, ksteps = ks * ks, cot // 32, kc // 16
         co = np.arange(cout, dtype=np.int64)[:, None, None]
         ci = np.arange(cin, dtype=np.int64)[None, :, None]
         tap = np.arange(taps, dtype=np.int64)[None, None, :]
         cob, col = co // cot, co % cot
-        chunk, cl = ci // ck, ci % ck
-        cp, hh = cl // 2, cl % 2
-        idx = ((((cob * nchunk + chunk) * taps + tap) * (ck // 2) + cp) * 2 + hh) * cot + col
-        total = ncob * nchunk * taps * ck * cot
+        t, row = col // 32, col % 32
+        chunk, cl = ci // kc, ci % kc
+        kstep, kh, j = cl // 16, (cl % 16) // 8, cl % 8
+        group = (((cob * nchunk + chunk) * taps + tap) * ksteps + kstep) * nt + t
+        idx = group * 512 + (kh * 32 + row) * 8 + j
+        total = ncob * nchunk * taps * kc * cot
         _PACK_IDX_CACHE[key] = (np.ascontiguousarray(np.broadcast_to(idx, (cout, cin, taps))).reshape(-1), total)
     return _PACK_IDX_CACHE[key]
 
 
-def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
-    """[cout, cin, k, k] (any device) -> packed fp32 CPU tensor in MFMA lane order."""
+def pack_conv_part(w: torch.Tensor) -> torch.Tensor:
+    """[cout, cin, k, k] -> fp32 CPU tensor of one image part (zero padded), lane order."""
     cout, cin, ks, _ = w.shape
     idx, total = conv_pack_index(cout, cin, ks)
     out = np.zeros(total, dtype=np.float32)
     out[idx] = w.detach().to("cpu", torch.float32).contiguous().numpy().reshape(-1)
     return torch.from_numpy(out)
+
+
+def split_bf16_image(part: torch.Tensor) -> torch.Tensor:
+    """fp32 part [n*512] -> int16 image [n][2][512]: hi = bf16(v), lo = bf16(v - hi) (RNE both)."""
+    hi = part.to(torch.bfloat16)
+    lo = (part - hi.to(torch.float32)).to(torch.bfloat16)
+    img = torch.stack([hi.view(-1, 512), lo.view(-1, 512)], dim=1).contiguous()
+    return img.view(torch.int16).reshape(-1)
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """[cout, cin, k, k] -> split-bf16 weight image (int16 CPU tensor) for savsr_conv2d."""
+    return split_bf16_image(pack_conv_part(w))
 
 
 def acc_row(r: int, half: int) -> int:
@@ -92,14 +112,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-class _Src:
-    """A conv input: device tensor viewed as [ch][h][w] with explicit strides (in floats)."""
-    __slots__ = ("t", "ptr", "ch", "plane", "row")
+class Src:
+    """A channel-last feature map slice: element (px, c) at ptr + 4*(px*pix + c), c < ch."""
+    __slots__ = ("t", "ptr", "ch", "pix")
 
-    def __init__(self, t: torch.Tensor, ch: int, plane: int, row: int, offset_floats: int = 0):
+    def __init__(self, t: torch.Tensor, ch: int, pix: int, ch_off: int = 0, float_off: int = 0):
         self.t = t
-        self.ptr = t.data_ptr() + 4 * offset_floats
-        self.ch, self.plane, self.row = ch, plane, row
+        self.ptr = t.data_ptr() + 4 * (ch_off + float_off)
+        self.ch, self.pix = ch, pix
 
 
 class HipEngine:
@@ -113,7 +133,9 @@ class HipEngine:
         self.nf = cfg["num_feat"]
         if self.nf != 64:
             raise RuntimeError("the HIP SATU kernels are specialised for num_feat == 64")
-        self.pw: Dict[str, tuple] = {}      # conv key -> (wpacked, bias, cout, cin, ks)
+        if cfg["slid_win"] != 3 or cfg["num_in_ch"] != 3:
+            raise RuntimeError("the input-window packing is specialised for slid_win == 3, num_in_ch == 3")
+        self.pw: Dict[str, tuple] = {}      # conv key -> (wimage, bias, cout, cin, ks)
         self.osc: Dict[str, dict] = {}      # osconv key -> tensors
         self.se: Dict[str, tuple] = {}
         self._keep: List[torch.Tensor] = []
@@ -123,12 +145,12 @@ class HipEngine:
         self._pack_all({k: v.detach() for k, v in state.items()})
 
     # ------------------------------------------------------------------ weight preparation
-    def _dev(self, t: torch.Tensor) -> torch.Tensor:
-        d = t.to(self.dev, torch.float32).contiguous()
+    def _dev(self, t: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+        d = t.to(self.dev, dtype).contiguous()
         self._keep.append(d)
         return d
 
-    def _add_conv(self, sd, key: str, bn: Optional[str] = None):
+    def _fold(self, sd, key: str, bn: Optional[str]):
         w = sd[key + ".weight"].to("cpu", torch.float32)
         b = sd.get(key + ".bias")
         b = None if b is None else b.to("cpu", torch.float32)
@@ -137,19 +159,38 @@ class HipEngine:
             w = w * s.view(-1, 1, 1, 1)
             b0 = b if b is not None else torch.zeros_like(s)
             b = (b0 - sd[bn + ".running_mean"].cpu()) * s + sd[bn + ".bias"].cpu()
+        return w, b
+
+    def _register(self, key: str, w: torch.Tensor, b: Optional[torch.Tensor]):
         cout, cin, ks, _ = w.shape
-        self.pw[key] = (self._dev(pack_conv_weight(w)), None if b is None else self._dev(b), cout, cin, ks)
+        self.pw[key] = (self._dev(pack_conv_weight(w), torch.int16), None if b is None else self._dev(b), cout, cin, ks)
+
+    def _add_conv(self, sd, key: str, bn: Optional[str] = None):
+        w, b = self._fold(sd, key, bn)
+        self._register(key, w, b)
+
+    def _add_window_conv(self, sd, d: str):
+        """conv_c (3->64) and conv_sup (6->64) of one direction fused into a 16 -> 128 conv over
+        the packed window tensor (channels: frame t | t-1 | t+1 | zeros), savsr_arch.py:429-431,456-457."""
+        nf = self.nf
+        wc, bc = sd[d + ".conv_c.weight"].cpu().float(), sd[d + ".conv_c.bias"].cpu().float()
+        ws, bs = sd[d + ".conv_sup.weight"].cpu().float(), sd[d + ".conv_sup.bias"].cpu().float()
+        w = torch.zeros(2 * nf, 16, 3, 3)
+        w[:nf, 0:3] = wc
+        w[nf:, 3:9] = ws
+        self._register(d + ".win", w, torch.cat([bc, bs]))
 
     def _add_osconv(self, sd, key: str):
         bank = sd[key + ".weight"].to("cpu", torch.float32)       # [K, cout, cin, 3, 3]
         knum, cout, cin = bank.shape[:3]
-        packed = torch.stack([pack_conv_weight(bank[k]) for k in range(knum)], 0)
+        packed = torch.stack([pack_conv_part(bank[k]) for k in range(knum)], 0)
         a = key + ".attention"
         bn_s = sd[a + ".bn.weight"].cpu() / torch.sqrt(sd[a + ".bn.running_var"].cpu() + BN_EPS)
         bn_b = sd[a + ".bn.bias"].cpu() - sd[a + ".bn.running_mean"].cpu() * bn_s
         hidden = sd[a + ".fc.weight"].shape[0]
         g = lambda k: self._dev(sd[k].reshape(sd[k].shape[0], -1) if sd[k].dim() > 1 else sd[k])
-        ent = dict(cin=cin, cout=cout, knum=knum, hidden=hidden, bank=self._dev(packed),
+        elems = packed.shape[1]
+        ent = dict(cin=cin, cout=cout, knum=knum, hidden=hidden, bank=self._dev(packed), nunits=elems // 8,
                    l1_w=g(key + ".scale_routing.0.weight"), l1_b=g(key + ".scale_routing.0.bias"),
                    l2_w=g(key + ".scale_routing.2.weight"), l2_b=g(key + ".scale_routing.2.bias"),
                    fc_w=g(a + ".fc.weight"), bn_scale=self._dev(bn_s), bn_shift=self._dev(bn_b),
@@ -157,45 +198,53 @@ class HipEngine:
                    fl_w=g(a + ".filter_fc.weight"), fl_b=g(a + ".filter_fc.bias"),
                    sp_w=g(a + ".spatial_fc.weight"), sp_b=g(a + ".spatial_fc.bias"),
                    kn_w=g(a + ".kernel_fc.weight"), kn_b=g(a + ".kernel_fc.bias"),
-                   mean=torch.empty(cin, device=self.dev), att=torch.empty(cin + cout + 9 + knum, device=self.dev),
-                   wdyn=torch.empty(packed.shape[1], device=self.dev))
+                   v1=torch.empty(2 * cin, device=self.dev), v2=torch.empty(cin, device=self.dev),
+                   att=torch.empty(cin + cout + 9 + knum, device=self.dev),
+                   partial=torch.empty(MAX_SUM_BLOCKS * cin, device=self.dev),
+                   wdyn=torch.empty(2 * elems, device=self.dev, dtype=torch.int16))
         self.osc[key] = ent
 
     def _pack_satu(self, sd):
         p = "upsample."
         c = self.nf
         f32 = torch.float32
-        wk = sd[p + "kernel_conv.0.weight"].to("cpu", f32).reshape(25 * c, c)     # [n = 25 ch + tap][k]
-        bk = sd[p + "kernel_conv.0.bias"].to("cpu", f32)
+        wk = sd[p + "kernel_conv.0.weight"].to("cpu", f32).reshape(25 * c, c).numpy()     # [n = 25 ch + tap][k]
+        bk = sd[p + "kernel_conv.0.bias"].to("cpu", f32).numpy()
         lane = np.arange(64)
         li, lh = lane & 31, lane >> 5
-        # kconv_w[tap][cg][s][lane] = Wk[25 (32 cg + (lane & 31)) + tap][2 s + (lane >> 5)]
-        tap = np.arange(25)[:, None, None, None]
-        cg = np.arange(2)[None, :, None, None]
-        s = np.arange(32)[None, None, :, None]
-        n_idx = 25 * (32 * cg + li[None, None, None, :]) + tap
-        k_idx = 2 * s + lh[None, None, None, :]
-        kconv_w = wk.numpy()[n_idx, k_idx].astype(np.float32)                       # [25,2,32,64]
-        kconv_b = bk.numpy().reshape(c, 25).T.copy()                                  # [tap][ch]
-        fus = sd[p + "fusion.weight"].to("cpu", f32).reshape(c, 2 * c)
-        wa, wb = fus[:, :c].numpy(), fus[:, c:].numpy()                              # cat((sta, fea)), :374
+        jj = np.arange(8)
+        # kconv part [tap][cg][ks][lane][j] = Wk[25 (32 cg + (lane & 31)) + tap][16 ks + 8 (lane >> 5) + j]
+        tap = np.arange(25)[:, None, None, None, None]
+        cg = np.arange(2)[None, :, None, None, None]
+        ks = np.arange(4)[None, None, :, None, None]
+        n_idx = 25 * (32 * cg + li[None, None, None, :, None]) + tap
+        k_idx = 16 * ks + 8 * lh[None, None, None, :, None] + jj[None, None, None, None, :]
+        n_idx, k_idx = np.broadcast_arrays(n_idx, k_idx)
+        kconv = wk[n_idx, k_idx].astype(np.float32)                                  # [25,2,4,64,8]
+        kconv_b = bk.reshape(c, 25).T.copy()                                          # [tap][ch]
+        fus = sd[p + "fusion.weight"].to("cpu", f32).reshape(c, 2 * c).numpy()
+        wa, wb = fus[:, :c], fus[:, c:]                                              # cat((sta, fea)), :374
         comp = sd[p + "weight_compress"].to("cpu", f32).reshape(4, 8, c).numpy()     # C_m[j][c]
         expd = sd[p + "weight_expand"].to("cpu", f32).reshape(4, c, 8).numpy()       # E_n[c][j]
-        rows = np.array([acc_row(r, 0) for r in range(16)]), np.array([acc_row(r, 1) for r in range(16)])
-        proj = np.zeros((5, 32, 64), dtype=np.float32)
+        # projections, one 512-element group per (matrix tile, k step): [lane][j]
+        pa = np.zeros((2, 4, 64, 8), dtype=np.float32)
+        pb = np.zeros((2, 4, 64, 8), dtype=np.float32)
+        pc = np.zeros((4, 64, 8), dtype=np.float32)
         for t in range(2):
-            for kidx in range(32):
-                cgi, r = kidx // 16, kidx % 16
-                ch = 32 * cgi + np.where(lh == 0, rows[0][r], rows[1][r])
-                proj[t, kidx, :] = wa[32 * t + li, ch]                               # Wa . sta  (k order = accumulator order)
-            for si in range(32):
-                proj[2 + t, si, :] = wb[32 * t + li, 2 * si + lh]                    # Wb . x
+            for kidx in range(4):
+                cgi, s = kidx // 2, kidx % 2
+                # k order of an accumulator used as B operand: row 16 s + 8 (j >> 2) + 4 half + (j & 3)
+                ch = 32 * cgi + 16 * s + 8 * (jj[None, :] >> 2) + 4 * lh[:, None] + (jj[None, :] & 3)
+                pa[t, kidx] = wa[(32 * t + li)[:, None], ch]
+            for ksi in range(4):
+                pb[t, ksi] = wb[(32 * t + li)[:, None], 16 * ksi + 8 * lh[:, None] + jj[None, :]]
         cstack = comp.reshape(32, c)                                                  # row m*8 + j
         r_of_i = (li & 3) + 4 * (li >> 3)
         hh_of_i = (li >> 2) & 1
         ch_of_i = 8 * (r_of_i >> 2) + 2 * (r_of_i & 3) + hh_of_i                     # record slot r = 4m+jj <-> j = 2jj+hh
-        for si in range(32):
-            proj[4, si, :] = cstack[ch_of_i, 2 * si + lh]
+        for ksi in range(4):
+            pc[ksi] = cstack[ch_of_i[:, None], 16 * ksi + 8 * lh[:, None] + jj[None, :]]
+        proj = np.concatenate([pa.reshape(-1), pb.reshape(-1), pc.reshape(-1)])
         wbe = np.einsum("oc,ncj->noj", wb.astype(np.float64), expd.astype(np.float64)).astype(np.float32)   # (Wb E_n)[co][j]
         wbe_p = np.zeros((2, 16, 64), dtype=np.float32)
         for t in range(2):
@@ -211,11 +260,12 @@ class HipEngine:
         head_w = torch.cat([sd[p + "routing.0.weight"], sd[p + "offset.weight"], sd[p + "st_offset.weight"]], 0)
         head_b = torch.cat([sd[p + "routing.0.bias"], sd[p + "offset.bias"], sd[p + "st_offset.bias"]], 0)
         t_ = lambda a: self._dev(torch.from_numpy(np.ascontiguousarray(a)))
+        img = lambda a: self._dev(split_bf16_image(torch.from_numpy(np.ascontiguousarray(a.reshape(-1)))), torch.int16)
         self.satu_t = dict(
             body0_w=self._dev(sd[p + "body.0.weight"].reshape(64, 4)), body0_b=self._dev(sd[p + "body.0.bias"]),
             body2_w=self._dev(sd[p + "body.2.weight"].reshape(64, 64).t()), body2_b=self._dev(sd[p + "body.2.bias"]),
             head_w=self._dev(head_w.reshape(8, 64)), head_b=self._dev(head_b),
-            kconv_w=t_(kconv_w), kconv_b=t_(kconv_b), proj_w=t_(proj), wbe_w=t_(wbe_p), fusion_b=t_(fb_p))
+            kconv_w=img(kconv), kconv_b=t_(kconv_b), proj_w=img(proj), wbe_w=t_(wbe_p), fusion_b=t_(fb_p))
         sw = SatuWeights()
         for k, v in self.satu_t.items():
             setattr(sw, k, v.data_ptr())
@@ -226,8 +276,7 @@ class HipEngine:
     def _pack_all(self, sd):
         cfg = self.cfg
         for d in ("f2p_win", "p2f_win"):
-            self._add_conv(sd, d + ".conv_c")
-            self._add_conv(sd, d + ".conv_sup")
+            self._add_window_conv(sd, d)
             for k in range(cfg["w1_num_block"]):
                 b = f"{d}.blocks.{k}"
                 for i in range(3):
@@ -271,7 +320,7 @@ class HipEngine:
         self._add_conv(sd, "conv_last")
         self.gamma = float(sd["gamma"].reshape(-1)[0])
         self._pack_satu(sd)
-        self.se_mean = torch.empty(self.nf, device=self.dev)
+        self.se_partial = torch.empty(MAX_SUM_BLOCKS * self.nf, device=self.dev)
         self.se_gate = torch.empty(self.nf, device=self.dev)
 
     # ------------------------------------------------------------------ buffers / launch helpers
@@ -287,110 +336,115 @@ class HipEngine:
     def _stream() -> int:
         return torch.cuda.current_stream().cuda_stream
 
-    def full(self, t: torch.Tensor, ch: int, hp: int, wp: int) -> _Src:
-        return _Src(t, ch, hp * wp, wp)
+    @staticmethod
+    def full(t: torch.Tensor, ch: Optional[int] = None, ch_off: int = 0) -> Src:
+        """Channel slice [ch_off, ch_off+ch) of a contiguous channel-last tensor [h][w][C]."""
+        c_total = t.shape[-1]
+        return Src(t, c_total - ch_off if ch is None else ch, c_total, ch_off)
 
-    def conv(self, key, srcs: List[_Src], out: torch.Tensor, h: int, w: int, act=ACT_NONE, slope=0.0,
-             mul_px=None, res1=None, res2=None, res2_scale=0.0, weights=None):
+    def conv(self, key, srcs: List[Src], out: Src, h: int, w: int, act=ACT_NONE, slope=0.0,
+             mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None):
         wpk, bias, cout, cin, ks = weights if weights is not None else self.pw[key]
         d = ConvDesc()
         assert len(srcs) <= _lib.MAX_SRC and all(s.ch == srcs[0].ch for s in srcs)
         assert cin == len(srcs) * srcs[0].ch, (key, cin, len(srcs), srcs[0].ch)
+        assert out.ch == cout, (key, out.ch, cout)
         for i, s in enumerate(srcs):
             d.src[i] = s.ptr
-            d.src_plane[i] = s.plane
-            d.src_row[i] = s.row
+            d.src_pix[i] = s.pix
         d.nsrc, d.src_ch, d.h, d.w, d.cin, d.cout, d.ksize = len(srcs), srcs[0].ch, h, w, cin, cout, ks
         d.wpacked, d.bias, d.act, d.slope = wpk.data_ptr(), _ptr(bias), act, slope
-        d.mul_px, d.res1, d.res2, d.res2_scale = _ptr(mul_px), _ptr(res1), _ptr(res2), res2_scale
-        d.out, d.out_plane, d.out_row = out.data_ptr(), h * w, w
+        d.mul_px = _ptr(mul_px)
+        if res1 is not None:
+            d.res1, d.res1_pix = res1.ptr, res1.pix
+        if res2 is not None:
+            d.res2, d.res2_pix = res2.ptr, res2.pix
+        d.res2_scale = res2_scale
+        d.out, d.out_pix = out.ptr, out.pix
         _lib.check(self.lib.savsr_conv2d(C.byref(d), self._stream()), f"savsr_conv2d[{key}]")
         return out
 
-    def channel_mean(self, srcs: List[_Src], h: int, w: int, mean: torch.Tensor):
+    def channel_sums(self, srcs: List[Src], npx: int, partial: torch.Tensor) -> int:
         n = len(srcs)
+        nblk = max(1, min(MAX_SUM_BLOCKS, npx // 512))
         ptrs = (_lib.fptr * n)(*[s.ptr for s in srcs])
-        planes = (C.c_int64 * n)(*[s.plane for s in srcs])
-        rows = (C.c_int32 * n)(*[s.row for s in srcs])
-        _lib.check(self.lib.savsr_channel_mean(ptrs, planes, rows, n, srcs[0].ch, h, w, mean.data_ptr(), self._stream()),
-                   "savsr_channel_mean")
+        pix = (C.c_int32 * n)(*[s.pix for s in srcs])
+        _lib.check(self.lib.savsr_channel_sums(ptrs, pix, n, srcs[0].ch, npx, nblk, partial.data_ptr(), self._stream()),
+                   "savsr_channel_sums")
+        return nblk
 
-    def osconv_weights(self, key: str, srcs: List[_Src], h: int, w: int, scale):
-        """Pool -> routing/attention -> aggregated packed weight (savsr_arch.py:143-163)."""
+    def osconv_weights(self, key: str, srcs: List[Src], h: int, w: int, scale):
+        """Pool -> routing/attention -> aggregated split-bf16 weight image (savsr_arch.py:143-163)."""
         e = self.osc[key]
-        self.channel_mean(srcs, h, w, e["mean"])
+        nblk = self.channel_sums(srcs, h * w, e["partial"])
         d = OSConvAttnDesc()
         d.cin, d.cout, d.hidden, d.knum = e["cin"], e["cout"], e["hidden"], e["knum"]
         d.inv_sh, d.inv_sw = 1.0 / scale[0], 1.0 / scale[1]
-        for k in ("mean", "l1_w", "l1_b", "l2_w", "l2_b", "fc_w", "bn_scale", "bn_shift", "ch_w", "ch_b", "fl_w", "fl_b",
-                  "sp_w", "sp_b", "kn_w", "kn_b", "att"):
+        d.nblk, d.inv_n, d.nunits = nblk, 1.0 / (h * w), e["nunits"]
+        for k in ("partial", "l1_w", "l1_b", "l2_w", "l2_b", "fc_w", "bn_scale", "bn_shift", "ch_w", "ch_b", "fl_w", "fl_b",
+                  "sp_w", "sp_b", "kn_w", "kn_b", "v1", "v2", "bank", "att"):
             setattr(d, k, e[k].data_ptr())
-        st = self._stream()
-        _lib.check(self.lib.savsr_osconv_attention(C.byref(d), st), f"savsr_osconv_attention[{key}]")
-        _lib.check(self.lib.savsr_osconv_aggregate(e["bank"].data_ptr(), e["att"].data_ptr(), e["cin"], e["cout"], e["knum"],
-                                                   e["wdyn"].data_ptr(), st), f"savsr_osconv_aggregate[{key}]")
+        d.wimg_out = e["wdyn"].data_ptr()
+        _lib.check(self.lib.savsr_osconv_weights(C.byref(d), self._stream()), f"savsr_osconv_weights[{key}]")
         return (e["wdyn"], None, e["cout"], e["cin"], 3)
 
     # ------------------------------------------------------------------ network pieces
-    def residual_block(self, pfx: str, xs: List[torch.Tensor], hp: int, wp: int, scale, use_osconv: bool, tag: str):
+    def residual_block(self, pfx: str, xs: List[Src], hp: int, wp: int, scale, use_osconv: bool, tag: str) -> List[Src]:
         """savsr_arch.py:399-415, cat-free."""
-        n = len(xs)
-        nf = self.nf
-        x1 = [self.conv(f"{pfx}.conv0.{i}", [self.full(xs[i], nf, hp, wp)], self.buf(f"{tag}.x1.{i}", nf, hp, wp), hp, wp,
-                        ACT_LRELU, 0.2) for i in range(n)]
-        x1s = [self.full(t, nf, hp, wp) for t in x1]
-        base = self.buf(f"{tag}.base", nf, hp, wp)
+        n, nf = len(xs), self.nf
+        x1 = [self.conv(f"{pfx}.conv0.{i}", [xs[i]], self.full(self.buf(f"{tag}.x1.{i}", hp, wp, nf)), hp, wp, ACT_LRELU, 0.2)
+              for i in range(n)]
+        base = self.full(self.buf(f"{tag}.base", hp, wp, nf))
         if use_osconv:
-            wd = self.osconv_weights(pfx + ".osconv", x1s, hp, wp, scale)
-            self.conv(pfx + ".osconv", x1s, base, hp, wp, ACT_LRELU, 0.2, weights=wd)
+            wd = self.osconv_weights(pfx + ".osconv", x1, hp, wp, scale)
+            self.conv(pfx + ".osconv", x1, base, hp, wp, ACT_LRELU, 0.2, weights=wd)
         else:
-            self.conv(pfx + ".conv1", x1s, base, hp, wp, ACT_LRELU, 0.2)
-        bs = self.full(base, nf, hp, wp)
-        return [self.conv(f"{pfx}.conv2.{i}", [bs, x1s[i]], self.buf(f"{tag}.out.{i}", nf, hp, wp), hp, wp, ACT_LRELU, 0.2,
-                          res1=xs[i]) for i in range(n)]
+            self.conv(pfx + ".conv1", x1, base, hp, wp, ACT_LRELU, 0.2)
+        return [self.conv(f"{pfx}.conv2.{i}", [base, x1[i]], self.full(self.buf(f"{tag}.out.{i}", hp, wp, nf)), hp, wp,
+                          ACT_LRELU, 0.2, res1=xs[i]) for i in range(n)]
 
-    def window_l1(self, pfx: str, frames: torch.Tensor, t: int, h_past: torch.Tensor, hp: int, wp: int, scale, tag: str):
-        """savsr_arch.py:444-464.  frames: padded clip [T][3][hp][wp]; window (t-1, t, t+1)."""
+    def window_l1(self, pfx: str, win: Src, h_past: Src, hp: int, wp: int, scale, tag: str) -> List[Src]:
+        """savsr_arch.py:444-464.  win: packed window [hp][wp][16] (frame t | t-1 | t+1 | 0)."""
         nf = self.nf
-        fr = lambda k: _Src(frames, 3, hp * wp, wp, offset_floats=k * 3 * hp * wp)
-        h_sup = self.conv(pfx + ".conv_sup", [fr(t - 1), fr(t + 1)], self.buf(f"{tag}.hsup", nf, hp, wp), hp, wp, ACT_LRELU, 0.2)
-        h_c = self.conv(pfx + ".conv_c", [fr(t)], self.buf(f"{tag}.hc", nf, hp, wp), hp, wp, ACT_LRELU, 0.2)
-        feats = [h_c, h_sup, h_past]
+        hcs = self.buf(f"{tag}.hcs", hp, wp, 2 * nf)                 # h_c | h_sup from one fused conv
+        self.conv(pfx + ".win", [win], self.full(hcs), hp, wp, ACT_LRELU, 0.2)
+        feats = [self.full(hcs, nf, 0), self.full(hcs, nf, nf), h_past]
         for k in range(self.cfg["w1_num_block"]):
             feats = self.residual_block(f"{pfx}.blocks.{k}", feats, hp, wp, scale, k >= 1, f"{tag}.b{k}")
         return feats
 
-    def rcab(self, pfx: str, x: torch.Tensor, out: torch.Tensor, hp: int, wp: int, tag: str):
+    def rcab(self, pfx: str, x: Src, out: Src, hp: int, wp: int, tag: str) -> Src:
         """savsr_arch.py:527-549."""
         nf = self.nf
-        r1 = self.conv(pfx + ".0", [self.full(x, nf, hp, wp)], self.buf(f"{tag}.t1", nf, hp, wp), hp, wp, ACT_RELU)
-        r2 = self.conv(pfx + ".2", [self.full(r1, nf, hp, wp)], self.buf(f"{tag}.t2", nf, hp, wp), hp, wp, ACT_NONE)
-        self.channel_mean([self.full(r2, nf, hp, wp)], hp, wp, self.se_mean)
+        r1 = self.conv(pfx + ".0", [x], self.full(self.buf(f"{tag}.t1", hp, wp, nf)), hp, wp, ACT_RELU)
+        r2 = self.conv(pfx + ".2", [r1], self.full(self.buf(f"{tag}.t2", hp, wp, nf)), hp, wp, ACT_NONE)
+        nblk = self.channel_sums([r2], hp * wp, self.se_partial)
         w1, b1, w2, b2, cm = self.se[pfx]
         st = self._stream()
-        _lib.check(self.lib.savsr_se_gate(self.se_mean.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                          nf, cm, self.se_gate.data_ptr(), st), "savsr_se_gate")
-        _lib.check(self.lib.savsr_scale_residual(r2.data_ptr(), self.se_gate.data_ptr(), x.data_ptr(), out.data_ptr(), nf,
-                                                 hp * wp, st), "savsr_scale_residual")
+        _lib.check(self.lib.savsr_se_gate(self.se_partial.data_ptr(), nblk, 1.0 / (hp * wp), w1.data_ptr(), b1.data_ptr(),
+                                          w2.data_ptr(), b2.data_ptr(), nf, cm, self.se_gate.data_ptr(), st), "savsr_se_gate")
+        assert x.pix == nf and out.pix == nf
+        _lib.check(self.lib.savsr_scale_residual(r2.ptr, self.se_gate.data_ptr(), x.ptr, out.ptr, nf, hp * wp, st),
+                   "savsr_scale_residual")
         return out
 
-    def osadapt(self, g: int, x: torch.Tensor, share: torch.Tensor, out: torch.Tensor, hp: int, wp: int, scale):
-        """savsr_arch.py:186-214 fused with `+ gamma * share` of :732."""
-        nf = self.nf
+    def osadapt(self, g: int, x: Src, share: Optional[Src], out: Src, hp: int, wp: int, scale) -> Src:
+        """savsr_arch.py:186-214 fused with `+ gamma * share` of :732 (share=None: OSAdapt alone)."""
         m = f"adapt.{g}.mask"
         st = self._stream()
         c4 = self.pw[m + ".0"][2]
-        m1 = self.conv(m + ".0", [self.full(x, nf, hp, wp)], self.buf("ad.m1", c4, hp, wp), hp, wp, ACT_RELU)
-        m2 = self.buf("ad.m2", c4, hp // 2, wp // 2)
-        _lib.check(self.lib.savsr_avgpool2(m1.data_ptr(), m2.data_ptr(), c4, hp, wp, st), "savsr_avgpool2")
-        m3 = self.conv(m + ".4", [self.full(m2, c4, hp // 2, wp // 2)], self.buf("ad.m3", c4, hp // 2, wp // 2), hp // 2, wp // 2, ACT_RELU)
-        m4 = self.conv(m + ".7", [self.full(m3, c4, hp // 2, wp // 2)], self.buf("ad.m4", c4, hp // 2, wp // 2), hp // 2, wp // 2, ACT_RELU)
-        m5 = self.buf("ad.m5", c4, hp, wp)
-        _lib.check(self.lib.savsr_upsample2x(m4.data_ptr(), m5.data_ptr(), c4, hp // 2, wp // 2, st), "savsr_upsample2x")
-        mask = self.conv(m + ".11", [self.full(m5, c4, hp, wp)], self.buf("ad.mask", 1, hp, wp), hp, wp, ACT_SIGMOID)
-        xs = [self.full(x, nf, hp, wp)]
-        wd = self.osconv_weights(f"adapt.{g}.adapt", xs, hp, wp, scale)
-        return self.conv(f"adapt.{g}.adapt", xs, out, hp, wp, ACT_NONE, mul_px=mask, res1=x, res2=share,
+        h2, w2 = hp // 2, wp // 2
+        m1 = self.conv(m + ".0", [x], self.full(self.buf("ad.m1", hp, wp, c4)), hp, wp, ACT_RELU)
+        m2 = self.buf("ad.m2", h2, w2, c4)
+        _lib.check(self.lib.savsr_avgpool2(m1.ptr, m2.data_ptr(), c4, hp, wp, st), "savsr_avgpool2")
+        m3 = self.conv(m + ".4", [self.full(m2)], self.full(self.buf("ad.m3", h2, w2, c4)), h2, w2, ACT_RELU)
+        m4 = self.conv(m + ".7", [m3], self.full(self.buf("ad.m4", h2, w2, c4)), h2, w2, ACT_RELU)
+        m5 = self.buf("ad.m5", hp, wp, c4)
+        _lib.check(self.lib.savsr_upsample2x(m4.ptr, m5.data_ptr(), c4, h2, w2, st), "savsr_upsample2x")
+        mask = self.buf("ad.mask", hp, wp, 1)
+        self.conv(m + ".11", [self.full(m5)], self.full(mask), hp, wp, ACT_SIGMOID)
+        wd = self.osconv_weights(f"adapt.{g}.adapt", [x], hp, wp, scale)
+        return self.conv(f"adapt.{g}.adapt", [x], out, hp, wp, ACT_NONE, mul_px=mask, res1=x, res2=share,
                          res2_scale=self.gamma, weights=wd)
 
     # ------------------------------------------------------------------ SATU
@@ -410,8 +464,9 @@ class HipEngine:
             self._satu_axes[key] = ent
         return ent
 
-    def satu(self, x: _Src, st: _Src, h: int, w: int, scale, out: torch.Tensor):
-        """STAUpsample.forward (savsr_arch.py:315-376).  x, st: strided [64][h][w] views."""
+    def satu(self, x: Src, st: Src, row_px: int, h: int, w: int, scale, out: torch.Tensor):
+        """STAUpsample.forward (savsr_arch.py:315-376).  x, st: channel-last crops (row pitch row_px
+        pixels) of [..][..][64] maps; out: [64][H][W] planar."""
         ax = self.satu_axes(h, w, scale)
         s = self._stream()
         sw = C.byref(self.satu_w)
@@ -420,9 +475,9 @@ class HipEngine:
             ev0.record()
         _lib.check(self.lib.savsr_satu_phase_table(sw, ax["uh"].data_ptr(), ax["n_uh"], ax["uw"].data_ptr(), ax["n_uw"],
                                                    1.0 / scale[1], 1.0 / scale[0], ax["table"].data_ptr(), s), "savsr_satu_phase_table")
-        assert x.plane == st.plane and x.row == st.row
+        assert x.pix == st.pix
         lrcat = self.buf("satu.lrcat", h, w, _lib.SATU_LRCAT)
-        _lib.check(self.lib.savsr_satu_lr_stage(sw, x.ptr, st.ptr, x.plane, x.row, h, w, lrcat.data_ptr(), s), "savsr_satu_lr_stage")
+        _lib.check(self.lib.savsr_satu_lr_stage(sw, x.ptr, st.ptr, x.pix, row_px, h, w, lrcat.data_ptr(), s), "savsr_satu_lr_stage")
         _lib.check(self.lib.savsr_satu_hr_upsample(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(),
                                                    ax["iw"].data_ptr(), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"],
                                                    out.data_ptr(), s), "savsr_satu_hr_upsample")
@@ -441,59 +496,54 @@ class HipEngine:
             raise ValueError("SAVSR needs h, w >= 2")
         center = T // 2 if cfg["center_frame_idx"] is None else cfg["center_frame_idx"]
         H, W = get_hw(h_in, w_in, scale)
-        hp, wp = h_in + (h_in & 1), w_in + (w_in & 1)
+        hp, wp = h_in + (h_in & 1), w_in + (w_in & 1)              # pad_spatial to even (savsr_arch.py:670-690)
         st = self._stream()
-        if (hp, wp) != (h_in, w_in):
-            frames = self.buf("frames", T, 3, hp, wp)
-            _lib.check(self.lib.savsr_reflect_pad(lq.data_ptr(), frames.data_ptr(), T * 3, h_in, w_in, hp, wp, st), "savsr_reflect_pad")
-        else:
-            frames = lq
+        wins = self.buf("windows", T - 2, hp, wp, 16)
+        _lib.check(self.lib.savsr_pack_windows(lq.data_ptr(), wins.data_ptr(), T, h_in, w_in, hp, wp, st), "savsr_pack_windows")
+        win = lambda t: Src(wins, 16, 16, 0, float_off=(t - 1) * hp * wp * 16)
         sw, fw = cfg["slid_win"], cfg["fusion_win"]
         steps = T - sw + 1
-        zero = self.buf("zero", nf, hp, wp)
+        zero = self.buf("zero", hp, wp, nf)
         zero.zero_()          # hidden state restarts from zero every window (savsr_arch.py:705-706)
-        hb, hf = zero, zero
-        lb: List[Optional[torch.Tensor]] = [None] * steps
-        lf: List[Optional[torch.Tensor]] = [None] * steps
+        hb = hf = self.full(zero)
+        hpair = [self.buf(f"hpair{i}", hp, wp, 2 * nf) for i in range(steps)]   # cat(f2p[i], p2f[i]) of :721, written in place
         for idx in range(steps):                                                    # :708-719
             cur = T - 1 - sw // 2 - idx
-            feats = self.window_l1("f2p_win", frames, cur, hb, hp, wp, scale, "f2p")
-            hb = self.conv("f2p_win.merge", [self.full(t, nf, hp, wp) for t in feats], self.buf(f"f2p.h{idx}", nf, hp, wp), hp, wp)
-            lb[steps - 1 - idx] = hb
+            feats = self.window_l1("f2p_win", win(cur), hb, hp, wp, scale, "f2p")
+            hb = self.conv("f2p_win.merge", feats, self.full(hpair[steps - 1 - idx], nf, 0), hp, wp)
             cur = idx + sw // 2
-            feats = self.window_l1("p2f_win", frames, cur, hf, hp, wp, scale, "p2f")
-            hf = self.conv("p2f_win.merge", [self.full(t, nf, hp, wp) for t in feats], self.buf(f"p2f.h{idx}", nf, hp, wp), hp, wp)
-            lf[idx] = hf
-        # pyramid fusion (:616-618, :485-501, :721-722): inputs as source lists, never concatenated
-        level: List[List[_Src]] = [[self.full(lb[i], nf, hp, wp), self.full(lf[i], nf, hp, wp)] for i in range(steps)]
+            feats = self.window_l1("p2f_win", win(cur), hf, hp, wp, scale, "p2f")
+            hf = self.conv("p2f_win.merge", feats, self.full(hpair[idx], nf, nf), hp, wp)
+        # pyramid fusion (:616-618, :485-501, :721-722)
+        level: List[Src] = [self.full(t) for t in hpair]
         for i in range(self.n_l2):
             u = f"h_win.{i}"
             ws = steps - 2 * i
-            hfs = [self.conv(f"{u}.conv_h.{j}", level[j], self.buf(f"l2.{i}.hf{j}", nf, hp, wp), hp, wp, ACT_LRELU, 0.2) for j in range(ws)]
-            nxt: List[List[_Src]] = []
+            hfs = [self.conv(f"{u}.conv_h.{j}", [level[j]], self.full(self.buf(f"l2.{i}.hf{j}", hp, wp, nf)), hp, wp, ACT_LRELU, 0.2)
+                   for j in range(ws)]
+            nxt: List[Src] = []
             for j in range(ws - fw + 1):
                 swf = hfs[j:j + fw]
                 for k in range(cfg["w2_num_block"]):
                     swf = self.residual_block(f"{u}.blocks.{k}", swf, hp, wp, scale, True, f"l2.{i}.{j}.b{k}")
-                o = self.conv(u + ".merge", [self.full(t, nf, hp, wp) for t in swf], self.buf(f"l2.{i}.o{j}", 2 * nf, hp, wp), hp, wp)
-                nxt.append([self.full(o, 2 * nf, hp, wp)])
+                nxt.append(self.conv(u + ".merge", swf, self.full(self.buf(f"l2.{i}.o{j}", hp, wp, 2 * nf)), hp, wp))
             level = nxt
-        align = self.conv("h_win_conv_h", level[0], self.buf("align", nf, hp, wp), hp, wp, ACT_LRELU, 0.2)   # :723
+        align = self.conv("h_win_conv_h", [level[0]], self.full(self.buf("align", hp, wp, nf)), hp, wp, ACT_LRELU, 0.2)   # :723
         share = align
         hcur = align
         for g in range(cfg["n_resgroups"]):                                         # :728-732
             xin = hcur
             r = xin
             for k in range(cfg["n_resblocks"]):
-                r = self.rcab(f"RG.{g}.residual_group.{k}.rcab", r, self.buf(f"rg.r{k & 1}", nf, hp, wp), hp, wp, "rg")
-            rg = self.conv(f"RG.{g}.conv", [self.full(r, nf, hp, wp)], self.buf("rg.out", nf, hp, wp), hp, wp, res1=xin)
-            hcur = self.osadapt(g, rg, share, self.buf(f"rg.h{g & 1}", nf, hp, wp), hp, wp, scale)
-        hfeat = self.conv("conv_last", [self.full(hcur, nf, hp, wp)], self.buf("hfeat", nf, hp, wp), hp, wp, res1=share)   # :733-734
-        if taps is not None:
-            taps["align_feat"] = align
-            taps["h_feat"] = hfeat
+                r = self.rcab(f"RG.{g}.residual_group.{k}.rcab", r, self.full(self.buf(f"rg.r{k & 1}", hp, wp, nf)), hp, wp, "rg")
+            rg = self.conv(f"RG.{g}.conv", [r], self.full(self.buf("rg.out", hp, wp, nf)), hp, wp, res1=xin)
+            hcur = self.osadapt(g, rg, share, self.full(self.buf(f"rg.h{g & 1}", hp, wp, nf)), hp, wp, scale)
+        hfeat = self.conv("conv_last", [hcur], self.full(self.buf("hfeat", hp, wp, nf)), hp, wp, res1=share)   # :733-734
+        if taps is not None:                    # channel-last [hp][wp][64] tensors
+            taps["align_feat"] = align.t
+            taps["h_feat"] = hfeat.t
         satu_out = self.buf("satu.out", nf, H, W)
-        self.satu(_Src(hfeat, nf, hp * wp, wp), _Src(align, nf, hp * wp, wp), h_in, w_in, scale, satu_out)   # crops of :737
+        self.satu(hfeat, align, wp, h_in, w_in, scale, satu_out)                     # crops of :737 via (row pitch, h, w)
         if taps is not None:
             taps["satu"] = satu_out
         cptr = lq.data_ptr() + 4 * center * 3 * h_in * w_in                         # unpadded centre frame (:696)

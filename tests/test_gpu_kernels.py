@@ -33,15 +33,27 @@ def _maxerr(a, b):
     return float((a.detach().cpu().float() - b.detach().cpu().float()).abs().max())
 
 
+def cl(x):
+    """planar [C, h, w] (CPU) -> channel-last [h, w, C] on the GPU"""
+    return x.permute(1, 2, 0).contiguous().to("cuda:0")
+
+
+def pl(t):
+    """channel-last [h, w, C] (GPU) -> planar [C, h, w] on the CPU"""
+    return t.detach().cpu().permute(2, 0, 1).contiguous()
+
+
 @pytest.mark.parametrize("cin,cout,ks,nsrc,h,w", [
     (64, 64, 3, 1, 10, 12), (192, 64, 3, 3, 9, 40), (128, 64, 3, 2, 12, 33), (320, 128, 3, 5, 8, 35),
-    (192, 64, 1, 3, 7, 50), (3, 64, 3, 1, 13, 31), (6, 64, 3, 2, 6, 70), (64, 16, 3, 1, 10, 12),
-    (16, 16, 3, 1, 5, 6), (16, 1, 3, 1, 10, 12), (128, 64, 3, 1, 9, 11)])
+    (192, 64, 1, 3, 7, 50), (16, 128, 3, 1, 13, 31), (64, 16, 3, 1, 10, 12),
+    (16, 16, 3, 1, 5, 6), (16, 1, 3, 1, 10, 12), (128, 64, 3, 1, 19, 11)])
 def test_conv2d(eng, cin, cout, ks, nsrc, h, w):
+    """savsr_conv2d (split-bf16 MFMA) vs F.conv2d fp32 incl. the fused epilogue; tolerance 1e-4
+    absolute on O(1) outputs (bf16x3 products carry ~2^-17 relative error)."""
     from savsr_amd import engine as E
     from savsr_amd._lib import ACT_LRELU
     g = np.random.RandomState(cin * 7 + cout)
-    wt = torch.from_numpy(g.standard_normal((cout, cin, ks, ks)).astype(np.float32) / np.sqrt(cin * ks * ks))
+    wt = torch.from_numpy((g.standard_normal((cout, cin, ks, ks)) / np.sqrt(cin * ks * ks)).astype(np.float32))
     bias = torch.from_numpy(g.standard_normal(cout).astype(np.float32))
     x = torch.from_numpy(g.standard_normal((cin, h, w)).astype(np.float32))
     res = torch.from_numpy(g.standard_normal((cout, h, w)).astype(np.float32))
@@ -49,13 +61,18 @@ def test_conv2d(eng, cin, cout, ks, nsrc, h, w):
     mul = torch.from_numpy(g.uniform(0, 1, (h, w)).astype(np.float32))
     ref = F.leaky_relu(F.conv2d(x[None], wt, bias, padding=ks // 2), 0.2)[0] * mul + res + 0.9 * res2
     sch = cin // nsrc
-    xs = [_dev(x[i * sch:(i + 1) * sch]) for i in range(nsrc)]
-    out = torch.full((cout, h, w), float("nan"), device="cuda:0")
+    # sources are channel slices of ONE wider channel-last tensor (exercises pix > ch)
+    xall = cl(x)
+    srcs = [eng.full(xall, sch, i * sch) for i in range(nsrc)]
+    wide = torch.full((h, w, cout + 4), float("nan"), device="cuda:0")       # output written as a slice, too
+    out = E.Src(wide, cout, cout + 4, 4 if cout % 4 == 0 else 0)
     weights = (_dev(E.pack_conv_weight(wt)), _dev(bias), cout, cin, ks)
-    eng.conv("test", [eng.full(t, sch, h, w) for t in xs], out, h, w, ACT_LRELU, 0.2, mul_px=_dev(mul), res1=_dev(res),
-             res2=_dev(res2), res2_scale=0.9, weights=weights)
+    eng.conv("test", srcs, out, h, w, ACT_LRELU, 0.2, mul_px=_dev(mul), res1=eng.full(cl(res)), res2=eng.full(cl(res2)),
+             res2_scale=0.9, weights=weights)
     torch.cuda.synchronize()
-    assert _maxerr(out, ref) < 1e-4
+    off = 4 if cout % 4 == 0 else 0
+    got = pl(wide[..., off:off + cout])
+    assert _maxerr(got, ref) < 1e-4
 
 
 def test_conv2d_rejects_bad_args(eng):
@@ -64,6 +81,8 @@ def test_conv2d_rejects_bad_args(eng):
     d.ksize = 5
     assert eng.lib.savsr_conv2d(C.byref(d), None) < 0
     assert b"ksize" in eng.lib.savsr_last_error()
+    d.ksize, d.nsrc, d.src_ch, d.cin = 3, 1, 24, 24          # not a multiple of 16
+    assert eng.lib.savsr_conv2d(C.byref(d), None) < 0
 
 
 @pytest.mark.parametrize("tag,pfx,cin", OSCONV_CASES)
@@ -72,14 +91,14 @@ def test_osconv_vs_golden(eng, golden, synth_sd, tag, pfx, cin):
     for sc in OSCONV_SCALES:
         x = rnd((1, cin, 10, 12), 11 + cin, 0.7)
         nsrc = cin // 64
-        xs = [_dev(x[0, i * 64:(i + 1) * 64]) for i in range(nsrc)]
-        srcs = [eng.full(t, 64, 10, 12) for t in xs]
+        xall = cl(x[0])
+        srcs = [eng.full(xall, 64, i * 64) for i in range(nsrc)]
         wd = eng.osconv_weights(pfx, srcs, 10, 12, sc)
-        out = torch.empty(64, 10, 12, device="cuda:0")
-        eng.conv(pfx, srcs, out, 10, 12, weights=wd)
+        out = torch.empty(10, 12, 64, device="cuda:0")
+        eng.conv(pfx, srcs, eng.full(out), 10, 12, weights=wd)
         torch.cuda.synchronize()
         gold = torch.from_numpy(golden[f"osconv/{tag}/{sc[0]}_{sc[1]}"])[0]
-        assert _maxerr(out, gold) < 1e-4
+        assert _maxerr(pl(out), gold) < 1e-4
         # attention vector itself against the oracle
         with torch.no_grad():
             b = 1
@@ -93,27 +112,32 @@ def test_osconv_vs_golden(eng, golden, synth_sd, tag, pfx, cin):
         assert _maxerr(att, ref_att) < 1e-5
 
 
+def test_channel_sums_large(eng):
+    """Many-block pooled means (64 workgroups) against torch."""
+    x = rnd((192, 90, 100), 7)
+    xall = cl(x)
+    srcs = [eng.full(xall, 64, i * 64) for i in range(3)]
+    part = torch.zeros(64 * 192, device="cuda:0")
+    nblk = eng.channel_sums(srcs, 90 * 100, part)
+    torch.cuda.synchronize()
+    mean = part.view(64, 192)[:nblk].sum(0).cpu() / (90 * 100)
+    assert _maxerr(mean, x.mean(dim=(1, 2))) < 1e-5
+
+
 def test_osadapt_vs_golden(eng, golden):
     x = rnd((1, 64, 10, 12), 5, 0.8)
-    share = torch.zeros(64, 10, 12)
-    out = torch.empty(64, 10, 12, device="cuda:0")
-    g0 = eng.gamma
-    eng.gamma = 0.0          # the golden is OSAdapt alone (no + gamma*share)
-    try:
-        eng.osadapt(1, _dev(x[0]), _dev(share), out, 10, 12, (2.5, 2.5))
-        torch.cuda.synchronize()
-    finally:
-        eng.gamma = g0
-    assert _maxerr(out, torch.from_numpy(golden["osadapt/a1/2.5_2.5"])[0]) < 1e-4
+    out = torch.empty(10, 12, 64, device="cuda:0")
+    eng.osadapt(1, eng.full(cl(x[0])), None, eng.full(out), 10, 12, (2.5, 2.5))      # golden is OSAdapt alone
+    torch.cuda.synchronize()
+    assert _maxerr(pl(out), torch.from_numpy(golden["osadapt/a1/2.5_2.5"])[0]) < 1e-4
 
 
 def _run_satu(eng, x, st, sc):
-    from savsr_amd.engine import _Src, get_hw
+    from savsr_amd.engine import get_hw
     h, w = x.shape[-2:]
     H, W = get_hw(h, w, sc)
-    xd, sd_ = _dev(x[0]), _dev(st[0])
     out = torch.full((64, H, W), float("nan"), device="cuda:0")
-    eng.satu(_Src(xd, 64, h * w, w), _Src(sd_, 64, h * w, w), h, w, sc, out)
+    eng.satu(eng.full(cl(x[0])), eng.full(cl(st[0])), w, h, w, sc, out)
     torch.cuda.synchronize()
     return out
 
@@ -164,14 +188,13 @@ def test_satu_large_offsets_and_borders(eng, synth_sd):
 
 def test_satu_strided_crop(eng, synth_sd):
     """SATU reads crops of padded tensors through strides (savsr_arch.py:737)."""
-    from savsr_amd.engine import _Src, get_hw
+    from savsr_amd.engine import get_hw
     hp, wp, h, w, sc = 10, 12, 9, 11, (2, 2)
     xf = rnd((1, 64, hp, wp), 41, 1.0)
     sf = rnd((1, 64, hp, wp), 42, 0.6)
     H, W = get_hw(h, w, sc)
     out = torch.empty(64, H, W, device="cuda:0")
-    xd, sd_ = _dev(xf[0]), _dev(sf[0])
-    eng.satu(_Src(xd, 64, hp * wp, wp), _Src(sd_, 64, hp * wp, wp), h, w, sc, out)
+    eng.satu(eng.full(cl(xf[0])), eng.full(cl(sf[0])), wp, h, w, sc, out)
     torch.cuda.synchronize()
     with torch.no_grad():
         ref = O.sta_upsample(synth_sd, "upsample", xf[..., :h, :w], sc, sf[..., :h, :w])[0]
@@ -195,15 +218,28 @@ def test_tail_residual(eng, synth_sd):
 
 def test_small_elementwise(eng):
     from savsr_amd import _lib
-    x = rnd((5, 8, 10), 61)
-    xd = _dev(x)
-    o = torch.empty(5, 4, 5, device="cuda:0")
-    _lib.check(eng.lib.savsr_avgpool2(xd.data_ptr(), o.data_ptr(), 5, 8, 10, None), "avgpool2")
-    assert _maxerr(o, F.avg_pool2d(x[None], 2)[0]) < 1e-6
-    o = torch.empty(5, 16, 20, device="cuda:0")
-    _lib.check(eng.lib.savsr_upsample2x(xd.data_ptr(), o.data_ptr(), 5, 8, 10, None), "upsample2x")
-    assert _maxerr(o, F.interpolate(x[None], scale_factor=2, mode="bilinear", align_corners=False)[0]) < 1e-6
-    x = rnd((6, 7, 9), 62)
-    o = torch.empty(6, 8, 10, device="cuda:0")
-    _lib.check(eng.lib.savsr_reflect_pad(_dev(x).data_ptr(), o.data_ptr(), 6, 7, 9, 8, 10, None), "reflect_pad")
-    assert _maxerr(o, F.pad(x[None], [0, 1, 0, 1], mode="reflect")[0]) == 0.0
+    x = rnd((16, 8, 10), 61)
+    xd = cl(x)
+    o = torch.empty(4, 5, 16, device="cuda:0")
+    _lib.check(eng.lib.savsr_avgpool2(xd.data_ptr(), o.data_ptr(), 16, 8, 10, None), "avgpool2")
+    torch.cuda.synchronize()
+    assert _maxerr(pl(o), F.avg_pool2d(x[None], 2)[0]) < 1e-6
+    o = torch.empty(16, 20, 16, device="cuda:0")
+    _lib.check(eng.lib.savsr_upsample2x(xd.data_ptr(), o.data_ptr(), 16, 8, 10, None), "upsample2x")
+    torch.cuda.synchronize()
+    assert _maxerr(pl(o), F.interpolate(x[None], scale_factor=2, mode="bilinear", align_corners=False)[0]) < 1e-6
+
+
+def test_pack_windows_reflect_pad(eng):
+    """Window packing + pad_spatial reflect padding (savsr_arch.py:448-454, 670-690), exact."""
+    from savsr_amd import _lib
+    T, h, w = 7, 7, 9
+    lq = torch.from_numpy(np.random.RandomState(3).uniform(0, 1, (T, 3, h, w)).astype(np.float32))
+    o = torch.empty(T - 2, 8, 10, 16, device="cuda:0")
+    _lib.check(eng.lib.savsr_pack_windows(_dev(lq).data_ptr(), o.data_ptr(), T, h, w, 8, 10, None), "pack_windows")
+    torch.cuda.synchronize()
+    padded = F.pad(lq, [0, 1, 0, 1], mode="reflect")
+    for q in range(T - 2):
+        t = q + 1
+        ref = torch.cat([padded[t], padded[t - 1], padded[t + 1], torch.zeros(7, 8, 10)], 0)
+        assert torch.equal(pl(o[q]), ref)

@@ -49,7 +49,10 @@ def test_stage_taps_vs_oracle(net, synth_sd):
     with torch.no_grad():
         ref = O.forward(synth_sd, lq, sc, taps=otaps)
     for k in ("align_feat", "h_feat", "satu"):
-        e = float((taps[k].cpu() - otaps[k][0]).abs().max())
+        got = taps[k].cpu()
+        if k != "satu":                       # channel-last [hp][wp][64] -> planar
+            got = got.permute(2, 0, 1)
+        e = float((got - otaps[k][0]).abs().max())
         print(k, e)
         assert e < 5e-4, (k, e)
     assert float((out.cpu() - ref).abs().max()) < 2e-4
@@ -106,19 +109,18 @@ def test_full_size_config2(net, synth_sd):
 def test_full_size_satu_linearity(net):
     """Size-independent property at 180x320 -> 720x1280: for fixed st_feat, SATU is affine in x
     (dynamic filters depend on st only, offsets/routing on coordinates only)."""
-    from savsr_amd.engine import _Src
     eng = net.engine()
     g = torch.Generator(device="cpu").manual_seed(0)
-    x1, x2, st = (torch.randn(64, 180, 320, generator=g).to("cuda:0") for _ in range(3))
+    x1, x2, st = (torch.randn(180, 320, 64, generator=g).to("cuda:0") for _ in range(3))
     z = torch.zeros_like(x1)
     outs = []
     for x in (x1, x2, 0.5 * x1 - 2.0 * x2, z):
         o = torch.empty(64, 720, 1280, device="cuda:0")
-        eng.satu(_Src(x, 64, 180 * 320, 320), _Src(st, 64, 180 * 320, 320), 180, 320, (4, 4), o)
+        eng.satu(eng.full(x), eng.full(st), 320, 180, 320, (4, 4), o)
         outs.append(o)
     torch.cuda.synchronize()
     y1, y2, y3, y0 = outs
     lin = 0.5 * (y1 - y0) - 2.0 * (y2 - y0) + y0
     rel = float((y3 - lin).abs().max() / y3.abs().max())
     print("satu linearity rel err", rel)
-    assert rel < 1e-5
+    assert rel < 5e-5

@@ -24,16 +24,16 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.savsr_abi_version() == 1
+    assert lib.savsr_abi_version() == _lib.ABI_VERSION
     assert b"gfx950" in lib.savsr_version()
 
 
 def test_pack_index_matches_c_abi():
     lib = _lib.load()
     rng = np.random.RandomState(0)
-    for (co, ci, ks) in [(64, 64, 3), (64, 192, 3), (128, 320, 3), (16, 64, 3), (1, 16, 3), (64, 192, 1), (64, 3, 3), (64, 6, 3)]:
+    for (co, ci, ks) in [(64, 64, 3), (64, 192, 3), (128, 320, 3), (16, 64, 3), (1, 16, 3), (64, 192, 1), (128, 16, 3)]:
         idx, total = E.conv_pack_index(co, ci, ks)
-        assert total == lib.savsr_conv_packed_floats(co, ci, ks)
+        assert total == lib.savsr_conv_packed_elems(co, ci, ks)
         assert len(np.unique(idx)) == len(idx) and idx.max() < total
         view = idx.reshape(co, ci, ks * ks)
         for _ in range(40):
@@ -46,7 +46,18 @@ def test_invalid_arguments_are_rejected_without_gpu():
     assert lib.savsr_conv2d(None, None) == -1
     assert b"null" in lib.savsr_last_error()
     assert lib.savsr_avgpool2(1, 2, 4, 3, 4, None) == -1      # odd height
-    assert lib.savsr_conv_packed_floats(64, 64, 5) == -1
+    assert lib.savsr_conv_packed_elems(64, 64, 5) == -1 and lib.savsr_conv_packed_elems(64, 24, 3) == -1
+
+
+def test_split_bf16_image_roundtrip():
+    """hi + lo reproduces fp32 weights to ~2^-17 relative; image interleaves parts per 512-element group."""
+    w = torch.from_numpy(np.random.RandomState(0).standard_normal((64, 32, 3, 3)).astype(np.float32))
+    part = E.pack_conv_part(w)
+    img = E.pack_conv_weight(w).view(torch.bfloat16).view(-1, 2, 512).float()
+    rec = (img[:, 0] + img[:, 1]).reshape(-1)
+    assert float(((rec - part).abs() / part.abs().clamp_min(1e-20)).max()) < 2.0 ** -15
+    idx, total = E.conv_pack_index(64, 32, 3)
+    assert torch.equal(part[torch.from_numpy(idx)], w.reshape(-1)) and total == part.numel()
 
 
 def test_integer_grids_bit_exact_vs_reference(golden):
