@@ -40,19 +40,25 @@ def effective_cpus():
 
 
 def cpu_baseline(sd, threads):
-    """Oracle (CPU restatement of the reference path, kind='port') on a bounded sample: one frame of a
-    quarter-area crop (7x3x90x160, x4 -> 360x640) of the workload clip."""
+    """Oracle (CPU restatement of the reference path, kind='port') on a bounded sample of the same
+    workload: whole 7x3x180x320 -> 720x1280 frames until ~12 s of CPU time are spent (>= 1 frame),
+    after one untimed quarter-area warm-up that pages the weights in."""
     from oracle import savsr_oracle as O
     from savsr_amd.utils import synth
     torch.set_num_threads(threads)
-    lq = synth.synth_clip(7, 3, LR_H, LR_W, seed=0)[..., :90, :160].contiguous()
+    lq = synth.synth_clip(7, 3, LR_H, LR_W, seed=0)
     with torch.no_grad():
-        t0 = time.perf_counter()
-        out = O.forward(sd, lq, SCALE)
-        dt = time.perf_counter() - t0
-    hr_px = out.shape[-1] * out.shape[-2]
+        O.forward(sd, lq[..., :90, :160].contiguous(), SCALE)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            out = O.forward(sd, lq, SCALE)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > 12.0 or n >= 8:
+                break
+    hr_px = n * out.shape[-1] * out.shape[-2]
     return {"value": round(hr_px / dt / 1e6, 5), "unit": "HR Mpixel/s", "cores": threads, "kind": "port",
-            "sample": f"1 frame, oracle/savsr_oracle.py on a 7x3x90x160 crop (x4 -> 360x640) of the workload clip, {dt:.2f} s"}, out, lq
+            "sample": f"{n} frame(s) of the workload clip (7x3x180x320, x4 -> 720x1280) through oracle/savsr_oracle.py, {dt:.2f} s"}, out, lq
 
 
 def main():
