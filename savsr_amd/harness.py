@@ -1,0 +1,94 @@
+"""Thin test-time harness around the hot path: what `VideoBaseModel.dist_validation` +
+`ASVSRModel.test` do for one dataset (lbasicsr/models/video_base_model.py:18-118,
+asvsr_model.py:31-61), on in-memory clips.
+
+    for idx in range(rank, n_frames, world):            # frame round-robin   (:50)
+        window  = 7 frames around idx, reflection pad    (data_util.py:63-112)
+        net.set_scale(scale); out = net(window)          (asvsr_model.py:54-60)
+        psnr_y, ssim_y  vs GT                            (:94-98)
+    one collective per dataset: gather of the [n_frames, 2] metric rows (:108-113)
+
+Frames are independent units (hidden state restarts per window), so there is no data-path
+collective; with RCCL (backend "nccl") the gather rides xGMI, with gloo it runs on CPU tensors.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+from .metrics import calculate_psnr, calculate_ssim, tensor2img
+
+
+def frame_indices(n_frames: int, rank: int, world: int) -> List[int]:
+    """Frames owned by `rank` (video_base_model.py:50)."""
+    return list(range(rank, n_frames, world))
+
+
+def window_indices(crt_idx: int, max_frame_num: int, num_frames: int = 7, padding: str = "reflection") -> List[int]:
+    """Index list of a `num_frames` window centred on `crt_idx` (generate_frame_indices,
+    data_util.py:63-112).  e.g. idx 0 of 41 frames -> [3, 2, 1, 0, 1, 2, 3]."""
+    if num_frames % 2 != 1:
+        raise AssertionError("num_frames should be an odd number.")
+    if padding not in ("replicate", "reflection", "reflection_circle", "circle"):
+        raise AssertionError(f"Wrong padding mode: {padding}.")
+    last = max_frame_num - 1
+    half = num_frames // 2
+    out = []
+    for i in range(crt_idx - half, crt_idx + half + 1):
+        if i < 0:
+            j = {"replicate": 0, "reflection": -i, "reflection_circle": crt_idx + half - i, "circle": num_frames + i}[padding]
+        elif i > last:
+            j = {"replicate": last, "reflection": 2 * last - i, "reflection_circle": (crt_idx - half) - (i - last),
+                 "circle": i - num_frames}[padding]
+        else:
+            j = i
+        out.append(j)
+    return out
+
+
+def gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int) -> torch.Tensor:
+    """All ranks' per-frame rows in frame order.  local: [len(frame_indices(n_total, rank, world)), k].
+    One padded all_gather (RCCL all_gather_into_tensor on GPU tensors; list all_gather on gloo)."""
+    if world == 1:
+        return local
+    import torch.distributed as dist
+    per = (n_total + world - 1) // world
+    k = local.shape[1]
+    padded = torch.zeros(per, k, dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    if local.is_cuda:
+        buf = torch.empty(world * per, k, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(buf, padded)
+        parts = buf.view(world, per, k)
+    else:
+        lst = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(lst, padded)
+        parts = torch.stack(lst, 0)
+    out = torch.empty(n_total, k, dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = frame_indices(n_total, r, world)
+        out[idx] = parts[r, : len(idx)]
+    return out
+
+
+def validate_folder(net: Callable, lq_frames: torch.Tensor, gt_frames: Sequence[torch.Tensor], scale: Tuple[float, float],
+                    rank: int = 0, world: int = 1, num_frame: int = 7, padding: str = "reflection",
+                    device: Optional[torch.device] = None) -> torch.Tensor:
+    """PSNR-Y / SSIM-Y of every frame of one folder.  lq_frames: [N, 3, h, w]; gt_frames[i]: [3, H, W].
+    Returns the gathered [N, 2] rows (identical on every rank)."""
+    n = lq_frames.shape[0]
+    mine = frame_indices(n, rank, world)
+    rows = torch.zeros(len(mine), 2, dtype=torch.float64)
+    net.set_scale(scale)
+    for k, idx in enumerate(mine):
+        win = lq_frames[window_indices(idx, n, num_frame, padding)].unsqueeze(0)
+        if device is not None:
+            win = win.to(device)
+        out = net(win)
+        sr, gt = tensor2img(out[0]), tensor2img(gt_frames[idx])
+        rows[k, 0] = calculate_psnr(sr, gt, 0, test_y_channel=True)
+        rows[k, 1] = calculate_ssim(sr, gt, 0, test_y_channel=True)
+    if device is not None and world > 1 and device.type == "cuda":
+        return gather_rows(rows.to(device), n, rank, world).cpu()
+    return gather_rows(rows, n, rank, world)
