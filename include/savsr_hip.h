@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 2
+#define SAVSR_ABI_VERSION 3
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -168,7 +168,7 @@ typedef struct savsr_satu_weights {      /* all device pointers; packed by the c
     const float* head_w;  const float* head_b;    /* [8][64], [8]: routing(4) | offset(2) | st_offset(2)  :252,256,257 */
     const void*  kconv_w; const float* kconv_b;   /* split-bf16 image [25][2][4 ks][part][64 lanes][8], fp32 [25][64]  :227 */
     const void*  proj_w;                          /* split-bf16 image of the LR projections (Wa | Wb | C-stack) */
-    const float* wbe_w;                           /* packed (Wb E_n): [2][16][64 lanes]        */
+    const void*  wbe_w;                           /* split-bf16 image of (Wb E_n): [2 t][2 ks][part][64 lanes][8] */
     const float* fusion_b;                        /* [64] :260 */
 } savsr_satu_weights;
 
@@ -183,12 +183,22 @@ int savsr_satu_phase_table(const savsr_satu_weights* wt, const float* uniq_ch, i
 int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const float* st,
                         int32_t pix, int32_t row_px, int h, int w, float* lrcat, void* stream);
 
+/* Optional LDS staging plan of the HR stage (a pure performance hint; results never depend on it):
+ * each workgroup owns tile_rows x (32 * tile_cols32) HR pixels and stages an lr_rows x lr_cols window
+ * of LRcat records whose origin is the tile's base sampling coordinate + (off_min_x, off_min_y).
+ * Waves whose taps leave the window gather from global memory instead.  NULL = no staging. */
+typedef struct savsr_satu_tiling {
+    int32_t tile_rows, tile_cols32, lr_rows, lr_cols;
+    float   off_min_x, off_min_y;
+} savsr_satu_tiling;
+
 /* gxn[W], gyn[H]: normalised base grid coordinates (savsr_arch.py:270-280) computed by the caller
  * in fp32; idx_h[H], idx_w[W]: index of each row/column's (coor_h, coor_w) value in the table.
  * out: [64][H][W] contiguous. */
 int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w,
                            const float* table, int n_uw, const int32_t* idx_h, const int32_t* idx_w,
-                           const float* gyn, const float* gxn, int H, int W, float* out, void* stream);
+                           const float* gyn, const float* gxn, int H, int W,
+                           const savsr_satu_tiling* tiling, float* out, void* stream);
 
 /* tail conv 3x3 64->3 + bias at HR plus the bilinear residual of the (unpadded) centre frame
  * (savsr_arch.py:738-739).  feat: [64][H][W]; center: [3][h][w]; out: [3][H][W]; all contiguous. */

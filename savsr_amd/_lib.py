@@ -15,7 +15,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 fptr = C.c_void_p   # raw device pointers travel as integers
 
@@ -60,6 +60,11 @@ class SatuWeights(C.Structure):
     ]
 
 
+class SatuTiling(C.Structure):
+    _fields_ = [("tile_rows", C.c_int32), ("tile_cols32", C.c_int32), ("lr_rows", C.c_int32), ("lr_cols", C.c_int32),
+                ("off_min_x", C.c_float), ("off_min_y", C.c_float)]
+
+
 # name -> (restype, argtypes); must list every symbol include/savsr_hip.h declares
 SIGNATURES = {
     "savsr_version": (C.c_char_p, []),
@@ -80,7 +85,7 @@ SIGNATURES = {
     "savsr_satu_lr_stage": (C.c_int, [C.POINTER(SatuWeights), fptr, fptr, C.c_int32, C.c_int32, C.c_int, C.c_int,
                                       fptr, C.c_void_p]),
     "savsr_satu_hr_upsample": (C.c_int, [C.POINTER(SatuWeights), fptr, C.c_int, C.c_int, fptr, C.c_int, fptr, fptr,
-                                         fptr, fptr, C.c_int, C.c_int, fptr, C.c_void_p]),
+                                         fptr, fptr, C.c_int, C.c_int, C.POINTER(SatuTiling), fptr, C.c_void_p]),
     "savsr_tail_residual": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
 }
 

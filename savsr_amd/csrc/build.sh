@@ -12,7 +12,7 @@ for f in conv_mfma.hip osconv.hip elementwise.hip satu.hip tail.hip; do
   fi
   OBJS+=("$o")
 done
-if [ ! -f api.o ] || [ api.cpp -nt api.o ] || [ common.hpp -nt api.o ]; then
+if [ ! -f api.o ] || [ api.cpp -nt api.o ] || [ common.hpp -nt api.o ] || [ ../../include/savsr_hip.h -nt api.o ]; then
   $HIPCC $FLAGS -x hip -c api.cpp -o api.o &
 fi
 wait

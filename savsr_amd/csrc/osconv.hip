@@ -49,12 +49,6 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(const SumParams p) {
     }
 }
 
-__device__ __forceinline__ float mean_from_partials(const float* partial, int nblk, int ctot, int c, float inv_n) {
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * ctot + c];
-    return s * inv_n;
-}
-
 __device__ __forceinline__ float wave_dot(const float* __restrict__ w, const float* v, int n, int lane) {
     float acc = 0.f;
     for (int c = lane; c < n; c += 64) acc += w[c] * v[c];
@@ -63,10 +57,25 @@ __device__ __forceinline__ float wave_dot(const float* __restrict__ w, const flo
 
 // scale routing layer 1 (savsr_arch.py:123-125,143-146): v1 = ReLU(L1 [1/sh, 1/sw, mean] + c1)
 __global__ __launch_bounds__(512) void osconv_l1_kernel(const savsr_osconv_attn_desc d) {
-    extern __shared__ float v0[];
+    extern __shared__ float v0[];           // [cin + 2] then scratch [8][cin]
+    float* scr = v0 + d.cin + 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { v0[0] = d.inv_sh; v0[1] = d.inv_sw; }
-    for (int i = tid; i < d.cin; i += 512) v0[2 + i] = mean_from_partials(d.partial, d.nblk, d.cin, i, d.inv_n);
+    // pooled mean from the block-ordered partial sums: 8 interleaved slices per channel, then a
+    // fixed-order 8-way add (deterministic)
+    for (int i = tid; i < d.cin * 8; i += 512) {
+        const int c = i % d.cin, part = i / d.cin;
+        float s = 0.f;
+        for (int b = part; b < d.nblk; b += 8) s += d.partial[(long long)b * d.cin + c];
+        scr[part * d.cin + c] = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < d.cin; c += 512) {
+        float s = 0.f;
+#pragma unroll
+        for (int part = 0; part < 8; ++part) s += scr[part * d.cin + c];
+        v0[2 + c] = s * d.inv_n;
+    }
     __syncthreads();
     const int r = blockIdx.x * 8 + wave;
     if (r >= 2 * d.cin) return;
@@ -168,13 +177,26 @@ __global__ __launch_bounds__(512) void osconv_aggregate_kernel(const savsr_oscon
     img[group * 128 + 64 + ln] = lo;
 }
 
-// RCAN ChannelAttention MLP (savsr_arch.py:514-520); one workgroup.
-__global__ __launch_bounds__(64) void se_gate_kernel(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
+// RCAN ChannelAttention MLP (savsr_arch.py:514-520); one workgroup of 256 threads.
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
                                                      const float* w2, const float* b2, int c, int cmid, float* gate) {
+    __shared__ float scr[8 * 128];
     __shared__ float m[128];
     __shared__ float z[64];
     const int t = threadIdx.x;
-    for (int i = t; i < c; i += 64) m[i] = mean_from_partials(partial, nblk, c, i, inv_n);
+    for (int i = t; i < c * 8; i += 256) {
+        const int ch = i % c, part = i / c;
+        float s = 0.f;
+        for (int b = part; b < nblk; b += 8) s += partial[(long long)b * c + ch];
+        scr[part * c + ch] = s;
+    }
+    __syncthreads();
+    for (int ch = t; ch < c; ch += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int part = 0; part < 8; ++part) s += scr[part * c + ch];
+        m[ch] = s * inv_n;
+    }
     __syncthreads();
     if (t < cmid) {
         float acc = b1[t];
@@ -182,7 +204,7 @@ __global__ __launch_bounds__(64) void se_gate_kernel(const float* partial, int n
         z[t] = fmaxf(acc, 0.f);
     }
     __syncthreads();
-    for (int o = t; o < c; o += 64) {
+    for (int o = t; o < c; o += 256) {
         float acc = b2[o];
         for (int k = 0; k < cmid; ++k) acc += w2[o * cmid + k] * z[k];
         gate[o] = sigmoidf_(acc);
@@ -235,7 +257,7 @@ extern "C" int savsr_osconv_weights(const savsr_osconv_attn_desc* d, void* strea
         return SAVSR_E_ALIGN;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(osconv_l1_kernel, dim3((2 * d->cin + 7) / 8), dim3(512), sizeof(float) * (d->cin + 2), st, *d);
+    hipLaunchKernelGGL(osconv_l1_kernel, dim3((2 * d->cin + 7) / 8), dim3(512), sizeof(float) * (9 * d->cin + 2), st, *d);
     int rc = check_launch("osconv_l1_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(osconv_l2_kernel, dim3((d->cin + 7) / 8), dim3(512), sizeof(float) * 2 * d->cin, st, *d);
@@ -250,7 +272,7 @@ extern "C" int savsr_se_gate(const float* partial, int nblk, float inv_n, const 
                              const float* b2, int c, int cmid, float* gate, void* stream) {
     if (!partial || !w1 || !b1 || !w2 || !b2 || !gate) return fail_arg("se_gate: null pointer");
     if (c < 1 || c > 128 || cmid < 1 || cmid > 64 || nblk < 1) return fail_arg("se_gate: shape");
-    hipLaunchKernelGGL(se_gate_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), partial, nblk, inv_n, w1, b1, w2, b2, c, cmid, gate);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partial, nblk, inv_n, w1, b1, w2, b2, c, cmid, gate);
     return check_launch("se_gate_kernel");
 }
 

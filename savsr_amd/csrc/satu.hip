@@ -12,18 +12,16 @@
 //     369 MB unfolded features ever exists.
 //
 // Record layout of the LR-side tensor LRcat[h][w][160] (one 640-B record per LR pixel):
-//   half hh in {0,1} (= MFMA lane half) owns floats [80*hh, 80*hh+80):
-//     [ 0,32)  (Wa sta)[co]   at q = 16 t + r  <->  co = 32 t + acc_row(r, hh)
-//     [32,64)  (Wb x)[co]     same q
-//     [64,80)  (C_m x)[j]     at r = 4 m + jj  <->  j = 2 jj + hh
-//   i.e. exactly the 32x32 MFMA accumulator layout of the lane that produced it (LR stage) and
-//   of the lane that consumes it (HR stage): no cross-lane movement on either side.
+//   [64 hh, 64 hh + 32)       (Wa sta)[co] at q = 16 t + r  <->  co = 32 t + acc_row(r, hh)   (hh = MFMA lane half)
+//   [64 hh + 32, 64 hh + 64)  (Wb x)[co]   same q
+//   [128, 160)                (C_m x)[j]   at 8 m + j  (natural order, shared by both halves)
+//   i.e. the 32x32 MFMA accumulator layout of the lane that produced a value (LR stage) and of
+//   the lane that consumes it (HR stage): no cross-lane movement on either side.
 #include "common.hpp"
 
 namespace savsr {
 
 constexpr int REC = SAVSR_SATU_LRCAT;      // 160
-constexpr int HREC = REC / 2;              // 80
 
 // ------------------------------------------------------------------------------------------
 // Phase table: one wave per distinct (coor_h, coor_w) pair; lane j owns hidden unit j.
@@ -213,7 +211,8 @@ __global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
         accC = mma3(pc[(ks * 2 + 0) * 64], pc[(ks * 2 + 1) * 64], xh, xl, accC);
     }
     if (!valid) return;
-    f32x4* rec = reinterpret_cast<f32x4*>(p.lrcat + ((long long)gy * p.w + gx) * REC + half * HREC);
+    float* recf = p.lrcat + ((long long)gy * p.w + gx) * REC;
+    f32x4* rec = reinterpret_cast<f32x4*>(recf + half * 64);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 c = {accC[4 * g], accC[4 * g + 1], accC[4 * g + 2], accC[4 * g + 3]};
-        rec[16 + g] = c;
+        *reinterpret_cast<f32x4*>(recf + 128 + 8 * g + 4 * half) = c;     // rows 8g + 4 half + {0..3} = C-stack channels
     }
 }
 
@@ -234,6 +233,13 @@ __global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
 // HR stage.  One wave = 32 consecutive HR pixels of one output row x all 64 channels; two lanes
 // (half 0 / half 1) per pixel, each owning 32 of the 64 output channels in MFMA accumulator
 // order.  grid_sample (zeros padding, align_corners=True) semantics of savsr_arch.py:262-295.
+//
+// A workgroup (4 waves) owns an HR tile of TY rows x 32*TXW columns and first stages the LRcat
+// records its taps can touch (tile footprint + the offset range of the phase table) into LDS
+// with a 656-B record pitch (conflict-free b128 reads).  A wave whose 8 taps all fall inside the
+// staged window gathers from LDS (256 B/clk/CU); any other wave -- and every wave when the
+// caller passes lrh == 0 -- gathers the same records from global memory, so correctness never
+// depends on the window the caller chose.
 // ------------------------------------------------------------------------------------------
 struct HrParams {
     savsr_satu_weights wt;
@@ -247,11 +253,15 @@ struct HrParams {
     const float* gxn;
     int H, W;
     float* out;
+    int ty, txw, lrh, lrw;       // HR tile rows, 32-px column tiles per workgroup, staged LR window
+    float omin_x, omin_y;        // lower bound of the sampling offsets (window origin)
 };
 
+constexpr int HR_LDS_REC = 164;  // floats per staged record (160 used)
+
 struct Taps {
-    int o[4];        // record offsets (in pixels) of the 4 taps: nw, ne, sw, se
-    float wgt[4];    // bilinear weights, 0 for taps outside the image
+    int ty[4], tx[4];  // LR coordinates of the 4 taps (nw, ne, sw, se), clamped into the image
+    float wgt[4];      // bilinear weights, 0 for taps outside the image
 };
 
 __device__ __forceinline__ Taps make_taps(float gxn, float gyn, float offx, float offy, int h, int w) {
@@ -268,108 +278,142 @@ __device__ __forceinline__ Taps make_taps(float gxn, float gyn, float offx, floa
     const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
     const bool vx0 = x0 >= 0 && x0 < w, vx1 = x1 >= 0 && x1 < w;
     const bool vy0 = y0 >= 0 && y0 < h, vy1 = y1 >= 0 && y1 < h;
-    const int cx0 = vx0 ? x0 : 0, cx1 = vx1 ? x1 : 0, cy0 = vy0 ? y0 : 0, cy1 = vy1 ? y1 : 0;
+    // an out-of-image tap contributes 0 (zeros padding); park it on its in-image neighbour so
+    // that it never widens the window a wave needs
+    const int cx0 = vx0 ? x0 : (vx1 ? x1 : (x0 < 0 ? 0 : w - 1)), cx1 = vx1 ? x1 : cx0;
+    const int cy0 = vy0 ? y0 : (vy1 ? y1 : (y0 < 0 ? 0 : h - 1)), cy1 = vy1 ? y1 : cy0;
     Taps t;
-    t.o[0] = cy0 * w + cx0; t.wgt[0] = (vy0 && vx0) ? sy * ex : 0.f;
-    t.o[1] = cy0 * w + cx1; t.wgt[1] = (vy0 && vx1) ? sy * lx : 0.f;
-    t.o[2] = cy1 * w + cx0; t.wgt[2] = (vy1 && vx0) ? ly * ex : 0.f;
-    t.o[3] = cy1 * w + cx1; t.wgt[3] = (vy1 && vx1) ? ly * lx : 0.f;
+    t.ty[0] = cy0; t.tx[0] = cx0; t.wgt[0] = (vy0 && vx0) ? sy * ex : 0.f;
+    t.ty[1] = cy0; t.tx[1] = cx1; t.wgt[1] = (vy0 && vx1) ? sy * lx : 0.f;
+    t.ty[2] = cy1; t.tx[2] = cx0; t.wgt[2] = (vy1 && vx0) ? ly * ex : 0.f;
+    t.ty[3] = cy1; t.tx[3] = cx1; t.wgt[3] = (vy1 && vx1) ? ly * lx : 0.f;
     return t;
 }
 
-__global__ __launch_bounds__(256) void satu_hr_kernel(const HrParams p) {
-    const int lane = threadIdx.x & 63, half = lane >> 5, px = lane & 31;
-    const long long wave_g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long nwaves = (long long)gridDim.x * 4;
-    const int ntx = (p.W + 31) / 32;
-    const long long ntiles = (long long)p.H * ntx;
-
-    float wbe[2][16];                        // A operands of the expert MFMA, resident
+template <bool FROM_LDS>
+__device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int ly0, int lx0, const Taps& to, const Taps& ts,
+                                        const f32x4 rr, int half, int lane, bool valid, float* o) {
+    auto rec_of = [&](int ty, int tx) -> const f32x4* {
+        if (FROM_LDS) return reinterpret_cast<const f32x4*>(lds + ((ty - ly0) * p.lrw + (tx - lx0)) * HR_LDS_REC);
+        return reinterpret_cast<const f32x4*>(p.lrcat + ((long long)ty * p.w + tx) * REC);
+    };
+    const f32x4* ro[4] = {rec_of(to.ty[0], to.tx[0]), rec_of(to.ty[1], to.tx[1]), rec_of(to.ty[2], to.tx[2]), rec_of(to.ty[3], to.tx[3])};
+    const f32x4* rs[4] = {rec_of(ts.ty[0], ts.tx[0]), rec_of(ts.ty[1], ts.tx[1]), rec_of(ts.ty[2], ts.tx[2]), rec_of(ts.ty[3], ts.tx[3])};
+    // ---- the 32 compressed channels G(C x, off); t_j = sum_m r_m (C_m f0)_j -------------------------
+    float tj[8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int j = 0; j < 8; ++j) tj[j] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) wbe[t][s] = p.wt.wbe_w[(t * 16 + s) * 64 + lane];
+    for (int k = 0; k < 4; ++k) {
+        const float wk = to.wgt[k];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 v0 = ro[k][32 + 2 * m], v1 = ro[k][32 + 2 * m + 1];
+            const float wr = wk * rr[m];
+            tj[0] += wr * v0[0]; tj[1] += wr * v0[1]; tj[2] += wr * v0[2]; tj[3] += wr * v0[3];
+            tj[4] += wr * v1[0]; tj[5] += wr * v1[1]; tj[6] += wr * v1[2]; tj[7] += wr * v1[3];
+        }
+    }
+    // ---- B operand of the expert MFMA: v[(n, j)] = r_n t_j, k = 16 ks + 8 half + j <-> n = 2 ks + half ----
+    bf16x8 bh[2], bl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const float rn = half ? rr[2 * ks + 1] : rr[2 * ks];
+        const f32x4 v0 = {rn * tj[0], rn * tj[1], rn * tj[2], rn * tj[3]};
+        const f32x4 v1 = {rn * tj[4], rn * tj[5], rn * tj[6], rn * tj[7]};
+        split8v(v0, v1, bh[ks], bl[ks]);
+    }
+    const bf16x8* wimg = reinterpret_cast<const bf16x8*>(p.wt.wbe_w) + lane;       // [t][ks][part][lane]
     const f32x4* fb4 = reinterpret_cast<const f32x4*>(p.wt.fusion_b + half * 32);   // packed [half][q]
+    const long long HW = (long long)p.H * p.W;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = fb4[t * 4 + g];
+            acc[4 * g] = b[0]; acc[4 * g + 1] = b[1]; acc[4 * g + 2] = b[2]; acc[4 * g + 3] = b[3];
+        }
+        // G(Wb x, off): channels q = 16 t .. 16 t + 15 of this half
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float wk = to.wgt[k];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = ro[k][16 * half + 8 + 4 * t + g];
+                acc[4 * g] += wk * v[0]; acc[4 * g + 1] += wk * v[1]; acc[4 * g + 2] += wk * v[2]; acc[4 * g + 3] += wk * v[3];
+            }
+        }
+        // + (Wb E) v on the bf16 matrix cores (split operands)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            acc = mma3(wimg[((t * 2 + ks) * 2 + 0) * 64], wimg[((t * 2 + ks) * 2 + 1) * 64], bh[ks], bl[ks], acc);
+        // + G(Wa sta, soff)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float wk = ts.wgt[k];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = rs[k][16 * half + 4 * t + g];
+                acc[4 * g] += wk * v[0]; acc[4 * g + 1] += wk * v[1]; acc[4 * g + 2] += wk * v[2]; acc[4 * g + 3] += wk * v[3];
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(long long)(32 * t + acc_row(r, half)) * HW] = acc[r];
+        }
+    }
+}
 
-    for (long long T = wave_g; T < ntiles; T += nwaves) {
-        const int Y = (int)(T / ntx);
-        const int X = (int)(T - (long long)Y * ntx) * 32 + px;
+__global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
+    const int X0 = blockIdx.x * 32 * p.txw, Y0 = blockIdx.y * p.ty;
+
+    // ---- stage the LRcat window of this tile ------------------------------------------------------
+    int ly0 = 0, lx0 = 0;
+    if (p.lrh > 0) {
+        const float by = ((p.gyn[Y0] + 1.f) / 2.f) * (float)(p.h - 1) + p.omin_y - 0.01f;
+        const float bx = ((p.gxn[X0 < p.W ? X0 : p.W - 1] + 1.f) / 2.f) * (float)(p.w - 1) + p.omin_x - 0.01f;
+        ly0 = (int)floorf(fminf(fmaxf(by, 0.f), (float)(p.h - 1)));
+        lx0 = (int)floorf(fminf(fmaxf(bx, 0.f), (float)(p.w - 1)));
+        const int nunit = p.lrh * p.lrw * (REC / 4);
+        for (int e = tid; e < nunit; e += 256) {
+            const int r = e / (REC / 4), u = e - r * (REC / 4);
+            const int ry = r / p.lrw, rx = r - ry * p.lrw;
+            const int gy = ly0 + ry, gx = lx0 + rx;
+            if (gy < p.h && gx < p.w)
+                *reinterpret_cast<f32x4*>(lds + r * HR_LDS_REC + 4 * u) =
+                    *reinterpret_cast<const f32x4*>(p.lrcat + ((long long)gy * p.w + gx) * REC + 4 * u);
+        }
+    }
+    __syncthreads();
+
+    const int ntile = p.ty * p.txw;
+    for (int T = wave; T < ntile; T += 4) {
+        const int trow = T / p.txw;
+        const int Y = Y0 + trow;
+        const int Xb = X0 + (T - trow * p.txw) * 32;
+        if (Y >= p.H || Xb >= p.W) continue;                      // wave-uniform
+        const int X = Xb + px;
         const bool valid = X < p.W;
         const int Xc = valid ? X : p.W - 1;
         const float* te = p.table + ((long long)p.idx_h[Y] * p.n_uw + p.idx_w[Xc]) * SAVSR_SATU_TABLE;
         const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
         const f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
         const float gxn = p.gxn[Xc], gyn = p.gyn[Y];
+        const Taps to = make_taps(gxn, gyn, oo[0], oo[1], p.h, p.w);
+        const Taps ts = make_taps(gxn, gyn, oo[2], oo[3], p.h, p.w);
 
-        f32x16 acc[2];
+        bool inside = p.lrh > 0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = fb4[t * 4 + g];
-                acc[t][4 * g] = b[0]; acc[t][4 * g + 1] = b[1]; acc[t][4 * g + 2] = b[2]; acc[t][4 * g + 3] = b[3];
-            }
-
-        // ---- G(Wb x, off) and the 32 compressed channels G(C x, off) -------------------------
-        float gc[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) gc[i] = 0.f;
-        {
-            const Taps tp = make_taps(gxn, gyn, oo[0], oo[1], p.h, p.w);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x4* rec = reinterpret_cast<const f32x4*>(p.lrcat + (long long)tp.o[k] * REC + half * HREC);
-                const float wk = tp.wgt[k];
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = rec[8 + t * 4 + g];
-                        acc[t][4 * g] += wk * v[0]; acc[t][4 * g + 1] += wk * v[1];
-                        acc[t][4 * g + 2] += wk * v[2]; acc[t][4 * g + 3] += wk * v[3];
-                    }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = rec[16 + g];
-                    gc[4 * g] += wk * v[0]; gc[4 * g + 1] += wk * v[1]; gc[4 * g + 2] += wk * v[2]; gc[4 * g + 3] += wk * v[3];
-                }
-            }
+        for (int k = 0; k < 4; ++k) {
+            inside = inside && (unsigned)(to.ty[k] - ly0) < (unsigned)p.lrh && (unsigned)(to.tx[k] - lx0) < (unsigned)p.lrw;
+            inside = inside && (unsigned)(ts.ty[k] - ly0) < (unsigned)p.lrh && (unsigned)(ts.tx[k] - lx0) < (unsigned)p.lrw;
         }
-        // ---- expert mixing: t_j = sum_m r_m (C_m f0)_j ; v[(n,j)] = r_n t_j ; acc += (Wb E) v ---
-        float tj[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) tj[jj] = rr[0] * gc[jj] + rr[1] * gc[4 + jj] + rr[2] * gc[8 + jj] + rr[3] * gc[12 + jj];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float v = rr[s >> 2] * tj[s & 3];       // k = 2 s + half  <->  n = s >> 2, j = 2 (s & 3) + half
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbe[0][s], v, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbe[1][s], v, acc[1], 0, 0, 0);
-        }
-        // ---- G(Wa sta, soff) -----------------------------------------------------------------
-        {
-            const Taps tp = make_taps(gxn, gyn, oo[2], oo[3], p.h, p.w);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x4* rec = reinterpret_cast<const f32x4*>(p.lrcat + (long long)tp.o[k] * REC + half * HREC);
-                const float wk = tp.wgt[k];
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = rec[t * 4 + g];
-                        acc[t][4 * g] += wk * v[0]; acc[t][4 * g + 1] += wk * v[1];
-                        acc[t][4 * g + 2] += wk * v[2]; acc[t][4 * g + 3] += wk * v[3];
-                    }
-            }
-        }
-        if (valid) {
-            float* o = p.out + (long long)Y * p.W + X;
-            const long long HW = (long long)p.H * p.W;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[(long long)(32 * t + acc_row(r, half)) * HW] = acc[t][r];
-        }
+        float* o = p.out + (long long)Y * p.W + X;
+        if (__all(inside)) hr_tile<true>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o);
+        else hr_tile<false>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o);
     }
 }
 
@@ -411,20 +455,34 @@ extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x,
 
 extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uw,
                                       const int32_t* idx_h, const int32_t* idx_w, const float* gyn, const float* gxn, int H, int W,
-                                      float* out, void* stream) {
+                                      const savsr_satu_tiling* tiling, float* out, void* stream) {
     if (!satu_weights_ok(wt) || !lrcat || !table || !idx_h || !idx_w || !gyn || !gxn || !out) return fail_arg("satu_hr_upsample: null pointer");
     if (h < 2 || w < 2 || H < 1 || W < 1 || n_uw < 1) return fail_arg("satu_hr_upsample: shape (h, w >= 2 required)");
-    if ((reinterpret_cast<uintptr_t>(lrcat) & 15) || (reinterpret_cast<uintptr_t>(table) & 15) ||
-        (reinterpret_cast<uintptr_t>(wt->fusion_b) & 15)) {
-        set_error("satu_hr_upsample: lrcat / table / fusion_b must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(lrcat) | reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(wt->fusion_b) |
+         reinterpret_cast<uintptr_t>(wt->wbe_w)) & 15) {
+        set_error("satu_hr_upsample: lrcat / table / fusion_b / wbe_w must be 16-byte aligned");
         return SAVSR_E_ALIGN;
     }
     HrParams p;
     p.wt = *wt; p.lrcat = lrcat; p.h = h; p.w = w; p.table = table; p.n_uw = n_uw; p.idx_h = idx_h; p.idx_w = idx_w;
     p.gyn = gyn; p.gxn = gxn; p.H = H; p.W = W; p.out = out;
-    const long long ntiles = (long long)H * ((W + 31) / 32);
-    long long blocks = (ntiles + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(satu_hr_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    p.ty = 8; p.txw = 1; p.lrh = 0; p.lrw = 0; p.omin_x = 0.f; p.omin_y = 0.f;      // default: no staging, gathers from global
+    if (tiling) {
+        if (tiling->tile_rows < 1 || tiling->tile_cols32 < 1 || tiling->lr_rows < 0 || tiling->lr_cols < 0)
+            return fail_arg("satu_hr_upsample: tiling");
+        p.ty = tiling->tile_rows; p.txw = tiling->tile_cols32; p.lrh = tiling->lr_rows; p.lrw = tiling->lr_cols;
+        p.omin_x = tiling->off_min_x; p.omin_y = tiling->off_min_y;
+        if (p.lrh == 0 || p.lrw == 0) { p.lrh = 0; p.lrw = 0; }
+    }
+    const size_t lds = (size_t)p.lrh * p.lrw * HR_LDS_REC * sizeof(float);
+    if (lds > 160 * 1024) return fail_arg("satu_hr_upsample: staged window exceeds 160 KiB of LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_hr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("satu_hr_upsample: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    dim3 grid((W + 32 * p.txw - 1) / (32 * p.txw), (H + p.ty - 1) / p.ty);
+    hipLaunchKernelGGL(satu_hr_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_hr_kernel");
 }

@@ -1,13 +1,19 @@
 // HR tail: 3x3 conv 64 -> 3 (+bias) on the SATU output, plus the bilinear residual of the
 // unpadded centre LR frame (savsr_arch.py:738-739).  N = 3 output channels is far too narrow for
 // MFMA (a 32-wide tile would waste >90 %), so this is a VALU kernel over an LDS-staged tile;
-// it is bound by the 236 MB read of the feature map.
+// it is bound by the 236 MB read of the feature map (config 2).
+//
+// Workgroup = 256 threads, tile = 16 rows x 32 cols; each thread owns two vertically adjacent
+// pixels, so one channel costs 12 LDS reads for 54 FMAs.  The 1 728 weights are wave-uniform and
+// come through the scalar cache (s_load), not LDS.  Interior tile columns are staged with 16-B
+// loads when the row pitch allows it.
 #include "common.hpp"
 
 namespace savsr {
 
-constexpr int TL_TH = 8, TL_TW = 32, TL_CH = 16;
-constexpr int TL_R = TL_TH + 2, TL_C = TL_TW + 2;
+constexpr int TL_TH = 16, TL_TW = 32, TL_CH = 16;
+constexpr int TL_R = TL_TH + 2;            // staged rows
+constexpr int TL_S = 40;                   // staged row pitch: [3] left halo, [4..35] interior, [36] right halo
 
 __device__ __forceinline__ void bil_src(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
     float s = scale * ((float)dst + 0.5f) - 0.5f;          // area_pixel_compute_source_index
@@ -20,53 +26,87 @@ __device__ __forceinline__ void bil_src(int dst, float scale, int in_size, int& 
 
 __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ feat, const float* __restrict__ wgt, const float* __restrict__ bias,
                                                    const float* __restrict__ center, int h, int w, int H, int W, float* __restrict__ out) {
-    __shared__ float tile[TL_CH * TL_R * TL_C];
-    __shared__ float wl[3 * 64 * 9];
+    __shared__ __attribute__((aligned(16))) float tile[TL_CH * TL_R * TL_S];
     const int tid = threadIdx.x;
     const int tx = tid & 31, ty = tid >> 5;
     const int X0 = blockIdx.x * TL_TW, Y0 = blockIdx.y * TL_TH;
-    for (int i = tid; i < 3 * 64 * 9; i += 256) wl[i] = wgt[i];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     const long long HW = (long long)H * W;
+    const bool vec = (W & 3) == 0 && X0 + TL_TW <= W;     // interior columns 16-B aligned and inside the image
+    float a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+
     for (int c0 = 0; c0 < 64; c0 += TL_CH) {
         __syncthreads();
-        for (int e = tid; e < TL_CH * TL_R * TL_C; e += 256) {
-            const int ch = e / (TL_R * TL_C);
-            const int rem = e - ch * (TL_R * TL_C);
-            const int r = rem / TL_C, c = rem - r * TL_C;
-            const int gy = Y0 - 1 + r, gx = X0 - 1 + c;
-            float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = feat[(long long)(c0 + ch) * HW + (long long)gy * W + gx];
-            tile[e] = v;
+        if (vec) {
+            // per (channel, row): 8 float4 interior + 2 halo scalars = 10 items
+            for (int e = tid; e < TL_CH * TL_R * 10; e += 256) {
+                const int cr = e / 10, it = e - cr * 10;
+                const int ch = cr / TL_R, r = cr - ch * TL_R;
+                const int gy = Y0 - 1 + r;
+                const bool rowok = gy >= 0 && gy < H;
+                const float* src = feat + (long long)(c0 + ch) * HW + (long long)gy * W + X0;
+                float* dst = tile + (ch * TL_R + r) * TL_S;
+                if (it < 8) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (rowok) v = *reinterpret_cast<const f32x4*>(src + 4 * it);
+                    *reinterpret_cast<f32x4*>(dst + 4 + 4 * it) = v;
+                } else if (it == 8) {
+                    dst[3] = (rowok && X0 > 0) ? src[-1] : 0.f;
+                } else {
+                    dst[36] = (rowok && X0 + TL_TW < W) ? src[TL_TW] : 0.f;
+                }
+            }
+        } else {
+            for (int e = tid; e < TL_CH * TL_R * 34; e += 256) {
+                const int cr = e / 34, c = e - cr * 34;
+                const int ch = cr / TL_R, r = cr - ch * TL_R;
+                const int gy = Y0 - 1 + r, gx = X0 - 1 + c;
+                float v = 0.f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = feat[(long long)(c0 + ch) * HW + (long long)gy * W + gx];
+                tile[(ch * TL_R + r) * TL_S + 3 + c] = v;
+            }
         }
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 2
         for (int ch = 0; ch < TL_CH; ++ch) {
-            const float* tp = tile + ch * (TL_R * TL_C) + ty * TL_C + tx;
-            const float* w0 = wl + (0 * 64 + c0 + ch) * 9;
-            const float* w1 = wl + (1 * 64 + c0 + ch) * 9;
-            const float* w2 = wl + (2 * 64 + c0 + ch) * 9;
+            const float* tp = tile + (ch * TL_R + 2 * ty) * TL_S + 3 + tx;
+            float v[4][3];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const float v = tp[(k / 3) * TL_C + (k % 3)];
-                a0 += w0[k] * v; a1 += w1[k] * v; a2 += w2[k] * v;
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[r][c] = tp[r * TL_S + c];
+            const float* wc = wgt + (c0 + ch) * 9;           // wave-uniform -> scalar loads
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float* wo = wc + o * 64 * 9;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float wk = wo[k];
+                    a[0][o] += wk * v[k / 3][k % 3];
+                    a[1][o] += wk * v[k / 3 + 1][k % 3];
+                }
             }
         }
     }
-    const int X = X0 + tx, Y = Y0 + ty;
-    if (X >= W || Y >= H) return;
+    const int X = X0 + tx;
+    if (X >= W) return;
     // F.interpolate(x_center, size=(H, W), mode='bilinear', align_corners=False), :739
-    int y0, y1, x0, x1;
-    float ly, lx;
-    bil_src(Y, (float)h / (float)H, h, y0, y1, ly);
+    int x0, x1;
+    float lx;
     bil_src(X, (float)w / (float)W, w, x0, x1, lx);
-    float acc[3] = {a0 + bias[0], a1 + bias[1], a2 + bias[2]};
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        const float* c = center + (long long)o * h * w;
-        const float top = (1.f - lx) * c[y0 * w + x0] + lx * c[y0 * w + x1];
-        const float bot = (1.f - lx) * c[y1 * w + x0] + lx * c[y1 * w + x1];
-        out[(long long)o * HW + (long long)Y * W + X] = acc[o] + ((1.f - ly) * top + ly * bot);
+    for (int q = 0; q < 2; ++q) {
+        const int Y = Y0 + 2 * ty + q;
+        if (Y >= H) continue;
+        int y0, y1;
+        float ly;
+        bil_src(Y, (float)h / (float)H, h, y0, y1, ly);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float* c = center + (long long)o * h * w;
+            const float top = (1.f - lx) * c[y0 * w + x0] + lx * c[y0 * w + x1];
+            const float bot = (1.f - lx) * c[y1 * w + x0] + lx * c[y1 * w + x1];
+            out[(long long)o * HW + (long long)Y * W + X] = (a[q][o] + bias[o]) + ((1.f - ly) * top + ly * bot);
+        }
     }
 }
 
@@ -78,6 +118,7 @@ extern "C" int savsr_tail_residual(const float* feat, const float* w, const floa
                                    float* out, void* stream) {
     if (!feat || !w || !b || !center || !out) return fail_arg("tail_residual: null pointer");
     if (h < 1 || wd < 1 || H < 1 || W < 1) return fail_arg("tail_residual: shape");
+    if (reinterpret_cast<uintptr_t>(feat) & 15) { set_error("tail_residual: feat must be 16-byte aligned"); return SAVSR_E_ALIGN; }
     dim3 grid((W + TL_TW - 1) / TL_TW, (H + TL_TH - 1) / TL_TH);
     hipLaunchKernelGGL(tail_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), feat, w, b, center, h, wd, H, W, out);
     return check_launch("tail_kernel");

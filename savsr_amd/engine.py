@@ -17,10 +17,10 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvDesc, OSConvAttnDesc, SatuWeights
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvDesc, OSConvAttnDesc, SatuTiling, SatuWeights
 
 BN_EPS = 1e-5
-MAX_SUM_BLOCKS = 64      # workgroups of one savsr_channel_sums launch
+MAX_SUM_BLOCKS = 256     # workgroups of one savsr_channel_sums launch
 
 
 # ----------------------------------------------------------------------------- host helpers (integer / grid logic)
@@ -238,19 +238,15 @@ class HipEngine:
                 pa[t, kidx] = wa[(32 * t + li)[:, None], ch]
             for ksi in range(4):
                 pb[t, ksi] = wb[(32 * t + li)[:, None], 16 * ksi + 8 * lh[:, None] + jj[None, :]]
-        cstack = comp.reshape(32, c)                                                  # row m*8 + j
-        r_of_i = (li & 3) + 4 * (li >> 3)
-        hh_of_i = (li >> 2) & 1
-        ch_of_i = 8 * (r_of_i >> 2) + 2 * (r_of_i & 3) + hh_of_i                     # record slot r = 4m+jj <-> j = 2jj+hh
+        cstack = comp.reshape(32, c)                                                  # row 8 m + j (natural order in the record)
         for ksi in range(4):
-            pc[ksi] = cstack[ch_of_i[:, None], 16 * ksi + 8 * lh[:, None] + jj[None, :]]
+            pc[ksi] = cstack[li[:, None], 16 * ksi + 8 * lh[:, None] + jj[None, :]]
         proj = np.concatenate([pa.reshape(-1), pb.reshape(-1), pc.reshape(-1)])
         wbe = np.einsum("oc,ncj->noj", wb.astype(np.float64), expd.astype(np.float64)).astype(np.float32)   # (Wb E_n)[co][j]
-        wbe_p = np.zeros((2, 16, 64), dtype=np.float32)
+        wbe_p = np.zeros((2, 2, 64, 8), dtype=np.float32)                            # [t][ks][lane][j], k = 16 ks + 8 kh + j = 8 n + j
         for t in range(2):
-            for si in range(16):
-                k = 2 * si + lh
-                wbe_p[t, si, :] = wbe[k // 8, 32 * t + li, k % 8]
+            for ksi in range(2):
+                wbe_p[t, ksi] = wbe[(2 * ksi + lh)[:, None], (32 * t + li)[:, None], jj[None, :]]
         fb = sd[p + "fusion.bias"].to("cpu", f32).numpy()
         fb_p = np.zeros((2, 32), dtype=np.float32)
         for hh in range(2):
@@ -265,7 +261,7 @@ class HipEngine:
             body0_w=self._dev(sd[p + "body.0.weight"].reshape(64, 4)), body0_b=self._dev(sd[p + "body.0.bias"]),
             body2_w=self._dev(sd[p + "body.2.weight"].reshape(64, 64).t()), body2_b=self._dev(sd[p + "body.2.bias"]),
             head_w=self._dev(head_w.reshape(8, 64)), head_b=self._dev(head_b),
-            kconv_w=img(kconv), kconv_b=t_(kconv_b), proj_w=img(proj), wbe_w=t_(wbe_p), fusion_b=t_(fb_p))
+            kconv_w=img(kconv), kconv_b=t_(kconv_b), proj_w=img(proj), wbe_w=img(wbe_p), fusion_b=t_(fb_p))
         sw = SatuWeights()
         for k, v in self.satu_t.items():
             setattr(sw, k, v.data_ptr())
@@ -366,7 +362,7 @@ class HipEngine:
 
     def channel_sums(self, srcs: List[Src], npx: int, partial: torch.Tensor) -> int:
         n = len(srcs)
-        nblk = max(1, min(MAX_SUM_BLOCKS, npx // 512))
+        nblk = max(1, min(MAX_SUM_BLOCKS, npx // 128))
         ptrs = (_lib.fptr * n)(*[s.ptr for s in srcs])
         pix = (C.c_int32 * n)(*[s.pix for s in srcs])
         _lib.check(self.lib.savsr_channel_sums(ptrs, pix, n, srcs[0].ch, npx, nblk, partial.data_ptr(), self._stream()),
@@ -461,8 +457,47 @@ class HipEngine:
             ent = dict(H=H, W=W, n_uh=len(uh), n_uw=len(uw), uh=up(uh, np.float32), uw=up(uw, np.float32),
                        ih=up(ih.reshape(-1), np.int32), iw=up(iw.reshape(-1), np.int32), gyn=up(gyn, np.float32), gxn=up(gxn, np.float32),
                        table=torch.empty(len(uh) * len(uw) * _lib.SATU_TABLE, device=self.dev))
+            self._plan_hr_tiling(ent, h, w, scale)
             self._satu_axes[key] = ent
         return ent
+
+    def _plan_hr_tiling(self, ent: dict, h: int, w: int, scale):
+        """One-time (per size/scale) choice of the HR stage's LDS window: evaluate the phase table,
+        read the range of the sampling offsets back and pick the largest HR tile whose LRcat window
+        (tile footprint + offset range + bilinear tap) fits two workgroups per CU.  Purely a
+        performance plan: waves whose taps leave the window gather from global memory."""
+        sw = C.byref(self.satu_w)
+        _lib.check(self.lib.savsr_satu_phase_table(sw, ent["uh"].data_ptr(), ent["n_uh"], ent["uw"].data_ptr(), ent["n_uw"],
+                                                   1.0 / scale[1], 1.0 / scale[0], ent["table"].data_ptr(), self._stream()),
+                   "savsr_satu_phase_table")
+        tab = ent["table"].view(-1, _lib.SATU_TABLE).cpu().numpy()       # synchronises once
+        ox = np.concatenate([tab[:, 4], tab[:, 6]])
+        oy = np.concatenate([tab[:, 5], tab[:, 7]])
+        if not (np.isfinite(ox).all() and np.isfinite(oy).all()):
+            ent["tiling"] = None
+            return
+        rx = float(ox.max() - ox.min())
+        ry = float(oy.max() - oy.min())
+        budget = (76 * 1024) // (164 * 4)                              # records per workgroup at 2 workgroups / CU
+        best = None
+        for tcols in (1, 2, 4):
+            for trows in (1, 2, 4, 6, 8, 12, 16, 24, 32):
+                lr_c = int(np.ceil(32 * tcols / scale[1] + rx)) + 3
+                lr_r = int(np.ceil(trows / scale[0] + ry)) + 3
+                if lr_c * lr_r > budget:
+                    continue
+                hr_px = trows * 32 * tcols
+                amp = lr_c * lr_r / max(hr_px / (scale[0] * scale[1]), 1e-9)
+                cand = (hr_px >= 256, -amp, hr_px)                     # enough work per workgroup first, then least re-staging
+                if best is None or cand > best[0]:
+                    best = (cand, trows, tcols, lr_r, lr_c)
+        if best is None:
+            ent["tiling"] = None
+            return
+        t = SatuTiling()
+        t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = best[1], best[2], min(best[3], h), min(best[4], w)
+        t.off_min_x, t.off_min_y = float(ox.min()), float(oy.min())
+        ent["tiling"] = t
 
     def satu(self, x: Src, st: Src, row_px: int, h: int, w: int, scale, out: torch.Tensor):
         """STAUpsample.forward (savsr_arch.py:315-376).  x, st: channel-last crops (row pitch row_px
@@ -480,6 +515,7 @@ class HipEngine:
         _lib.check(self.lib.savsr_satu_lr_stage(sw, x.ptr, st.ptr, x.pix, row_px, h, w, lrcat.data_ptr(), s), "savsr_satu_lr_stage")
         _lib.check(self.lib.savsr_satu_hr_upsample(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(),
                                                    ax["iw"].data_ptr(), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"],
+                                                   C.byref(ax["tiling"]) if ax["tiling"] is not None else None,
                                                    out.data_ptr(), s), "savsr_satu_hr_upsample")
         if self.satu_events is not None:
             ev1.record()

@@ -113,14 +113,14 @@ def test_osconv_vs_golden(eng, golden, synth_sd, tag, pfx, cin):
 
 
 def test_channel_sums_large(eng):
-    """Many-block pooled means (64 workgroups) against torch."""
+    """Many-block pooled means against torch."""
     x = rnd((192, 90, 100), 7)
     xall = cl(x)
     srcs = [eng.full(xall, 64, i * 64) for i in range(3)]
-    part = torch.zeros(64 * 192, device="cuda:0")
+    part = torch.zeros(256 * 192, device="cuda:0")
     nblk = eng.channel_sums(srcs, 90 * 100, part)
     torch.cuda.synchronize()
-    mean = part.view(64, 192)[:nblk].sum(0).cpu() / (90 * 100)
+    mean = part.view(256, 192)[:nblk].sum(0).cpu() / (90 * 100)
     assert _maxerr(mean, x.mean(dim=(1, 2))) < 1e-5
 
 
