@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 3
+#define SAVSR_ABI_VERSION 4
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -194,15 +194,17 @@ typedef struct savsr_satu_tiling {
 
 /* gxn[W], gyn[H]: normalised base grid coordinates (savsr_arch.py:270-280) computed by the caller
  * in fp32; idx_h[H], idx_w[W]: index of each row/column's (coor_h, coor_w) value in the table.
- * out: [64][H][W] contiguous. */
+ * out: [64] planes of [H][W], `out_plane` floats apart (>= H*W; a pitch that is not a multiple of a
+ * few KiB keeps the 64 planes of one pixel on different HBM channels). */
 int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w,
                            const float* table, int n_uw, const int32_t* idx_h, const int32_t* idx_w,
                            const float* gyn, const float* gxn, int H, int W,
-                           const savsr_satu_tiling* tiling, float* out, void* stream);
+                           const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream);
 
 /* tail conv 3x3 64->3 + bias at HR plus the bilinear residual of the (unpadded) centre frame
- * (savsr_arch.py:738-739).  feat: [64][H][W]; center: [3][h][w]; out: [3][H][W]; all contiguous. */
-int savsr_tail_residual(const float* feat, const float* tail_w /* [3][64][3][3] */, const float* tail_b,
+ * (savsr_arch.py:738-739).  feat: [64] planes of [H][W], feat_plane floats apart; center: [3][h][w];
+ * out: [3][H][W] contiguous. */
+int savsr_tail_residual(const float* feat, int64_t feat_plane, const float* tail_w /* [3][64][3][3] */, const float* tail_b,
                         const float* center, int h, int w, int H, int W, float* out, void* stream);
 
 #ifdef __cplusplus

@@ -15,7 +15,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 fptr = C.c_void_p   # raw device pointers travel as integers
 
@@ -85,8 +85,8 @@ SIGNATURES = {
     "savsr_satu_lr_stage": (C.c_int, [C.POINTER(SatuWeights), fptr, fptr, C.c_int32, C.c_int32, C.c_int, C.c_int,
                                       fptr, C.c_void_p]),
     "savsr_satu_hr_upsample": (C.c_int, [C.POINTER(SatuWeights), fptr, C.c_int, C.c_int, fptr, C.c_int, fptr, fptr,
-                                         fptr, fptr, C.c_int, C.c_int, C.POINTER(SatuTiling), fptr, C.c_void_p]),
-    "savsr_tail_residual": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
+                                         fptr, fptr, C.c_int, C.c_int, C.POINTER(SatuTiling), fptr, C.c_int64, C.c_void_p]),
+    "savsr_tail_residual": (C.c_int, [fptr, C.c_int64, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
 }
 
 _lib = None

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(const SumParams p) {
     const int per = (p.npx + p.nblk - 1) / p.nblk;
     const int p0 = blk * per, p1 = min(p.npx, p0 + per);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int q = p0 + pl; q < p1; q += PL) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)q * pix + 4 * cg);
         acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(512) void osconv_l1_kernel(const savsr_osconv_attn_
     for (int i = tid; i < d.cin * 8; i += 512) {
         const int c = i % d.cin, part = i / d.cin;
         float s = 0.f;
+#pragma unroll 8
         for (int b = part; b < d.nblk; b += 8) s += d.partial[(long long)b * d.cin + c];
         scr[part * d.cin + c] = s;
     }
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* partial, int 
     for (int i = t; i < c * 8; i += 256) {
         const int ch = i % c, part = i / c;
         float s = 0.f;
+#pragma unroll 8
         for (int b = part; b < nblk; b += 8) s += partial[(long long)b * c + ch];
         scr[part * c + ch] = s;
     }

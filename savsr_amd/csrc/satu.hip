@@ -253,6 +253,7 @@ struct HrParams {
     const float* gxn;
     int H, W;
     float* out;
+    long long out_plane;         // floats between output channel planes (>= H*W)
     int ty, txw, lrh, lrw;       // HR tile rows, 32-px column tiles per workgroup, staged LR window
     float omin_x, omin_y;        // lower bound of the sampling offsets (window origin)
 };
@@ -325,7 +326,7 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
     }
     const bf16x8* wimg = reinterpret_cast<const bf16x8*>(p.wt.wbe_w) + lane;       // [t][ks][part][lane]
     const f32x4* fb4 = reinterpret_cast<const f32x4*>(p.wt.fusion_b + half * 32);   // packed [half][q]
-    const long long HW = (long long)p.H * p.W;
+    const long long HW = p.out_plane;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         f32x16 acc;
@@ -455,9 +456,9 @@ extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x,
 
 extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uw,
                                       const int32_t* idx_h, const int32_t* idx_w, const float* gyn, const float* gxn, int H, int W,
-                                      const savsr_satu_tiling* tiling, float* out, void* stream) {
+                                      const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream) {
     if (!satu_weights_ok(wt) || !lrcat || !table || !idx_h || !idx_w || !gyn || !gxn || !out) return fail_arg("satu_hr_upsample: null pointer");
-    if (h < 2 || w < 2 || H < 1 || W < 1 || n_uw < 1) return fail_arg("satu_hr_upsample: shape (h, w >= 2 required)");
+    if (h < 2 || w < 2 || H < 1 || W < 1 || n_uw < 1 || out_plane < (int64_t)H * W) return fail_arg("satu_hr_upsample: shape (h, w >= 2, out_plane >= H*W required)");
     if ((reinterpret_cast<uintptr_t>(lrcat) | reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(wt->fusion_b) |
          reinterpret_cast<uintptr_t>(wt->wbe_w)) & 15) {
         set_error("satu_hr_upsample: lrcat / table / fusion_b / wbe_w must be 16-byte aligned");
@@ -465,7 +466,7 @@ extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float*
     }
     HrParams p;
     p.wt = *wt; p.lrcat = lrcat; p.h = h; p.w = w; p.table = table; p.n_uw = n_uw; p.idx_h = idx_h; p.idx_w = idx_w;
-    p.gyn = gyn; p.gxn = gxn; p.H = H; p.W = W; p.out = out;
+    p.gyn = gyn; p.gxn = gxn; p.H = H; p.W = W; p.out = out; p.out_plane = out_plane;
     p.ty = 8; p.txw = 1; p.lrh = 0; p.lrw = 0; p.omin_x = 0.f; p.omin_y = 0.f;      // default: no staging, gathers from global
     if (tiling) {
         if (tiling->tile_rows < 1 || tiling->tile_cols32 < 1 || tiling->lr_rows < 0 || tiling->lr_cols < 0)

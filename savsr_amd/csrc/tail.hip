@@ -25,13 +25,13 @@ __device__ __forceinline__ void bil_src(int dst, float scale, int in_size, int& 
 }
 
 __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ feat, const float* __restrict__ wgt, const float* __restrict__ bias,
-                                                   const float* __restrict__ center, int h, int w, int H, int W, float* __restrict__ out) {
+                                                   const float* __restrict__ center, int h, int w, int H, int W, long long FP, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float tile[TL_CH * TL_R * TL_S];
     const int tid = threadIdx.x;
     const int tx = tid & 31, ty = tid >> 5;
     const int X0 = blockIdx.x * TL_TW, Y0 = blockIdx.y * TL_TH;
     const long long HW = (long long)H * W;
-    const bool vec = (W & 3) == 0 && X0 + TL_TW <= W;     // interior columns 16-B aligned and inside the image
+    const bool vec = (W & 3) == 0 && (FP & 3) == 0 && X0 + TL_TW <= W;     // interior columns 16-B aligned and inside the image
     float a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 
     for (int c0 = 0; c0 < 64; c0 += TL_CH) {
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ fea
                 const int ch = cr / TL_R, r = cr - ch * TL_R;
                 const int gy = Y0 - 1 + r;
                 const bool rowok = gy >= 0 && gy < H;
-                const float* src = feat + (long long)(c0 + ch) * HW + (long long)gy * W + X0;
+                const float* src = feat + (long long)(c0 + ch) * FP + (long long)gy * W + X0;
                 float* dst = tile + (ch * TL_R + r) * TL_S;
                 if (it < 8) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ fea
                 const int ch = cr / TL_R, r = cr - ch * TL_R;
                 const int gy = Y0 - 1 + r, gx = X0 - 1 + c;
                 float v = 0.f;
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = feat[(long long)(c0 + ch) * HW + (long long)gy * W + gx];
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = feat[(long long)(c0 + ch) * FP + (long long)gy * W + gx];
                 tile[(ch * TL_R + r) * TL_S + 3 + c] = v;
             }
         }
@@ -114,12 +114,12 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ fea
 
 using namespace savsr;
 
-extern "C" int savsr_tail_residual(const float* feat, const float* w, const float* b, const float* center, int h, int wd, int H, int W,
-                                   float* out, void* stream) {
+extern "C" int savsr_tail_residual(const float* feat, int64_t feat_plane, const float* w, const float* b, const float* center, int h, int wd,
+                                   int H, int W, float* out, void* stream) {
     if (!feat || !w || !b || !center || !out) return fail_arg("tail_residual: null pointer");
-    if (h < 1 || wd < 1 || H < 1 || W < 1) return fail_arg("tail_residual: shape");
+    if (h < 1 || wd < 1 || H < 1 || W < 1 || feat_plane < (int64_t)H * W) return fail_arg("tail_residual: shape");
     if (reinterpret_cast<uintptr_t>(feat) & 15) { set_error("tail_residual: feat must be 16-byte aligned"); return SAVSR_E_ALIGN; }
     dim3 grid((W + TL_TW - 1) / TL_TW, (H + TL_TH - 1) / TL_TH);
-    hipLaunchKernelGGL(tail_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), feat, w, b, center, h, wd, H, W, out);
+    hipLaunchKernelGGL(tail_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), feat, w, b, center, h, wd, H, W, (long long)feat_plane, out);
     return check_launch("tail_kernel");
 }

@@ -499,7 +499,14 @@ class HipEngine:
         t.off_min_x, t.off_min_y = float(ox.min()), float(oy.min())
         ent["tiling"] = t
 
-    def satu(self, x: Src, st: Src, row_px: int, h: int, w: int, scale, out: torch.Tensor):
+    @staticmethod
+    def hr_plane(H: int, W: int) -> int:
+        """Plane pitch (floats) of the planar HR feature map: H*W rounded up to 1 KiB plus 4352 B, so the
+        64 channel planes of one pixel do not alias onto the same HBM channel (H*W*4 is a multiple of
+        16 KiB at 720x1280)."""
+        return ((H * W + 255) // 256) * 256 + 1088
+
+    def satu(self, x: Src, st: Src, row_px: int, h: int, w: int, scale, out: torch.Tensor, out_plane: Optional[int] = None):
         """STAUpsample.forward (savsr_arch.py:315-376).  x, st: channel-last crops (row pitch row_px
         pixels) of [..][..][64] maps; out: [64][H][W] planar."""
         ax = self.satu_axes(h, w, scale)
@@ -516,7 +523,8 @@ class HipEngine:
         _lib.check(self.lib.savsr_satu_hr_upsample(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(),
                                                    ax["iw"].data_ptr(), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"],
                                                    C.byref(ax["tiling"]) if ax["tiling"] is not None else None,
-                                                   out.data_ptr(), s), "savsr_satu_hr_upsample")
+                                                   out.data_ptr(), out_plane if out_plane is not None else ax["H"] * ax["W"], s),
+                   "savsr_satu_hr_upsample")
         if self.satu_events is not None:
             ev1.record()
             self.satu_events.append((ev0, ev1))
@@ -578,12 +586,13 @@ class HipEngine:
         if taps is not None:                    # channel-last [hp][wp][64] tensors
             taps["align_feat"] = align.t
             taps["h_feat"] = hfeat.t
-        satu_out = self.buf("satu.out", nf, H, W)
-        self.satu(hfeat, align, wp, h_in, w_in, scale, satu_out)                     # crops of :737 via (row pitch, h, w)
+        plane = self.hr_plane(H, W)
+        satu_out = self.buf("satu.out", nf, plane)
+        self.satu(hfeat, align, wp, h_in, w_in, scale, satu_out, plane)              # crops of :737 via (row pitch, h, w)
         if taps is not None:
-            taps["satu"] = satu_out
+            taps["satu"] = satu_out[:, : H * W].view(nf, H, W)
         cptr = lq.data_ptr() + 4 * center * 3 * h_in * w_in                         # unpadded centre frame (:696)
-        _lib.check(self.lib.savsr_tail_residual(satu_out.data_ptr(), self.tail_w.data_ptr(), self.tail_b.data_ptr(), cptr,
+        _lib.check(self.lib.savsr_tail_residual(satu_out.data_ptr(), plane, self.tail_w.data_ptr(), self.tail_b.data_ptr(), cptr,
                                                 h_in, w_in, H, W, out.data_ptr(), st), "savsr_tail_residual")
         return out
 

@@ -208,7 +208,7 @@ def test_tail_residual(eng, synth_sd):
     center = torch.from_numpy(np.random.RandomState(52).uniform(0, 1, (1, 3, h, w)).astype(np.float32))
     out = torch.empty(3, H, W, device="cuda:0")
     from savsr_amd import _lib
-    _lib.check(eng.lib.savsr_tail_residual(_dev(feat[0]).data_ptr(), eng.tail_w.data_ptr(), eng.tail_b.data_ptr(),
+    _lib.check(eng.lib.savsr_tail_residual(_dev(feat[0]).data_ptr(), H * W, eng.tail_w.data_ptr(), eng.tail_b.data_ptr(),
                                            (cd := _dev(center[0])).data_ptr(), h, w, H, W, out.data_ptr(), None), "tail")
     torch.cuda.synchronize()
     ref = F.conv2d(feat, synth_sd["tail.weight"], synth_sd["tail.bias"], padding=1) + \

@@ -1,0 +1,74 @@
+"""Micro-benchmarks of single kernels on the GPU box (used under rocprofv3 for PMC passes).
+
+    python3 tools/bench_kernels.py conv 64 64 3 --iters 20
+    python3 tools/bench_kernels.py satu --iters 20
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from savsr_amd import engine as E  # noqa: E402
+from savsr_amd._lib import ACT_LRELU  # noqa: E402
+from savsr_amd.archs.savsr_arch import SAVSR  # noqa: E402
+from savsr_amd.utils import synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["conv", "satu", "tail"])
+    ap.add_argument("cin", type=int, nargs="?", default=64)
+    ap.add_argument("cout", type=int, nargs="?", default=64)
+    ap.add_argument("ks", type=int, nargs="?", default=3)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--h", type=int, default=180)
+    ap.add_argument("--w", type=int, default=320)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    eng = E.HipEngine(synth.synth_state_dict(), SAVSR().cfg, dev)
+    h, w = a.h, a.w
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if a.what == "conv":
+        g = torch.Generator().manual_seed(0)
+        wt = torch.randn(a.cout, a.cin, a.ks, a.ks, generator=g) / (a.cin * a.ks * a.ks) ** 0.5
+        weights = (E.pack_conv_weight(wt).to(dev), torch.randn(a.cout, generator=g).to(dev), a.cout, a.cin, a.ks)
+        nsrc = max(1, a.cin // 64)
+        xs = [torch.randn(h, w, a.cin // nsrc, generator=g).to(dev) for _ in range(nsrc)]
+        out = torch.empty(h, w, a.cout, device=dev)
+        run = lambda: eng.conv("bench", [eng.full(x) for x in xs], eng.full(out), h, w, ACT_LRELU, 0.2, weights=weights)
+        flop = 2.0 * a.cin * a.cout * a.ks * a.ks * h * w
+    elif a.what == "satu":
+        g = torch.Generator().manual_seed(0)
+        x, st = torch.randn(h, w, 64, generator=g).to(dev), torch.randn(h, w, 64, generator=g).to(dev)
+        H, W = E.get_hw(h, w, (4, 4))
+        plane = eng.hr_plane(H, W)
+        out = torch.empty(64, plane, device=dev)
+        run = lambda: eng.satu(eng.full(x), eng.full(st), w, h, w, (4, 4), out, plane)
+        flop = 0.0
+    else:
+        from savsr_amd import _lib
+        H, W = 4 * h, 4 * w
+        plane = eng.hr_plane(H, W)
+        feat = torch.randn(64, plane, device=dev)
+        center = torch.rand(3, h, w, device=dev)
+        out = torch.empty(3, H, W, device=dev)
+        run = lambda: _lib.check(eng.lib.savsr_tail_residual(feat.data_ptr(), plane, eng.tail_w.data_ptr(), eng.tail_b.data_ptr(),
+                                                             center.data_ptr(), h, w, H, W, out.data_ptr(), eng._stream()), "tail")
+        flop = 0.0
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(a.iters):
+        run()
+    ev1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * ev0.elapsed_time(ev1) / a.iters
+    print(f"{a.what} cin={a.cin} cout={a.cout} ks={a.ks} {h}x{w}: {us:.2f} us/iter" + (f"  {flop / us / 1e6:.1f} TFLOP/s fp32-equivalent" if flop else ""))
+
+
+if __name__ == "__main__":
+    main()
