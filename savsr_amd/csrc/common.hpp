@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/savsr_hip.h"
 
@@ -31,6 +32,7 @@ __host__ __device__ constexpr int conv_kc(int ksize) { return ksize == 3 ? 16 : 
 __host__ __device__ inline int conv_cot(int cout) { return cout > 32 ? 64 : 32; }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

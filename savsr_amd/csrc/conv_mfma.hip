@@ -55,7 +55,7 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi,
     }
 }
 
-template <int KS, int NT>
+template <int KS, int NT, int PF, int STG>
 __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
     constexpr int TAPS = KS * KS, HALO = KS / 2;
     constexpr int KC = conv_kc(KS), KSTEPS = KC / 16;
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
     constexpr int B_PART = KSTEPS * 2 * NPX;                 // 16-B units per part (hi or lo)
     constexpr int B_UNITS = 2 * B_PART;
     constexpr int W_UNITS = TAPS * KSTEPS * NT * 2 * 64;     // 16-B units per phase
-    constexpr int B_IT = (B_PART + 511) / 512;
+    constexpr int B_ITEMS = STG ? B_PART * 2 : B_PART;     // STG 1: one float4 (4 channels) per item, 16 lines per wave load
+    constexpr int B_IT = (B_ITEMS + 511) / 512;
     constexpr int W_IT = (W_UNITS + 511) / 512;
     constexpr int STEPS = TAPS * KSTEPS;
 
@@ -90,15 +91,24 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
         for (int i = 0; i < B_IT; ++i) {
             const int e = tid + i * 512;
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-            if (e < B_PART) {
-                const int q = e / NPX;                      // kstep * 2 + khalf
-                const int pl = e - q * NPX;
+            if (e < B_ITEMS) {
+                int q, pl, sub = 0;
+                if (STG) {                                   // e = (pixel, float4-of-the-chunk): 4 lanes read one pixel's 64 B
+                    constexpr int PER = KSTEPS * 4;
+                    pl = e / PER;
+                    const int c8 = e - pl * PER;
+                    q = c8 >> 1;
+                    sub = c8 & 1;
+                } else {
+                    q = e / NPX;                            // kstep * 2 + khalf
+                    pl = e - q * NPX;
+                }
                 const int r = pl / IC, c = pl - r * IC;
                 const int gy = y0 - HALO + r, gx = x0 - HALO + c;
                 if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
-                    const f32x4* g = reinterpret_cast<const f32x4*>(base + ((long long)gy * p.w + gx) * pix + cb + q * 8);
+                    const f32x4* g = reinterpret_cast<const f32x4*>(base + ((long long)gy * p.w + gx) * pix + cb + q * 8 + sub * 4);
                     v0 = g[0];
-                    v1 = g[1];
+                    if (!STG) v1 = g[1];
                 }
             }
             b_reg[i][0] = v0;
@@ -119,11 +129,26 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int e = tid + i * 512;
-            if (e < B_PART) {
-                bf16x8 hi, lo;
-                split8(b_reg[i][0], b_reg[i][1], hi, lo);
-                bl[e] = hi;
-                bl[B_PART + e] = lo;
+            if (e < B_ITEMS) {
+                if (STG) {
+                    constexpr int PER = KSTEPS * 4;
+                    const int pl = e / PER, c8 = e - pl * PER, q = c8 >> 1, sub = c8 & 1;
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const __bf16 hh = (__bf16)b_reg[i][0][j];
+                        hi[j] = hh;
+                        lo[j] = (__bf16)(b_reg[i][0][j] - (float)hh);
+                    }
+                    bf16x4* dst = reinterpret_cast<bf16x4*>(bl + q * NPX + pl) + sub;
+                    dst[0] = hi;
+                    dst[B_PART * 2] = lo;
+                } else {
+                    bf16x8 hi, lo;
+                    split8(b_reg[i][0], b_reg[i][1], hi, lo);
+                    bl[e] = hi;
+                    bl[B_PART + e] = lo;
+                }
             }
         }
 #pragma unroll
@@ -175,15 +200,26 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bh, acc[t], 0, 0, 0);
             }
         };
-        Frag f0, f1;
-        load_frag(0, f0);
+        if (PF == 1) {
+            Frag f0, f1;
+            load_frag(0, f0);
 #pragma unroll
-        for (int s = 0; s < STEPS; s += 2) {
-            if (s + 1 < STEPS) load_frag(s + 1, f1);
-            mma(f0);
-            if (s + 1 < STEPS) {
-                if (s + 2 < STEPS) load_frag(s + 2, f0);
-                mma(f1);
+            for (int s = 0; s < STEPS; s += 2) {
+                if (s + 1 < STEPS) load_frag(s + 1, f1);
+                mma(f0);
+                if (s + 1 < STEPS) {
+                    if (s + 2 < STEPS) load_frag(s + 2, f0);
+                    mma(f1);
+                }
+            }
+        } else {                                   // fragments two (tap, kstep) steps ahead of their MFMAs
+            Frag f[3];
+            load_frag(0, f[0]);
+            if (STEPS > 1) load_frag(1, f[1]);
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                if (s + 2 < STEPS) load_frag(s + 2, f[(s + 2) % 3]);
+                mma(f[s % 3]);
             }
         }
         if (more) stage_store(buf ^ 1);
@@ -235,14 +271,14 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
     }
 }
 
-template <int KS, int NT>
-static int launch_conv(const ConvParams& p, hipStream_t st) {
+template <int KS, int NT, int PF, int STG>
+static int launch_conv_v(const ConvParams& p, hipStream_t st) {
     constexpr int TAPS = KS * KS, HALO = KS / 2, KC = conv_kc(KS), KSTEPS = KC / 16;
     constexpr int NPX = (CONV_TH + 2 * HALO) * (CONV_TW + 2 * HALO);
     constexpr size_t lds = 16ull * 2 * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64);
     static bool attr_done = false;      // benign race: idempotent attribute set
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PF, STG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("conv: hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds, hipGetErrorString(e));
@@ -251,8 +287,28 @@ static int launch_conv(const ConvParams& p, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid((p.w + CONV_TW - 1) / CONV_TW, (p.h + CONV_TH - 1) / CONV_TH, (p.cout + 32 * NT - 1) / (32 * NT));
-    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT>), grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, PF, STG>), grid, dim3(512), lds, st, p);
     return check_launch("conv_bf16x3_kernel");
+}
+
+// SAVSR_CONV_VARIANT (tuning knob, read once): bit 0 = fragment prefetch depth 2, bit 1 = coalesced staging
+static int conv_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SAVSR_CONV_VARIANT");
+        v = e ? atoi(e) & 3 : 3;
+    }
+    return v;
+}
+
+template <int KS, int NT>
+static int launch_conv(const ConvParams& p, hipStream_t st) {
+    switch (conv_variant()) {
+        case 0: return launch_conv_v<KS, NT, 1, 0>(p, st);
+        case 1: return launch_conv_v<KS, NT, 2, 0>(p, st);
+        case 2: return launch_conv_v<KS, NT, 1, 1>(p, st);
+        default: return launch_conv_v<KS, NT, 2, 1>(p, st);
+    }
 }
 
 }  // namespace savsr
