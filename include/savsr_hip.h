@@ -207,6 +207,12 @@ int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int
 int savsr_tail_residual(const float* feat, int64_t feat_plane, const float* tail_w /* [3][64][3][3] */, const float* tail_b,
                         const float* center, int h, int w, int H, int W, float* out, void* stream);
 
+/* ---- diagnostics (synchronous, never called by the product path) ----------------------------
+ * Per-workgroup s_memtime stamps of the conv kernel: [blk][6] = entry, after prologue, after the
+ * first K phase, after the K loop, after the stores drained, s_memrealtime at entry. */
+int savsr_debug_conv_stamps(int enable);
+int savsr_debug_read_conv_stamps(long long* host, int nblocks);
+
 #ifdef __cplusplus
 }
 #endif

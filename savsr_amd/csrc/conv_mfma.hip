@@ -45,6 +45,19 @@ struct ConvParams {
     int out_pix;
 };
 
+// Diagnostics (not used by the product path): per-workgroup s_memtime stamps of the conv kernel
+// phases, enabled by savsr_debug_conv_stamps(1) and read back with savsr_debug_read_conv_stamps().
+constexpr int STAMP_BLOCKS = 1024, STAMP_N = 6;
+__device__ long long g_conv_stamps[STAMP_BLOCKS * STAMP_N];
+__device__ int g_conv_stamps_on = 0;
+
+__device__ __forceinline__ void stamp(int on, int slot) {
+    if (on && threadIdx.x == 0) {
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (b < STAMP_BLOCKS) g_conv_stamps[b * STAMP_N + slot] = (slot == 5) ? (long long)__builtin_amdgcn_s_memrealtime() : (long long)__builtin_amdgcn_s_memtime();
+    }
+}
+
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
     const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
@@ -164,9 +177,13 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    const int stamps_on = __builtin_amdgcn_readfirstlane(g_conv_stamps_on);
+    stamp(stamps_on, 0);
+    stamp(stamps_on, 5);
     stage_load(0);
     stage_store(0);
     __syncthreads();
+    stamp(stamps_on, 1);
 
     struct Frag { bf16x8 ah[NT], al[NT], bh, bl; };
 
@@ -222,30 +239,56 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
                 mma(f[s % 3]);
             }
         }
+        if (chunk == 0) stamp(stamps_on, 2);
         if (more) stage_store(buf ^ 1);
         __syncthreads();
     }
+    stamp(stamps_on, 3);
 
-    // ---- epilogue: lane (pixel, half) holds channels 32 t + 8 g + 4 half + {0..3} in regs 4g..4g+3
-    const int y = y0 + wave, x = x0 + px;
-    if (y >= p.h || x >= p.w) return;
-    const long long pidx = (long long)y * p.w + x;
-    const float mul = p.mul_px ? p.mul_px[pidx] : 1.f;
+    // ---- epilogue ---------------------------------------------------------------------------
+    // Lane (pixel, half) holds channels 32 t + 8 g + 4 half + {0..3} in accumulator regs 4g..4g+3.
+    // Stored straight from that layout, a wave instruction would touch 32 lines with 32 B each
+    // (measured: 17.8 k cycles of store drain per workgroup).  Instead each wave transposes its
+    // 32 px x COT tile through its own LDS slice and stores whole pixel records: consecutive
+    // lanes write consecutive 16 B, 1 KiB contiguous per instruction when out_pix == cout; the
+    // residual reads are coalesced the same way.  (All waves passed the K loop's last barrier,
+    // so the staging buffers are free.)
+    constexpr int COT = 32 * NT, EPS = COT + 4, U = COT / 4;
+    float* ep = reinterpret_cast<float*>(smem_raw) + wave * (32 * EPS);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int co = cob * (32 * NT) + 32 * t + 8 * g + 4 * half;
-            if (co >= p.cout) continue;
-            float v[4] = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-            const bool full = co + 3 < p.cout;
+            const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(ep + px * EPS + 32 * t + 8 * g + 4 * half) = v;
+        }
+    const int y = y0 + wave;
+    if (y < p.h) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (p.bias && (full || co + i < p.cout)) v[i] += p.bias[co + i];
-                if (p.act == SAVSR_ACT_RELU) v[i] = fmaxf(v[i], 0.f);
-                else if (p.act == SAVSR_ACT_LRELU) v[i] = v[i] > 0.f ? v[i] : v[i] * p.slope;
-                else if (p.act == SAVSR_ACT_SIGMOID) v[i] = sigmoidf_(v[i]);
-                v[i] *= mul;
+        for (int i = 0; i < U / 2; ++i) {
+            const int unit = lane + 64 * i;
+            const int pl = unit / U, c4 = unit - pl * U;
+            const int x = x0 + pl, co = cob * COT + 4 * c4;
+            if (x >= p.w || co >= p.cout) continue;
+            const long long pidx = (long long)y * p.w + x;
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ep + pl * EPS + 4 * c4);
+            float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+            const bool full = co + 3 < p.cout;
+            const float mul = p.mul_px ? p.mul_px[pidx] : 1.f;
+            if (p.bias) {
+                if (full) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+                    v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+                } else {
+                    for (int j = 0; j < 4 && co + j < p.cout; ++j) v[j] += p.bias[co + j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (p.act == SAVSR_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+                else if (p.act == SAVSR_ACT_LRELU) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+                else if (p.act == SAVSR_ACT_SIGMOID) v[j] = sigmoidf_(v[j]);
+                v[j] *= mul;
             }
             float* o = p.out + pidx * p.out_pix + co;
             if (full) {
@@ -257,17 +300,21 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
                     const f32x4 r = *reinterpret_cast<const f32x4*>(p.res2 + pidx * p.res2_pix + co);
                     v[0] += p.res2_scale * r[0]; v[1] += p.res2_scale * r[1]; v[2] += p.res2_scale * r[2]; v[3] += p.res2_scale * r[3];
                 }
-                f32x4 ov = {v[0], v[1], v[2], v[3]};
+                const f32x4 ov = {v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(o) = ov;
             } else {
-                for (int i = 0; i < 4 && co + i < p.cout; ++i) {
-                    float vv = v[i];
-                    if (p.res1) vv += p.res1[pidx * p.res1_pix + co + i];
-                    if (p.res2) vv += p.res2_scale * p.res2[pidx * p.res2_pix + co + i];
-                    o[i] = vv;
+                for (int j = 0; j < 4 && co + j < p.cout; ++j) {
+                    float vv = v[j];
+                    if (p.res1) vv += p.res1[pidx * p.res1_pix + co + j];
+                    if (p.res2) vv += p.res2_scale * p.res2[pidx * p.res2_pix + co + j];
+                    o[j] = vv;
                 }
             }
         }
+    }
+    if (stamps_on) {
+        __builtin_amdgcn_s_waitcnt(0);          // diagnostics: include the store drain in the last stamp
+        stamp(stamps_on, 4);
     }
 }
 
@@ -314,6 +361,17 @@ static int launch_conv(const ConvParams& p, hipStream_t st) {
 }  // namespace savsr
 
 using namespace savsr;
+
+extern "C" int savsr_debug_conv_stamps(int enable) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps_on), &enable, sizeof(int));
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int savsr_debug_read_conv_stamps(long long* host, int nblocks) {
+    if (!host || nblocks < 1 || nblocks > STAMP_BLOCKS) return fail_arg("debug_read_conv_stamps");
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), sizeof(long long) * STAMP_N * nblocks);
+    return e == hipSuccess ? 0 : (int)e;
+}
 
 extern "C" int64_t savsr_conv_packed_elems(int cout, int cin, int ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return -1;

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--h", type=int, default=180)
     ap.add_argument("--w", type=int, default=320)
+    ap.add_argument("--stamps", action="store_true", help="conv only: print per-workgroup phase timings (s_memtime)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     eng = E.HipEngine(synth.synth_state_dict(), SAVSR().cfg, dev)
@@ -67,6 +68,22 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     us = 1e3 * ev0.elapsed_time(ev1) / a.iters
+    if a.stamps and a.what == "conv":
+        import ctypes as C
+        import numpy as np
+        eng.lib.savsr_debug_conv_stamps(1)
+        run()
+        torch.cuda.synchronize()
+        nb = min(1024, ((w + 31) // 32) * ((h + 7) // 8))
+        buf = (C.c_longlong * (6 * nb))()
+        eng.lib.savsr_debug_read_conv_stamps(buf, nb)
+        eng.lib.savsr_debug_conv_stamps(0)
+        st = np.array(buf[:], dtype=np.int64).reshape(nb, 6)
+        d = np.diff(st[:, :5], axis=1)
+        print("stamps (shader cycles, median over workgroups): prologue %d  phase0 %d  remaining phases %d  epilogue+drain %d  total %d" %
+              tuple(np.median(d, axis=0).tolist() + [np.median(st[:, 4] - st[:, 0])]))
+        rt = st[:, 5]
+        print("workgroup start spread (100 MHz ticks): min %d max %d -> %.2f us" % (rt.min(), rt.max(), (rt.max() - rt.min()) / 100.0))
     print(f"{a.what} cin={a.cin} cout={a.cout} ks={a.ks} {h}x{w}: {us:.2f} us/iter" + (f"  {flop / us / 1e6:.1f} TFLOP/s fp32-equivalent" if flop else ""))
 
 
