@@ -68,24 +68,26 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi,
     }
 }
 
-template <int KS, int NT, int PF, int STG>
-__global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
+template <int KS, int NT, int TH, int DB>
+__global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const ConvParams p) {
+    constexpr int PF = 2, STG = 1, NTHR = 64 * TH;
     constexpr int TAPS = KS * KS, HALO = KS / 2;
     constexpr int KC = conv_kc(KS), KSTEPS = KC / 16;
-    constexpr int IR = CONV_TH + 2 * HALO, IC = CONV_TW + 2 * HALO, NPX = IR * IC;
+    constexpr int IR = TH + 2 * HALO, IC = CONV_TW + 2 * HALO, NPX = IR * IC;
     constexpr int B_PART = KSTEPS * 2 * NPX;                 // 16-B units per part (hi or lo)
     constexpr int B_UNITS = 2 * B_PART;
     constexpr int W_UNITS = TAPS * KSTEPS * NT * 2 * 64;     // 16-B units per phase
     constexpr int B_ITEMS = STG ? B_PART * 2 : B_PART;     // STG 1: one float4 (4 channels) per item, 16 lines per wave load
-    constexpr int B_IT = (B_ITEMS + 511) / 512;
-    constexpr int W_IT = (W_UNITS + 511) / 512;
+    constexpr int B_IT = (B_ITEMS + NTHR - 1) / NTHR;
+    constexpr int W_IT = (W_UNITS + NTHR - 1) / NTHR;
     constexpr int STEPS = TAPS * KSTEPS;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16x8* smem = reinterpret_cast<bf16x8*>(smem_raw);      // 16-B units: [2][B_UNITS] then [2][W_UNITS]
+    bf16x8* smem = reinterpret_cast<bf16x8*>(smem_raw);      // 16-B units: [NB][B_UNITS] then [NB][W_UNITS], NB = DB ? 2 : 1
+    constexpr int NB = DB ? 2 : 1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
-    const int x0 = blockIdx.x * CONV_TW, y0 = blockIdx.y * CONV_TH, cob = blockIdx.z;
+    const int x0 = blockIdx.x * CONV_TW, y0 = blockIdx.y * TH, cob = blockIdx.z;
     const int per_src = p.src_ch / KC;
 
     f32x4 b_reg[B_IT][2];
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
         if (s == 4) { base = p.src[4]; pix = p.src_pix[4]; }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int e = tid + i * 512;
+            const int e = tid + i * NTHR;
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
             if (e < B_ITEMS) {
                 int q, pl, sub = 0;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wimg) + ((long long)cob * p.nchunk + chunk) * W_UNITS;
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) {
-            const int e = tid + i * 512;
+            const int e = tid + i * NTHR;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (e < W_UNITS) v = wsrc[e];
             w_reg[i] = v;
@@ -138,10 +140,10 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
     };
     auto stage_store = [&](int buf) {
         bf16x8* bl = smem + buf * B_UNITS;
-        f32x4* wl = reinterpret_cast<f32x4*>(smem + 2 * B_UNITS + buf * W_UNITS);
+        f32x4* wl = reinterpret_cast<f32x4*>(smem + NB * B_UNITS + buf * W_UNITS);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int e = tid + i * 512;
+            const int e = tid + i * NTHR;
             if (e < B_ITEMS) {
                 if (STG) {
                     constexpr int PER = KSTEPS * 4;
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
         }
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) {
-            const int e = tid + i * 512;
+            const int e = tid + i * NTHR;
             if (e < W_UNITS) wl[e] = w_reg[i];
         }
     };
@@ -188,12 +190,12 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
     struct Frag { bf16x8 ah[NT], al[NT], bh, bl; };
 
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-        const int buf = chunk & 1;
+        const int buf = DB ? (chunk & 1) : 0;
         const bool more = chunk + 1 < p.nchunk;
         if (more) stage_load(chunk + 1);
 
         const bf16x8* bl = smem + buf * B_UNITS;
-        const bf16x8* wl = smem + 2 * B_UNITS + buf * W_UNITS;
+        const bf16x8* wl = smem + NB * B_UNITS + buf * W_UNITS;
         const bf16x8* bbase = bl + half * NPX + wave * IC + px;
         const bf16x8* abase = wl + lane;
 
@@ -240,8 +242,16 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
             }
         }
         if (chunk == 0) stamp(stamps_on, 2);
-        if (more) stage_store(buf ^ 1);
-        __syncthreads();
+        if (DB) {
+            if (more) stage_store(buf ^ 1);
+            __syncthreads();
+        } else {                                  // single-buffered: everyone is done reading, then refill
+            __syncthreads();
+            if (more) {
+                stage_store(0);
+                __syncthreads();
+            }
+        }
     }
     stamp(stamps_on, 3);
 
@@ -318,14 +328,16 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const ConvParams p) {
     }
 }
 
-template <int KS, int NT, int PF, int STG>
+template <int KS, int NT, int TH, int DB>
 static int launch_conv_v(const ConvParams& p, hipStream_t st) {
     constexpr int TAPS = KS * KS, HALO = KS / 2, KC = conv_kc(KS), KSTEPS = KC / 16;
-    constexpr int NPX = (CONV_TH + 2 * HALO) * (CONV_TW + 2 * HALO);
-    constexpr size_t lds = 16ull * 2 * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64);
+    constexpr int NPX = (TH + 2 * HALO) * (CONV_TW + 2 * HALO);
+    constexpr size_t stage = 16ull * (DB ? 2 : 1) * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64);
+    constexpr size_t epi = 4ull * TH * 32 * (32 * NT + 4);
+    constexpr size_t lds = stage > epi ? stage : epi;
     static bool attr_done = false;      // benign race: idempotent attribute set
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PF, STG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, TH, DB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("conv: hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds, hipGetErrorString(e));
@@ -333,29 +345,26 @@ static int launch_conv_v(const ConvParams& p, hipStream_t st) {
         }
         attr_done = true;
     }
-    dim3 grid((p.w + CONV_TW - 1) / CONV_TW, (p.h + CONV_TH - 1) / CONV_TH, (p.cout + 32 * NT - 1) / (32 * NT));
-    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, PF, STG>), grid, dim3(512), lds, st, p);
+    dim3 grid((p.w + CONV_TW - 1) / CONV_TW, (p.h + TH - 1) / TH, (p.cout + 32 * NT - 1) / (32 * NT));
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, TH, DB>), grid, dim3(64 * TH), lds, st, p);
     return check_launch("conv_bf16x3_kernel");
 }
 
-// SAVSR_CONV_VARIANT (tuning knob, read once): bit 0 = fragment prefetch depth 2, bit 1 = coalesced staging
+// SAVSR_CONV_VARIANT (tuning knob, read once): 0 = 8-row tiles, double-buffered staging, 1 workgroup / CU;
+// 1 = 4-row tiles, single-buffered staging, 3 workgroups / CU (default)
 static int conv_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("SAVSR_CONV_VARIANT");
-        v = e ? atoi(e) & 3 : 3;
+        v = e ? atoi(e) & 1 : 1;
     }
     return v;
 }
 
 template <int KS, int NT>
 static int launch_conv(const ConvParams& p, hipStream_t st) {
-    switch (conv_variant()) {
-        case 0: return launch_conv_v<KS, NT, 1, 0>(p, st);
-        case 1: return launch_conv_v<KS, NT, 2, 0>(p, st);
-        case 2: return launch_conv_v<KS, NT, 1, 1>(p, st);
-        default: return launch_conv_v<KS, NT, 2, 1>(p, st);
-    }
+    if (conv_variant() == 0) return launch_conv_v<KS, NT, 8, 1>(p, st);
+    return launch_conv_v<KS, NT, 4, 0>(p, st);
 }
 
 }  // namespace savsr

@@ -11,6 +11,7 @@ include/savsr_hip.h.  There is no CPU / eager fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -142,6 +143,8 @@ class HipEngine:
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._satu_axes: Dict[tuple, dict] = {}
         self.satu_events: Optional[list] = None     # bench.py: (start, end) HIP events around SATU
+        self.use_graphs = os.environ.get("SAVSR_GRAPHS", "1") != "0"
+        self._graphs: Dict[tuple, tuple] = {}
         self._pack_all({k: v.detach() for k, v in state.items()})
 
     # ------------------------------------------------------------------ weight preparation
@@ -512,9 +515,6 @@ class HipEngine:
         ax = self.satu_axes(h, w, scale)
         s = self._stream()
         sw = C.byref(self.satu_w)
-        if self.satu_events is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
         _lib.check(self.lib.savsr_satu_phase_table(sw, ax["uh"].data_ptr(), ax["n_uh"], ax["uw"].data_ptr(), ax["n_uw"],
                                                    1.0 / scale[1], 1.0 / scale[0], ax["table"].data_ptr(), s), "savsr_satu_phase_table")
         assert x.pix == st.pix
@@ -525,21 +525,16 @@ class HipEngine:
                                                    C.byref(ax["tiling"]) if ax["tiling"] is not None else None,
                                                    out.data_ptr(), out_plane if out_plane is not None else ax["H"] * ax["W"], s),
                    "savsr_satu_hr_upsample")
-        if self.satu_events is not None:
-            ev1.record()
-            self.satu_events.append((ev0, ev1))
         return out
 
     # ------------------------------------------------------------------ whole frame
-    def forward_one(self, lq: torch.Tensor, scale, out: torch.Tensor, taps: Optional[dict] = None):
-        """lq: [T, 3, h, w] fp32 contiguous on device; out: [3, H, W]."""
+    def _stage_body(self, lq: torch.Tensor, scale) -> dict:
+        """Everything up to the SATU inputs (savsr_arch.py:692-734).  lq: [T, 3, h, w] on device."""
         cfg, nf = self.cfg, self.nf
         T, cin, h_in, w_in = lq.shape
         assert T == cfg["num_frame"] and cin == cfg["num_in_ch"] == 3 and cfg["interval"] == 0
         if h_in < 2 or w_in < 2:
             raise ValueError("SAVSR needs h, w >= 2")
-        center = T // 2 if cfg["center_frame_idx"] is None else cfg["center_frame_idx"]
-        H, W = get_hw(h_in, w_in, scale)
         hp, wp = h_in + (h_in & 1), w_in + (w_in & 1)              # pad_spatial to even (savsr_arch.py:670-690)
         st = self._stream()
         wins = self.buf("windows", T - 2, hp, wp, 16)
@@ -583,17 +578,76 @@ class HipEngine:
             rg = self.conv(f"RG.{g}.conv", [r], self.full(self.buf("rg.out", hp, wp, nf)), hp, wp, res1=xin)
             hcur = self.osadapt(g, rg, share, self.full(self.buf(f"rg.h{g & 1}", hp, wp, nf)), hp, wp, scale)
         hfeat = self.conv("conv_last", [hcur], self.full(self.buf("hfeat", hp, wp, nf)), hp, wp, res1=share)   # :733-734
-        if taps is not None:                    # channel-last [hp][wp][64] tensors
-            taps["align_feat"] = align.t
-            taps["h_feat"] = hfeat.t
+        H, W = get_hw(h_in, w_in, scale)
         plane = self.hr_plane(H, W)
-        satu_out = self.buf("satu.out", nf, plane)
-        self.satu(hfeat, align, wp, h_in, w_in, scale, satu_out, plane)              # crops of :737 via (row pitch, h, w)
-        if taps is not None:
-            taps["satu"] = satu_out[:, : H * W].view(nf, H, W)
-        cptr = lq.data_ptr() + 4 * center * 3 * h_in * w_in                         # unpadded centre frame (:696)
-        _lib.check(self.lib.savsr_tail_residual(satu_out.data_ptr(), plane, self.tail_w.data_ptr(), self.tail_b.data_ptr(), cptr,
-                                                h_in, w_in, H, W, out.data_ptr(), st), "savsr_tail_residual")
+        return dict(align=align, hfeat=hfeat, wp=wp, h=h_in, w=w_in, H=H, W=W, plane=plane, satu_out=self.buf("satu.out", nf, plane))
+
+    def _stage_satu(self, c: dict, scale):
+        self.satu(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], scale, c["satu_out"], c["plane"])   # crops of :737 via (row pitch, h, w)
+
+    def _stage_tail(self, c: dict, lq: torch.Tensor, out: torch.Tensor):
+        cfg = self.cfg
+        T = lq.shape[0]
+        center = T // 2 if cfg["center_frame_idx"] is None else cfg["center_frame_idx"]
+        cptr = lq.data_ptr() + 4 * center * 3 * c["h"] * c["w"]                     # unpadded centre frame (:696)
+        _lib.check(self.lib.savsr_tail_residual(c["satu_out"].data_ptr(), c["plane"], self.tail_w.data_ptr(), self.tail_b.data_ptr(), cptr,
+                                                c["h"], c["w"], c["H"], c["W"], out.data_ptr(), self._stream()), "savsr_tail_residual")
+
+    def forward_one(self, lq: torch.Tensor, scale, out: torch.Tensor, taps: Optional[dict] = None):
+        """Eager launch sequence.  lq: [T, 3, h, w] fp32 contiguous on device; out: [3, H, W]."""
+        c = self._stage_body(lq, scale)
+        if self.satu_events is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        self._stage_satu(c, scale)
+        if self.satu_events is not None:
+            ev1.record()
+            self.satu_events.append((ev0, ev1))
+        if taps is not None:                    # channel-last [hp][wp][64] tensors; SATU output planar
+            taps["align_feat"] = c["align"].t
+            taps["h_feat"] = c["hfeat"].t
+            taps["satu"] = c["satu_out"][:, : c["H"] * c["W"]].view(self.nf, c["H"], c["W"])
+        self._stage_tail(c, lq, out)
+        return out
+
+    def _forward_graphed(self, lq: torch.Tensor, scale, out: torch.Tensor):
+        """hipGraph replay of the same launch sequence (three graphs: body | SATU | tail, so the SATU
+        stage can be bracketed by HIP events).  The ~1400 launches of a frame cost ~11 us of host time
+        each when issued from Python; captured once per (shape, scale) they replay in tens of us."""
+        key = (tuple(lq.shape), float(scale[0]), float(scale[1]))
+        g = self._graphs.get(key)
+        if g is None:
+            s_in = torch.empty_like(lq)
+            s_out = torch.empty_like(out)
+            s_in.copy_(lq)
+            self.forward_one(s_in, scale, s_out)            # eager warm-up: allocates buffers, sets kernel attributes, plans SATU
+            torch.cuda.synchronize()
+            graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
+            ev = self.satu_events
+            self.satu_events = None
+            try:
+                with torch.cuda.graph(graphs[0]):
+                    c = self._stage_body(s_in, scale)
+                with torch.cuda.graph(graphs[1], pool=graphs[0].pool()):
+                    self._stage_satu(c, scale)
+                with torch.cuda.graph(graphs[2], pool=graphs[0].pool()):
+                    self._stage_tail(c, s_in, s_out)
+            finally:
+                self.satu_events = ev
+            g = (s_in, s_out, graphs)
+            self._graphs[key] = g
+        s_in, s_out, graphs = g
+        s_in.copy_(lq)
+        graphs[0].replay()
+        if self.satu_events is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        graphs[1].replay()
+        if self.satu_events is not None:
+            ev1.record()
+            self.satu_events.append((ev0, ev1))
+        graphs[2].replay()
+        out.copy_(s_out)
         return out
 
     def forward(self, lq: torch.Tensor, scale, taps: Optional[dict] = None) -> torch.Tensor:
@@ -605,5 +659,8 @@ class HipEngine:
         H, W = get_hw(h, w, scale)
         out = torch.empty(b, 3, H, W, device=self.dev, dtype=torch.float32)
         for i in range(b):      # samples are independent (OSConv groups=b, savsr_arch.py:166-167)
-            self.forward_one(lq[i], scale, out[i], taps if i == 0 else None)
+            if self.use_graphs and taps is None:
+                self._forward_graphed(lq[i], scale, out[i])
+            else:
+                self.forward_one(lq[i], scale, out[i], taps if i == 0 else None)
         return out

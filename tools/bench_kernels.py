@@ -74,7 +74,8 @@ def main():
         eng.lib.savsr_debug_conv_stamps(1)
         run()
         torch.cuda.synchronize()
-        nb = min(1024, ((w + 31) // 32) * ((h + 7) // 8))
+        th = 8 if os.environ.get('SAVSR_CONV_VARIANT') == '0' else 4
+        nb = min(1024, ((w + 31) // 32) * ((h + th - 1) // th))
         buf = (C.c_longlong * (6 * nb))()
         eng.lib.savsr_debug_read_conv_stamps(buf, nb)
         eng.lib.savsr_debug_conv_stamps(0)
