@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 4
+#define SAVSR_ABI_VERSION 5
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -96,6 +96,11 @@ int64_t savsr_conv_packed_elems(int cout, int cin, int ksize);
  * savsr_osconv_weights stores W at index p directly.  Unaddressed entries must be zero. */
 int64_t savsr_conv_pack_index(int cout, int cin, int ksize, int co, int ci, int tap);
 int savsr_conv2d(const savsr_conv_desc* d, void* stream);
+/* n (1..6) independent convs of identical geometry (ksize, nsrc, src_ch, h, w, cout) in ONE launch
+ * (grid.z = n * output-channel blocks): e.g. the per-stream convs of a ResidualBlock (savsr_arch.py:402,413)
+ * of both propagation directions.  More workgroups than CUs, so workgroups run out of phase and the
+ * load/store bursts of one overlap the MFMA phases of another. */
+int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-channel partial sums for the global average pools (AdaptiveAvgPool2d(1),

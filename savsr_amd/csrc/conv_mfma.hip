@@ -58,6 +58,12 @@ __device__ __forceinline__ void stamp(int on, int slot) {
     }
 }
 
+constexpr int CONV_MAX_BATCH = 6;
+struct MultiConvParams {
+    ConvParams c[CONV_MAX_BATCH];     // convs of identical geometry; blockIdx.z = conv * ncob + cob
+    int ncob;
+};
+
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
     const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
@@ -69,8 +75,9 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi,
 }
 
 template <int KS, int NT, int TH, int DB>
-__global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const MultiConvParams mp) {
     constexpr int PF = 2, STG = 1, NTHR = 64 * TH;
+    const ConvParams& p = mp.c[blockIdx.z / mp.ncob];
     constexpr int TAPS = KS * KS, HALO = KS / 2;
     constexpr int KC = conv_kc(KS), KSTEPS = KC / 16;
     constexpr int IR = TH + 2 * HALO, IC = CONV_TW + 2 * HALO, NPX = IR * IC;
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const ConvParams p
     constexpr int NB = DB ? 2 : 1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
-    const int x0 = blockIdx.x * CONV_TW, y0 = blockIdx.y * TH, cob = blockIdx.z;
+    const int x0 = blockIdx.x * CONV_TW, y0 = blockIdx.y * TH, cob = blockIdx.z % mp.ncob;
     const int per_src = p.src_ch / KC;
 
     f32x4 b_reg[B_IT][2];
@@ -329,7 +336,8 @@ __global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const ConvParams p
 }
 
 template <int KS, int NT, int TH, int DB>
-static int launch_conv_v(const ConvParams& p, hipStream_t st) {
+static int launch_conv_v(const MultiConvParams& mp, int nconv, hipStream_t st) {
+    const ConvParams& p = mp.c[0];
     constexpr int TAPS = KS * KS, HALO = KS / 2, KC = conv_kc(KS), KSTEPS = KC / 16;
     constexpr int NPX = (TH + 2 * HALO) * (CONV_TW + 2 * HALO);
     constexpr size_t stage = 16ull * (DB ? 2 : 1) * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64);
@@ -345,8 +353,8 @@ static int launch_conv_v(const ConvParams& p, hipStream_t st) {
         }
         attr_done = true;
     }
-    dim3 grid((p.w + CONV_TW - 1) / CONV_TW, (p.h + TH - 1) / TH, (p.cout + 32 * NT - 1) / (32 * NT));
-    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, TH, DB>), grid, dim3(64 * TH), lds, st, p);
+    dim3 grid((p.w + CONV_TW - 1) / CONV_TW, (p.h + TH - 1) / TH, mp.ncob * nconv);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, TH, DB>), grid, dim3(64 * TH), lds, st, mp);
     return check_launch("conv_bf16x3_kernel");
 }
 
@@ -362,9 +370,9 @@ static int conv_variant() {
 }
 
 template <int KS, int NT>
-static int launch_conv(const ConvParams& p, hipStream_t st) {
-    if (conv_variant() == 0) return launch_conv_v<KS, NT, 8, 1>(p, st);
-    return launch_conv_v<KS, NT, 4, 0>(p, st);
+static int launch_conv(const MultiConvParams& mp, int nconv, hipStream_t st) {
+    if (conv_variant() == 0) return launch_conv_v<KS, NT, 8, 1>(mp, nconv, st);
+    return launch_conv_v<KS, NT, 4, 0>(mp, nconv, st);
 }
 
 }  // namespace savsr
@@ -402,8 +410,7 @@ extern "C" int64_t savsr_conv_pack_index(int cout, int cin, int ksize, int co, i
     return group * 512 + (kh * 32 + row) * 8 + j;
 }
 
-extern "C" int savsr_conv2d(const savsr_conv_desc* d, void* stream) {
-    if (!d) return fail_arg("conv: null descriptor");
+static int fill_params(const savsr_conv_desc* d, ConvParams& p) {
     if (d->ksize != 1 && d->ksize != 3) return fail_arg("conv: ksize must be 1 or 3");
     const int kc = conv_kc(d->ksize);
     if (d->nsrc < 1 || d->nsrc > SAVSR_MAX_SRC || d->src_ch < kc || d->src_ch % kc) return fail_arg("conv: nsrc / src_ch (multiple of 16, or 32 for 1x1)");
@@ -411,7 +418,6 @@ extern "C" int savsr_conv2d(const savsr_conv_desc* d, void* stream) {
     if (d->h < 1 || d->w < 1 || d->cout < 1) return fail_arg("conv: shape");
     if (!d->wpacked || !d->out) return fail_arg("conv: null weights/out");
     uintptr_t al = reinterpret_cast<uintptr_t>(d->wpacked) | reinterpret_cast<uintptr_t>(d->out) | (uintptr_t)(d->out_pix * 4);
-    ConvParams p;
     for (int i = 0; i < SAVSR_MAX_SRC; ++i) {
         const bool on = i < d->nsrc;
         if (on && !d->src[i]) return fail_arg("conv: null source");
@@ -421,8 +427,9 @@ extern "C" int savsr_conv2d(const savsr_conv_desc* d, void* stream) {
     }
     if (d->res1) al |= reinterpret_cast<uintptr_t>(d->res1) | (uintptr_t)(d->res1_pix * 4);
     if (d->res2) al |= reinterpret_cast<uintptr_t>(d->res2) | (uintptr_t)(d->res2_pix * 4);
+    if (d->bias) al |= reinterpret_cast<uintptr_t>(d->bias);
     if ((al & 15) && d->cout >= 4) {
-        set_error("conv: sources / residuals / out / weights must be 16-byte aligned with pixel strides multiple of 4 floats");
+        set_error("conv: sources / residuals / bias / out / weights must be 16-byte aligned with pixel strides multiple of 4 floats");
         return SAVSR_E_ALIGN;
     }
     p.nsrc = d->nsrc; p.src_ch = d->src_ch;
@@ -433,8 +440,29 @@ extern "C" int savsr_conv2d(const savsr_conv_desc* d, void* stream) {
     p.mul_px = d->mul_px; p.res1 = d->res1; p.res1_pix = d->res1_pix; p.res2 = d->res2; p.res2_pix = d->res2_pix;
     p.res2_scale = d->res2_scale;
     p.out = d->out; p.out_pix = d->out_pix;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool wide = conv_cot(d->cout) == 64;
-    if (d->ksize == 3) return wide ? launch_conv<3, 2>(p, st) : launch_conv<3, 1>(p, st);
-    return wide ? launch_conv<1, 2>(p, st) : launch_conv<1, 1>(p, st);
+    return 0;
 }
+
+extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* stream) {
+    if (!descs) return fail_arg("conv: null descriptor");
+    if (n < 1 || n > CONV_MAX_BATCH) return fail_arg("conv: batch size must be 1..6");
+    MultiConvParams mp;
+    for (int i = 0; i < n; ++i) {
+        const int rc = fill_params(descs + i, mp.c[i]);
+        if (rc) return rc;
+        const savsr_conv_desc& a = descs[0];
+        const savsr_conv_desc& b = descs[i];
+        if (b.ksize != a.ksize || b.nsrc != a.nsrc || b.src_ch != a.src_ch || b.h != a.h || b.w != a.w || b.cout != a.cout)
+            return fail_arg("conv: all convs of a batch must share ksize / nsrc / src_ch / h / w / cout");
+    }
+    for (int i = n; i < CONV_MAX_BATCH; ++i) mp.c[i] = mp.c[0];
+    const savsr_conv_desc* d = descs;
+    const int cot = conv_cot(d->cout);
+    mp.ncob = (d->cout + cot - 1) / cot;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool wide = cot == 64;
+    if (d->ksize == 3) return wide ? launch_conv<3, 2>(mp, n, st) : launch_conv<3, 1>(mp, n, st);
+    return wide ? launch_conv<1, 2>(mp, n, st) : launch_conv<1, 1>(mp, n, st);
+}
+
+extern "C" int savsr_conv2d(const savsr_conv_desc* d, void* stream) { return savsr_conv2d_batch(d, 1, stream); }

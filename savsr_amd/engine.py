@@ -341,8 +341,8 @@ class HipEngine:
         c_total = t.shape[-1]
         return Src(t, c_total - ch_off if ch is None else ch, c_total, ch_off)
 
-    def conv(self, key, srcs: List[Src], out: Src, h: int, w: int, act=ACT_NONE, slope=0.0,
-             mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None):
+    def conv_desc(self, key, srcs: List[Src], out: Src, h: int, w: int, act=ACT_NONE, slope=0.0,
+                  mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None) -> ConvDesc:
         wpk, bias, cout, cin, ks = weights if weights is not None else self.pw[key]
         d = ConvDesc()
         assert len(srcs) <= _lib.MAX_SRC and all(s.ch == srcs[0].ch for s in srcs)
@@ -360,6 +360,19 @@ class HipEngine:
             d.res2, d.res2_pix = res2.ptr, res2.pix
         d.res2_scale = res2_scale
         d.out, d.out_pix = out.ptr, out.pix
+        return d
+
+    def conv_launch(self, descs: List[ConvDesc], label: str = "conv"):
+        """Independent convs of identical geometry, up to 6 per launch (savsr_conv2d_batch)."""
+        st = self._stream()
+        for i in range(0, len(descs), 6):
+            chunk = descs[i:i + 6]
+            arr = (ConvDesc * len(chunk))(*chunk)
+            _lib.check(self.lib.savsr_conv2d_batch(arr, len(chunk), st), f"savsr_conv2d_batch[{label}]")
+
+    def conv(self, key, srcs: List[Src], out: Src, h: int, w: int, act=ACT_NONE, slope=0.0,
+             mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None):
+        d = self.conv_desc(key, srcs, out, h, w, act, slope, mul_px, res1, res2, res2_scale, weights)
         _lib.check(self.lib.savsr_conv2d(C.byref(d), self._stream()), f"savsr_conv2d[{key}]")
         return out
 
@@ -388,29 +401,51 @@ class HipEngine:
         return (e["wdyn"], None, e["cout"], e["cin"], 3)
 
     # ------------------------------------------------------------------ network pieces
-    def residual_block(self, pfx: str, xs: List[Src], hp: int, wp: int, scale, use_osconv: bool, tag: str) -> List[Src]:
-        """savsr_arch.py:399-415, cat-free."""
-        n, nf = len(xs), self.nf
-        x1 = [self.conv(f"{pfx}.conv0.{i}", [xs[i]], self.full(self.buf(f"{tag}.x1.{i}", hp, wp, nf)), hp, wp, ACT_LRELU, 0.2)
-              for i in range(n)]
-        base = self.full(self.buf(f"{tag}.base", hp, wp, nf))
-        if use_osconv:
-            wd = self.osconv_weights(pfx + ".osconv", x1, hp, wp, scale)
-            self.conv(pfx + ".osconv", x1, base, hp, wp, ACT_LRELU, 0.2, weights=wd)
-        else:
-            self.conv(pfx + ".conv1", x1, base, hp, wp, ACT_LRELU, 0.2)
-        return [self.conv(f"{pfx}.conv2.{i}", [base, x1[i]], self.full(self.buf(f"{tag}.out.{i}", hp, wp, nf)), hp, wp,
-                          ACT_LRELU, 0.2, res1=xs[i]) for i in range(n)]
-
-    def window_l1(self, pfx: str, win: Src, h_past: Src, hp: int, wp: int, scale, tag: str) -> List[Src]:
-        """savsr_arch.py:444-464.  win: packed window [hp][wp][16] (frame t | t-1 | t+1 | 0)."""
+    def residual_blocks(self, groups: List[Tuple[str, List[Src], str]], hp: int, wp: int, scale, use_osconv: bool) -> List[List[Src]]:
+        """ResidualBlock (savsr_arch.py:399-415), cat-free, for several independent blocks of the same
+        shape at once (the two propagation directions): the per-stream convs of all of them go out as
+        single batched launches.  groups: (weight prefix, input streams, buffer tag)."""
         nf = self.nf
-        hcs = self.buf(f"{tag}.hcs", hp, wp, 2 * nf)                 # h_c | h_sup from one fused conv
-        self.conv(pfx + ".win", [win], self.full(hcs), hp, wp, ACT_LRELU, 0.2)
-        feats = [self.full(hcs, nf, 0), self.full(hcs, nf, nf), h_past]
+        L = ACT_LRELU
+        x1s, d0 = [], []
+        for pfx, xs, tag in groups:
+            x1 = [self.full(self.buf(f"{tag}.x1.{i}", hp, wp, nf)) for i in range(len(xs))]
+            d0 += [self.conv_desc(f"{pfx}.conv0.{i}", [xs[i]], x1[i], hp, wp, L, 0.2) for i in range(len(xs))]
+            x1s.append(x1)
+        self.conv_launch(d0, "conv0")
+        bases, d1 = [], []
+        for (pfx, xs, tag), x1 in zip(groups, x1s):
+            base = self.full(self.buf(f"{tag}.base", hp, wp, nf))
+            if use_osconv:
+                wd = self.osconv_weights(pfx + ".osconv", x1, hp, wp, scale)
+                d1.append(self.conv_desc(pfx + ".osconv", x1, base, hp, wp, L, 0.2, weights=wd))
+            else:
+                d1.append(self.conv_desc(pfx + ".conv1", x1, base, hp, wp, L, 0.2))
+            bases.append(base)
+        self.conv_launch(d1, "osconv" if use_osconv else "conv1")
+        outs, d2 = [], []
+        for (pfx, xs, tag), x1, base in zip(groups, x1s, bases):
+            o = [self.full(self.buf(f"{tag}.out.{i}", hp, wp, nf)) for i in range(len(xs))]
+            d2 += [self.conv_desc(f"{pfx}.conv2.{i}", [base, x1[i]], o[i], hp, wp, L, 0.2, res1=xs[i]) for i in range(len(xs))]
+            outs.append(o)
+        self.conv_launch(d2, "conv2")
+        return outs
+
+    def residual_block(self, pfx: str, xs: List[Src], hp: int, wp: int, scale, use_osconv: bool, tag: str) -> List[Src]:
+        return self.residual_blocks([(pfx, xs, tag)], hp, wp, scale, use_osconv)[0]
+
+    def windows_l1(self, units: List[Tuple[str, Src, Src, Src, str]], hp: int, wp: int, scale):
+        """WindowUnit_l1 (savsr_arch.py:444-464) for independent units at once (f2p and p2f of one
+        recurrence step).  units: (prefix, packed window [hp][wp][16], h_past, merge output, tag)."""
+        nf = self.nf
+        hcs = [self.buf(f"{tag}.hcs", hp, wp, 2 * nf) for _, _, _, _, tag in units]       # h_c | h_sup from one fused conv
+        self.conv_launch([self.conv_desc(pfx + ".win", [win], self.full(h), hp, wp, ACT_LRELU, 0.2)
+                          for (pfx, win, _, _, _), h in zip(units, hcs)], "win")
+        feats = [[self.full(h, nf, 0), self.full(h, nf, nf), past] for (_, _, past, _, _), h in zip(units, hcs)]
         for k in range(self.cfg["w1_num_block"]):
-            feats = self.residual_block(f"{pfx}.blocks.{k}", feats, hp, wp, scale, k >= 1, f"{tag}.b{k}")
-        return feats
+            feats = self.residual_blocks([(f"{u[0]}.blocks.{k}", f, f"{u[4]}.b{k}") for u, f in zip(units, feats)], hp, wp, scale, k >= 1)
+        self.conv_launch([self.conv_desc(u[0] + ".merge", f, u[3], hp, wp) for u, f in zip(units, feats)], "merge")
+        return [u[3] for u in units]
 
     def rcab(self, pfx: str, x: Src, out: Src, hp: int, wp: int, tag: str) -> Src:
         """savsr_arch.py:527-549."""
@@ -546,13 +581,10 @@ class HipEngine:
         zero.zero_()          # hidden state restarts from zero every window (savsr_arch.py:705-706)
         hb = hf = self.full(zero)
         hpair = [self.buf(f"hpair{i}", hp, wp, 2 * nf) for i in range(steps)]   # cat(f2p[i], p2f[i]) of :721, written in place
-        for idx in range(steps):                                                    # :708-719
-            cur = T - 1 - sw // 2 - idx
-            feats = self.window_l1("f2p_win", win(cur), hb, hp, wp, scale, "f2p")
-            hb = self.conv("f2p_win.merge", feats, self.full(hpair[steps - 1 - idx], nf, 0), hp, wp)
-            cur = idx + sw // 2
-            feats = self.window_l1("p2f_win", win(cur), hf, hp, wp, scale, "p2f")
-            hf = self.conv("p2f_win.merge", feats, self.full(hpair[idx], nf, nf), hp, wp)
+        for idx in range(steps):                                                    # :708-719, both directions per launch
+            cur_b, cur_f = T - 1 - sw // 2 - idx, idx + sw // 2
+            hb, hf = self.windows_l1([("f2p_win", win(cur_b), hb, self.full(hpair[steps - 1 - idx], nf, 0), "f2p"),
+                                      ("p2f_win", win(cur_f), hf, self.full(hpair[idx], nf, nf), "p2f")], hp, wp, scale)
         # pyramid fusion (:616-618, :485-501, :721-722)
         level: List[Src] = [self.full(t) for t in hpair]
         for i in range(self.n_l2):
