@@ -76,7 +76,7 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi,
 
 template <int KS, int NT, int TH, int DB>
 __global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const MultiConvParams mp) {
-    constexpr int PF = 2, STG = 1, NTHR = 64 * TH;
+    constexpr int STG = 1, NTHR = 64 * TH;
     const ConvParams& p = mp.c[blockIdx.z / mp.ncob];
     constexpr int TAPS = KS * KS, HALO = KS / 2;
     constexpr int KC = conv_kc(KS), KSTEPS = KC / 16;
@@ -226,27 +226,19 @@ __global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const MultiConvPar
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bh, acc[t], 0, 0, 0);
             }
         };
-        if (PF == 1) {
-            Frag f0, f1;
-            load_frag(0, f0);
+        // Operand fragments run two (tap, kstep) steps ahead of their MFMAs.  hipcc (ROCm 7.2) otherwise
+        // sinks every ds_read to just before its MFMA and re-uses one register quad for all A fragments
+        // (ds_read; s_waitcnt lgkmcnt(0); v_mfma ...: MFMA pipe 33 % busy, measured), so the issue order is
+        // pinned with sched_barriers: [reads of step s+2] | [6 NT/2 MFMAs of step s] | ...
+        Frag f[3];
+        load_frag(0, f[0]);
+        if (STEPS > 1) load_frag(1, f[1]);
 #pragma unroll
-            for (int s = 0; s < STEPS; s += 2) {
-                if (s + 1 < STEPS) load_frag(s + 1, f1);
-                mma(f0);
-                if (s + 1 < STEPS) {
-                    if (s + 2 < STEPS) load_frag(s + 2, f0);
-                    mma(f1);
-                }
-            }
-        } else {                                   // fragments two (tap, kstep) steps ahead of their MFMAs
-            Frag f[3];
-            load_frag(0, f[0]);
-            if (STEPS > 1) load_frag(1, f[1]);
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                if (s + 2 < STEPS) load_frag(s + 2, f[(s + 2) % 3]);
-                mma(f[s % 3]);
-            }
+        for (int s = 0; s < STEPS; ++s) {
+            if (s + 2 < STEPS) load_frag(s + 2, f[(s + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(f[s % 3]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (chunk == 0) stamp(stamps_on, 2);
         if (DB) {

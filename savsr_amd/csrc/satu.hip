@@ -156,8 +156,12 @@ __global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + 8 * g);
                 acc[4 * g + 0] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
             }
+            bf16x8 ah[4], al[4];                       // all 8 A fragments of the tap in flight before the first MFMA
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = mma3(wl[(ks * 2 + 0) * 64], wl[(ks * 2 + 1) * 64], sth[ks], stl[ks], acc);
+            for (int ks = 0; ks < 4; ++ks) { ah[ks] = wl[(ks * 2 + 0) * 64]; al[ks] = wl[(ks * 2 + 1) * 64]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = mma3(ah[ks], al[ks], sth[ks], stl[ks], acc);
             const int ky = tap / 5, kx = tap - ky * 5;
             const float* xp = xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half;
 #pragma unroll
