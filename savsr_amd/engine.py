@@ -520,8 +520,8 @@ class HipEngine:
         best = None
         for tcols in (1, 2, 4):
             for trows in (1, 2, 4, 6, 8, 12, 16, 24, 32):
-                lr_c = int(np.ceil(32 * tcols / scale[1] + rx)) + 3
-                lr_r = int(np.ceil(trows / scale[0] + ry)) + 3
+                lr_c = int(np.ceil(32 * tcols / scale[1] + rx)) + 2
+                lr_r = int(np.ceil(trows / scale[0] + ry)) + 2
                 if lr_c * lr_r > budget:
                     continue
                 hr_px = trows * 32 * tcols

@@ -67,7 +67,7 @@ def _draw(key: str, shape, seed: int) -> np.ndarray:
 # up to about a pixel, so random-weight outputs land in a range where tolerances are meaningful.
 _GAINS = {"RG": 0.35, "adapt": 0.5, "conv_last": 0.5, "tail": 0.25,
           "upsample.kernel_conv": 0.25, "upsample.fusion": 0.5,
-          "upsample.body": 2.5, "upsample.offset": 1.5, "upsample.st_offset": 1.0, "upsample.routing": 3.0}
+          "upsample.body": 2.5, "upsample.offset": 0.5, "upsample.st_offset": 0.4, "upsample.routing": 3.0}
 
 
 def _is_bn_key(key: str) -> bool:
