@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 5
+#define SAVSR_ABI_VERSION 6
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -195,6 +195,7 @@ int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const floa
 typedef struct savsr_satu_tiling {
     int32_t tile_rows, tile_cols32, lr_rows, lr_cols;
     float   off_min_x, off_min_y;
+    int32_t table_entries;   /* n_uh * n_uw (tables of <= 256 entries are cached in LDS); 0 = unknown */
 } savsr_satu_tiling;
 
 /* gxn[W], gyn[H]: normalised base grid coordinates (savsr_arch.py:270-280) computed by the caller

@@ -15,7 +15,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 fptr = C.c_void_p   # raw device pointers travel as integers
 
@@ -62,7 +62,7 @@ class SatuWeights(C.Structure):
 
 class SatuTiling(C.Structure):
     _fields_ = [("tile_rows", C.c_int32), ("tile_cols32", C.c_int32), ("lr_rows", C.c_int32), ("lr_cols", C.c_int32),
-                ("off_min_x", C.c_float), ("off_min_y", C.c_float)]
+                ("off_min_x", C.c_float), ("off_min_y", C.c_float), ("table_entries", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/savsr_hip.h declares

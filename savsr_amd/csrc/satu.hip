@@ -94,10 +94,10 @@ __device__ __forceinline__ f32x16 mma3(const bf16x8 ah, const bf16x8 al, const b
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
+__global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xt = smem;                                                   // [288][36]
-    bf16x8* wbuf = reinterpret_cast<bf16x8*>(smem + LR_NPX * LR_XS);    // [2][LR_SLAB]
+    bf16x8* wbuf = reinterpret_cast<bf16x8*>(smem + LR_NPX * LR_XS);    // [3][LR_SLAB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int x0 = blockIdx.x * LR_TW, y0 = blockIdx.y * LR_TH;
@@ -129,10 +129,17 @@ __global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + ((long long)sy * p.row_px + sx) * p.pix + 32 * cg + 4 * c4);
             *reinterpret_cast<f32x4*>(xt + pl * LR_XS + 4 * c4) = v;
         }
+        // weight slabs: 3-deep LDS ring, global loads issued two taps ahead of their use
         {
             const bf16x8* src = kw + (long long)(0 * 2 + cg) * LR_SLAB;
             wbuf[tid] = src[tid];
             wbuf[tid + 256] = src[tid + 256];
+        }
+        bf16x8 nx0, nx1;                          // slab of tap + 1, in flight
+        {
+            const bf16x8* src = kw + (long long)(1 * 2 + cg) * LR_SLAB;
+            nx0 = src[tid];
+            nx1 = src[tid + 256];
         }
         __syncthreads();
 
@@ -141,14 +148,13 @@ __global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 
         for (int tap = 0; tap < 25; ++tap) {
-            const bool more = tap + 1 < 25;
-            bf16x8 nx0 = wbuf[0], nx1 = nx0;
-            if (more) {
-                const bf16x8* src = kw + (long long)((tap + 1) * 2 + cg) * LR_SLAB;
-                nx0 = src[tid];
-                nx1 = src[tid + 256];
+            bf16x8 ny0 = nx0, ny1 = nx1;          // slab of tap + 2
+            if (tap + 2 < 25) {
+                const bf16x8* src = kw + (long long)((tap + 2) * 2 + cg) * LR_SLAB;
+                ny0 = src[tid];
+                ny1 = src[tid + 256];
             }
-            const bf16x8* wl = wbuf + (tap & 1) * LR_SLAB + lane;
+            const bf16x8* wl = wbuf + (tap % 3) * LR_SLAB + lane;
             const float* kb = p.wt.kconv_b + tap * 64 + cg * 32 + 4 * half;
             f32x16 acc;
 #pragma unroll
@@ -173,11 +179,13 @@ __global__ __launch_bounds__(256) void satu_lr_kernel(const LrParams p) {
                     sacc[4 * g + i] += fmaxf(k, 0.1f * k) * xv[i];     // LeakyReLU(0.1), :228
                 }
             }
-            if (more) {
-                bf16x8* dst = wbuf + ((tap + 1) & 1) * LR_SLAB;
+            if (tap + 1 < 25) {
+                bf16x8* dst = wbuf + ((tap + 1) % 3) * LR_SLAB;
                 dst[tid] = nx0;
                 dst[tid + 256] = nx1;
             }
+            nx0 = ny0;
+            nx1 = ny1;
             __syncthreads();
         }
         sta[cg] = sacc;
@@ -260,9 +268,12 @@ struct HrParams {
     long long out_plane;         // floats between output channel planes (>= H*W)
     int ty, txw, lrh, lrw;       // HR tile rows, 32-px column tiles per workgroup, staged LR window
     float omin_x, omin_y;        // lower bound of the sampling offsets (window origin)
+    int n_table;                 // phase-table entries (n_uh * n_uw); <= HR_TABLE_LDS entries are kept in LDS
 };
 
 constexpr int HR_LDS_REC = 164;  // floats per staged record (160 used)
+constexpr int HR_TABLE_LDS = 256; // phase-table entries cached in LDS (x4: 16; x3.9: 1521 stays in global/L1)
+constexpr int HR_CONST_FLOATS = 2 * 2 * 2 * 64 * 4 + 64 + HR_TABLE_LDS * SAVSR_SATU_TABLE;   // wbe image | fusion_b | table
 
 struct Taps {
     int ty[4], tx[4];  // LR coordinates of the 4 taps (nw, ne, sw, se), clamped into the image
@@ -297,7 +308,7 @@ __device__ __forceinline__ Taps make_taps(float gxn, float gyn, float offx, floa
 
 template <bool FROM_LDS>
 __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int ly0, int lx0, const Taps& to, const Taps& ts,
-                                        const f32x4 rr, int half, int lane, bool valid, float* o) {
+                                        const f32x4 rr, int half, int lane, bool valid, float* o, const float* cst) {
     auto rec_of = [&](int ty, int tx) -> const f32x4* {
         if (FROM_LDS) return reinterpret_cast<const f32x4*>(lds + ((ty - ly0) * p.lrw + (tx - lx0)) * HR_LDS_REC);
         return reinterpret_cast<const f32x4*>(p.lrcat + ((long long)ty * p.w + tx) * REC);
@@ -328,8 +339,8 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
         const f32x4 v1 = {rn * tj[4], rn * tj[5], rn * tj[6], rn * tj[7]};
         split8v(v0, v1, bh[ks], bl[ks]);
     }
-    const bf16x8* wimg = reinterpret_cast<const bf16x8*>(p.wt.wbe_w) + lane;       // [t][ks][part][lane]
-    const f32x4* fb4 = reinterpret_cast<const f32x4*>(p.wt.fusion_b + half * 32);   // packed [half][q]
+    const bf16x8* wimg = reinterpret_cast<const bf16x8*>(cst) + lane;               // LDS copy of [t][ks][part][lane]
+    const f32x4* fb4 = reinterpret_cast<const f32x4*>(cst + 2 * 2 * 2 * 64 * 4 + half * 32);   // LDS copy of fusion_b, packed [half][q]
     const long long HW = p.out_plane;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -375,7 +386,8 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int X0 = blockIdx.x * 32 * p.txw, Y0 = blockIdx.y * p.ty;
 
-    // ---- stage the LRcat window of this tile ------------------------------------------------------
+    // ---- stage the LRcat window of this tile, the expert-MFMA A operands, the bias and the phase table -------
+    float* cst = lds + p.lrh * p.lrw * HR_LDS_REC;
     int ly0 = 0, lx0 = 0;
     if (p.lrh > 0) {
         const float by = ((p.gyn[Y0] + 1.f) / 2.f) * (float)(p.h - 1) + p.omin_y - 0.01f;
@@ -392,6 +404,15 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
                     *reinterpret_cast<const f32x4*>(p.lrcat + ((long long)gy * p.w + gx) * REC + 4 * u);
         }
     }
+    {
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wt.wbe_w);
+        for (int e = tid; e < 2 * 2 * 2 * 64; e += 256) reinterpret_cast<f32x4*>(cst)[e] = wsrc[e];
+        if (tid < 16) reinterpret_cast<f32x4*>(cst + 2 * 2 * 2 * 64 * 4)[tid] = reinterpret_cast<const f32x4*>(p.wt.fusion_b)[tid];
+        if (p.n_table <= HR_TABLE_LDS)
+            for (int e = tid; e < p.n_table * 2; e += 256)
+                reinterpret_cast<f32x4*>(cst + 2 * 2 * 2 * 64 * 4 + 64)[e] = reinterpret_cast<const f32x4*>(p.table)[e];
+    }
+    const float* tab = (p.n_table <= HR_TABLE_LDS) ? cst + 2 * 2 * 2 * 64 * 4 + 64 : nullptr;
     __syncthreads();
 
     const int ntile = p.ty * p.txw;
@@ -403,7 +424,8 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
         const int X = Xb + px;
         const bool valid = X < p.W;
         const int Xc = valid ? X : p.W - 1;
-        const float* te = p.table + ((long long)p.idx_h[Y] * p.n_uw + p.idx_w[Xc]) * SAVSR_SATU_TABLE;
+        const long long ent = ((long long)p.idx_h[Y] * p.n_uw + p.idx_w[Xc]) * SAVSR_SATU_TABLE;
+        const float* te = tab ? tab + ent : p.table + ent;
         const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
         const f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
         const float gxn = p.gxn[Xc], gyn = p.gyn[Y];
@@ -417,8 +439,8 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
             inside = inside && (unsigned)(ts.ty[k] - ly0) < (unsigned)p.lrh && (unsigned)(ts.tx[k] - lx0) < (unsigned)p.lrw;
         }
         float* o = p.out + (long long)Y * p.W + X;
-        if (__all(inside)) hr_tile<true>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o);
-        else hr_tile<false>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o);
+        if (__all(inside)) hr_tile<true>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o, cst);
+        else hr_tile<false>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o, cst);
     }
 }
 
@@ -452,7 +474,7 @@ extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x,
     }
     LrParams p;
     p.wt = *wt; p.x = x; p.st = st; p.pix = pix; p.row_px = row_px; p.h = h; p.w = w; p.lrcat = lrcat;
-    const size_t lds = LR_NPX * LR_XS * sizeof(float) + 2 * LR_SLAB * 16;
+    const size_t lds = LR_NPX * LR_XS * sizeof(float) + 3 * LR_SLAB * 16;
     dim3 grid((w + LR_TW - 1) / LR_TW, (h + LR_TH - 1) / LR_TH);
     hipLaunchKernelGGL(satu_lr_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_lr_kernel");
@@ -471,15 +493,16 @@ extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float*
     HrParams p;
     p.wt = *wt; p.lrcat = lrcat; p.h = h; p.w = w; p.table = table; p.n_uw = n_uw; p.idx_h = idx_h; p.idx_w = idx_w;
     p.gyn = gyn; p.gxn = gxn; p.H = H; p.W = W; p.out = out; p.out_plane = out_plane;
-    p.ty = 8; p.txw = 1; p.lrh = 0; p.lrw = 0; p.omin_x = 0.f; p.omin_y = 0.f;      // default: no staging, gathers from global
+    p.ty = 8; p.txw = 1; p.lrh = 0; p.lrw = 0; p.omin_x = 0.f; p.omin_y = 0.f; p.n_table = 1 << 30;      // default: no staging, gathers from global
     if (tiling) {
         if (tiling->tile_rows < 1 || tiling->tile_cols32 < 1 || tiling->lr_rows < 0 || tiling->lr_cols < 0)
             return fail_arg("satu_hr_upsample: tiling");
         p.ty = tiling->tile_rows; p.txw = tiling->tile_cols32; p.lrh = tiling->lr_rows; p.lrw = tiling->lr_cols;
         p.omin_x = tiling->off_min_x; p.omin_y = tiling->off_min_y;
+        p.n_table = tiling->table_entries > 0 ? tiling->table_entries : (1 << 30);
         if (p.lrh == 0 || p.lrw == 0) { p.lrh = 0; p.lrw = 0; }
     }
-    const size_t lds = (size_t)p.lrh * p.lrw * HR_LDS_REC * sizeof(float);
+    const size_t lds = ((size_t)p.lrh * p.lrw * HR_LDS_REC + HR_CONST_FLOATS) * sizeof(float);
     if (lds > 160 * 1024) return fail_arg("satu_hr_upsample: staged window exceeds 160 KiB of LDS");
     static bool attr_done = false;
     if (!attr_done) {

@@ -516,7 +516,7 @@ class HipEngine:
             return
         rx = float(ox.max() - ox.min())
         ry = float(oy.max() - oy.min())
-        budget = (76 * 1024) // (164 * 4)                              # records per workgroup at 2 workgroups / CU
+        budget = (78 * 1024 - 16640) // (164 * 4)                      # records per workgroup at 2 workgroups / CU (16.6 KB of constants)
         best = None
         for tcols in (1, 2, 4):
             for trows in (1, 2, 4, 6, 8, 12, 16, 24, 32):
@@ -529,12 +529,15 @@ class HipEngine:
                 cand = (hr_px >= 256, -amp, hr_px)                     # enough work per workgroup first, then least re-staging
                 if best is None or cand > best[0]:
                     best = (cand, trows, tcols, lr_r, lr_c)
-        if best is None:
-            ent["tiling"] = None
-            return
         t = SatuTiling()
+        if best is None:                                               # no window fits: gathers go to global memory
+            t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = 8, 1, 0, 0
+            t.off_min_x, t.off_min_y, t.table_entries = 0.0, 0.0, ent["n_uh"] * ent["n_uw"]
+            ent["tiling"] = t
+            return
         t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = best[1], best[2], min(best[3], h), min(best[4], w)
         t.off_min_x, t.off_min_y = float(ox.min()), float(oy.min())
+        t.table_entries = ent["n_uh"] * ent["n_uw"]
         ent["tiling"] = t
 
     @staticmethod
