@@ -218,6 +218,9 @@ int savsr_tail_residual(const float* feat, int64_t feat_plane, const float* tail
  * first K phase, after the K loop, after the stores drained, s_memrealtime at entry. */
 int savsr_debug_conv_stamps(int enable);
 int savsr_debug_read_conv_stamps(long long* host, int nblocks);
+/* SATU LR / HR kernels: [blk][8] accumulated section times of wave 0 (see satu.hip), last = total. */
+int savsr_debug_satu_stamps(int enable);
+int savsr_debug_read_satu_stamps(long long* host, int nblocks);
 
 #ifdef __cplusplus
 }

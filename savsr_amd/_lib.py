@@ -88,6 +88,8 @@ SIGNATURES = {
     "savsr_satu_hr_upsample": (C.c_int, [C.POINTER(SatuWeights), fptr, C.c_int, C.c_int, fptr, C.c_int, fptr, fptr,
                                          fptr, fptr, C.c_int, C.c_int, C.POINTER(SatuTiling), fptr, C.c_int64, C.c_void_p]),
     "savsr_debug_conv_stamps": (C.c_int, [C.c_int]),
+    "savsr_debug_satu_stamps": (C.c_int, [C.c_int]),
+    "savsr_debug_read_satu_stamps": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
     "savsr_debug_read_conv_stamps": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
     "savsr_tail_residual": (C.c_int, [fptr, C.c_int64, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
 }

@@ -23,6 +23,13 @@ namespace savsr {
 
 constexpr int REC = SAVSR_SATU_LRCAT;      // 160
 
+// Diagnostics (never used by the product path): accumulated s_memtime deltas of kernel sections, written by
+// wave 0 of each workgroup when enabled with savsr_debug_satu_stamps(1).
+constexpr int SSTAMP_BLOCKS = 2048, SSTAMP_N = 8;
+__device__ long long g_satu_stamps[SSTAMP_BLOCKS * SSTAMP_N];
+__device__ int g_satu_stamps_on = 0;
+#define SATU_T() ((long long)__builtin_amdgcn_s_memtime())
+
 // ------------------------------------------------------------------------------------------
 // Phase table: one wave per distinct (coor_h, coor_w) pair; lane j owns hidden unit j.
 // savsr_arch.py:335-350 (body, offset, st_offset, routing).
@@ -98,6 +105,7 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xt = smem;                                                   // [288][36]
     bf16x8* wbuf = reinterpret_cast<bf16x8*>(smem + LR_NPX * LR_XS);    // [3][LR_SLAB]
+    float* kbl = smem + LR_NPX * LR_XS + 3 * LR_SLAB * 4;               // [25][64] kernel_conv bias
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int x0 = blockIdx.x * LR_TW, y0 = blockIdx.y * LR_TH;
@@ -105,6 +113,12 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
     const bool valid = gy < p.h && gx < p.w;
     const int cy = gy < p.h ? gy : p.h - 1, cx = gx < p.w ? gx : p.w - 1;
     const long long cpix = ((long long)cy * p.row_px + cx) * p.pix + 8 * half;
+
+    const int stamps_on = __builtin_amdgcn_readfirstlane(g_satu_stamps_on);
+    long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_prev = stamps_on ? SATU_T() : 0;
+    const long long t_begin = t_prev;
+#define LR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     // B operand of the kernel-prediction GEMM: st[16 ks + 8 half + j][pixel], resident for all 50 tiles
     bf16x8 sth[4], stl[4];
@@ -114,20 +128,31 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
         split8v(g[0], g[1], sth[ks], stl[ks]);
     }
     const bf16x8* kw = reinterpret_cast<const bf16x8*>(p.wt.kconv_w);
+    for (int e = tid; e < 25 * 64 / 4; e += 256) reinterpret_cast<f32x4*>(kbl)[e] = reinterpret_cast<const f32x4*>(p.wt.kconv_b)[e];
 
     f32x16 sta[2];
 #pragma unroll
     for (int cg = 0; cg < 2; ++cg) {
         __syncthreads();                    // previous group's readers are done with xt / wbuf
-        // replicate-padded x tile of this channel group (F.pad replicate, :302)
-        for (int e = tid; e < LR_NPX * 8; e += 256) {
-            const int pl = e >> 3, c4 = e & 7;
-            const int r = pl / LR_XC, c = pl - r * LR_XC;
-            int sy = y0 - LR_HALO + r, sx = x0 - LR_HALO + c;
-            sy = sy < 0 ? 0 : (sy > p.h - 1 ? p.h - 1 : sy);
-            sx = sx < 0 ? 0 : (sx > p.w - 1 ? p.w - 1 : sx);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + ((long long)sy * p.row_px + sx) * p.pix + 32 * cg + 4 * c4);
-            *reinterpret_cast<f32x4*>(xt + pl * LR_XS + 4 * c4) = v;
+        // replicate-padded x tile of this channel group (F.pad replicate, :302): all 9 loads of a thread in
+        // flight before the first LDS write (a load->store loop exposes 9 global latencies: 14 k cycles measured)
+        {
+            f32x4 xv[LR_NPX * 8 / 256];
+#pragma unroll
+            for (int i = 0; i < LR_NPX * 8 / 256; ++i) {
+                const int e = tid + i * 256;
+                const int pl = e >> 3, c4 = e & 7;
+                const int r = pl / LR_XC, c = pl - r * LR_XC;
+                int sy = y0 - LR_HALO + r, sx = x0 - LR_HALO + c;
+                sy = sy < 0 ? 0 : (sy > p.h - 1 ? p.h - 1 : sy);
+                sx = sx < 0 ? 0 : (sx > p.w - 1 ? p.w - 1 : sx);
+                xv[i] = *reinterpret_cast<const f32x4*>(p.x + ((long long)sy * p.row_px + sx) * p.pix + 32 * cg + 4 * c4);
+            }
+#pragma unroll
+            for (int i = 0; i < LR_NPX * 8 / 256; ++i) {
+                const int e = tid + i * 256;
+                *reinterpret_cast<f32x4*>(xt + (e >> 3) * LR_XS + 4 * (e & 7)) = xv[i];
+            }
         }
         // weight slabs: 3-deep LDS ring, global loads issued two taps ahead of their use
         {
@@ -135,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
             wbuf[tid] = src[tid];
             wbuf[tid + 256] = src[tid + 256];
         }
+        LR_MARK(0);                               // prologue: st fragments / x tile / first slab
         bf16x8 nx0, nx1;                          // slab of tap + 1, in flight
         {
             const bf16x8* src = kw + (long long)(1 * 2 + cg) * LR_SLAB;
@@ -155,19 +181,22 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
                 ny1 = src[tid + 256];
             }
             const bf16x8* wl = wbuf + (tap % 3) * LR_SLAB + lane;
-            const float* kb = p.wt.kconv_b + tap * 64 + cg * 32 + 4 * half;
+            const float* kb = kbl + tap * 64 + cg * 32 + 4 * half;
             f32x16 acc;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {            // bias as the initial accumulator
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + 8 * g);
                 acc[4 * g + 0] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
             }
+            LR_MARK(1);                                // slab load issue + bias load
             bf16x8 ah[4], al[4];                       // all 8 A fragments of the tap in flight before the first MFMA
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { ah[ks] = wl[(ks * 2 + 0) * 64]; al[ks] = wl[(ks * 2 + 1) * 64]; }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) acc = mma3(ah[ks], al[ks], sth[ks], stl[ks], acc);
+            if (stamps_on) { asm volatile("" :: "v"(acc[0])); }
+            LR_MARK(2);                                // fragment reads + 12 MFMAs
             const int ky = tap / 5, kx = tap - ky * 5;
             const float* xp = xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half;
 #pragma unroll
@@ -179,6 +208,8 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
                     sacc[4 * g + i] += fmaxf(k, 0.1f * k) * xv[i];     // LeakyReLU(0.1), :228
                 }
             }
+            if (stamps_on) { asm volatile("" :: "v"(sacc[0])); }
+            LR_MARK(3);                                // LeakyReLU * x accumulate
             if (tap + 1 < 25) {
                 bf16x8* dst = wbuf + ((tap + 1) % 3) * LR_SLAB;
                 dst[tid] = nx0;
@@ -186,7 +217,9 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
             }
             nx0 = ny0;
             nx1 = ny1;
+            LR_MARK(4);                                // wait for the next slab + LDS write
             __syncthreads();
+            LR_MARK(5);                                // barrier
         }
         sta[cg] = sacc;
     }
@@ -221,6 +254,14 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
         for (int t = 0; t < 2; ++t)
             accB[t] = mma3(pb[((t * 4 + ks) * 2 + 0) * 64], pb[((t * 4 + ks) * 2 + 1) * 64], xh, xl, accB[t]);
         accC = mma3(pc[(ks * 2 + 0) * 64], pc[(ks * 2 + 1) * 64], xh, xl, accC);
+    }
+    LR_MARK(6);                                        // projections
+    if (stamps_on && tid == 0) {
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        if (b < SSTAMP_BLOCKS) {
+            for (int i = 0; i < 7; ++i) g_satu_stamps[b * SSTAMP_N + i] = tacc[i];
+            g_satu_stamps[b * SSTAMP_N + 7] = SATU_T() - t_begin;
+        }
     }
     if (!valid) return;
     float* recf = p.lrcat + ((long long)gy * p.w + gx) * REC;
@@ -273,7 +314,8 @@ struct HrParams {
 
 constexpr int HR_LDS_REC = 164;  // floats per staged record (160 used)
 constexpr int HR_TABLE_LDS = 256; // phase-table entries cached in LDS (x4: 16; x3.9: 1521 stays in global/L1)
-constexpr int HR_CONST_FLOATS = 2 * 2 * 2 * 64 * 4 + 64 + HR_TABLE_LDS * SAVSR_SATU_TABLE;   // wbe image | fusion_b | table
+constexpr int HR_MAX_ROWS = 64;
+constexpr int HR_CONST_FLOATS = 2 * 2 * 2 * 64 * 4 + 64 + HR_TABLE_LDS * SAVSR_SATU_TABLE + 2 * HR_MAX_ROWS;   // wbe image | fusion_b | table | row idx, gyn
 
 struct Taps {
     int ty[4], tx[4];  // LR coordinates of the 4 taps (nw, ne, sw, se), clamped into the image
@@ -413,8 +455,19 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
                 reinterpret_cast<f32x4*>(cst + 2 * 2 * 2 * 64 * 4 + 64)[e] = reinterpret_cast<const f32x4*>(p.table)[e];
     }
     const float* tab = (p.n_table <= HR_TABLE_LDS) ? cst + 2 * 2 * 2 * 64 * 4 + 64 : nullptr;
+    float* rowc = cst + 2 * 2 * 2 * 64 * 4 + 64 + HR_TABLE_LDS * SAVSR_SATU_TABLE;     // [ty] table row index (as int bits) | [ty] gyn
+    if (tid < p.ty) {
+        const int Yc = Y0 + tid < p.H ? Y0 + tid : p.H - 1;
+        rowc[tid] = __int_as_float(p.idx_h[Yc]);
+        rowc[HR_MAX_ROWS + tid] = p.gyn[Yc];
+    }
     __syncthreads();
 
+    const int stamps_on = __builtin_amdgcn_readfirstlane(g_satu_stamps_on);
+    long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_prev = stamps_on ? SATU_T() : 0;
+    const long long t_begin = t_prev;
+#define HR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
     const int ntile = p.ty * p.txw;
     for (int T = wave; T < ntile; T += 4) {
         const int trow = T / p.txw;
@@ -424,13 +477,17 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
         const int X = Xb + px;
         const bool valid = X < p.W;
         const int Xc = valid ? X : p.W - 1;
-        const long long ent = ((long long)p.idx_h[Y] * p.n_uw + p.idx_w[Xc]) * SAVSR_SATU_TABLE;
+        const long long ent = ((long long)__float_as_int(rowc[trow]) * p.n_uw + p.idx_w[Xc]) * SAVSR_SATU_TABLE;
         const float* te = tab ? tab + ent : p.table + ent;
         const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
         const f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
-        const float gxn = p.gxn[Xc], gyn = p.gyn[Y];
+        const float gxn = p.gxn[Xc], gyn = rowc[HR_MAX_ROWS + trow];
+        if (stamps_on) { asm volatile("" :: "v"(rr[0]), "v"(oo[0])); }
+        HR_MARK(0);                                                  // table lookup
         const Taps to = make_taps(gxn, gyn, oo[0], oo[1], p.h, p.w);
         const Taps ts = make_taps(gxn, gyn, oo[2], oo[3], p.h, p.w);
+        if (stamps_on) { asm volatile("" :: "v"(to.wgt[3]), "v"(ts.wgt[3])); }
+        HR_MARK(1);                                                  // tap arithmetic
 
         bool inside = p.lrh > 0;
 #pragma unroll
@@ -441,12 +498,35 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
         float* o = p.out + (long long)Y * p.W + X;
         if (__all(inside)) hr_tile<true>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o, cst);
         else hr_tile<false>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o, cst);
+        HR_MARK(2);                                                  // gathers + MFMA + store issue
+    }
+    if (stamps_on) {
+        __builtin_amdgcn_s_waitcnt(0);
+        HR_MARK(3);                                                  // store drain
+        if (tid == 0) {
+            const int b = blockIdx.x + gridDim.x * blockIdx.y;
+            if (b < SSTAMP_BLOCKS) {
+                for (int i = 0; i < 7; ++i) g_satu_stamps[b * SSTAMP_N + i] = tacc[i];
+                g_satu_stamps[b * SSTAMP_N + 7] = SATU_T() - t_begin;
+            }
+        }
     }
 }
 
 }  // namespace savsr
 
 using namespace savsr;
+
+extern "C" int savsr_debug_satu_stamps(int enable) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_satu_stamps_on), &enable, sizeof(int));
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int savsr_debug_read_satu_stamps(long long* host, int nblocks) {
+    if (!host || nblocks < 1 || nblocks > SSTAMP_BLOCKS) return fail_arg("debug_read_satu_stamps");
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_satu_stamps), sizeof(long long) * SSTAMP_N * nblocks);
+    return e == hipSuccess ? 0 : (int)e;
+}
 
 static bool satu_weights_ok(const savsr_satu_weights* w) {
     return w && w->body0_w && w->body0_b && w->body2_w && w->body2_b && w->head_w && w->head_b && w->kconv_w && w->kconv_b &&
@@ -474,7 +554,7 @@ extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x,
     }
     LrParams p;
     p.wt = *wt; p.x = x; p.st = st; p.pix = pix; p.row_px = row_px; p.h = h; p.w = w; p.lrcat = lrcat;
-    const size_t lds = LR_NPX * LR_XS * sizeof(float) + 3 * LR_SLAB * 16;
+    const size_t lds = LR_NPX * LR_XS * sizeof(float) + 3 * LR_SLAB * 16 + 25 * 64 * sizeof(float);
     dim3 grid((w + LR_TW - 1) / LR_TW, (h + LR_TH - 1) / LR_TH);
     hipLaunchKernelGGL(satu_lr_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_lr_kernel");
@@ -495,7 +575,7 @@ extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float*
     p.gyn = gyn; p.gxn = gxn; p.H = H; p.W = W; p.out = out; p.out_plane = out_plane;
     p.ty = 8; p.txw = 1; p.lrh = 0; p.lrw = 0; p.omin_x = 0.f; p.omin_y = 0.f; p.n_table = 1 << 30;      // default: no staging, gathers from global
     if (tiling) {
-        if (tiling->tile_rows < 1 || tiling->tile_cols32 < 1 || tiling->lr_rows < 0 || tiling->lr_cols < 0)
+        if (tiling->tile_rows < 1 || tiling->tile_rows > HR_MAX_ROWS || tiling->tile_cols32 < 1 || tiling->lr_rows < 0 || tiling->lr_cols < 0)
             return fail_arg("satu_hr_upsample: tiling");
         p.ty = tiling->tile_rows; p.txw = tiling->tile_cols32; p.lrh = tiling->lr_rows; p.lrw = tiling->lr_cols;
         p.omin_x = tiling->off_min_x; p.omin_y = tiling->off_min_y;

@@ -516,7 +516,7 @@ class HipEngine:
             return
         rx = float(ox.max() - ox.min())
         ry = float(oy.max() - oy.min())
-        budget = (78 * 1024 - 16640) // (164 * 4)                      # records per workgroup at 2 workgroups / CU (16.6 KB of constants)
+        budget = (78 * 1024 - 17152) // (164 * 4)                      # records per workgroup at 2 workgroups / CU (16.6 KB of constants)
         best = None
         for tcols in (1, 2, 4):
             for trows in (1, 2, 4, 6, 8, 12, 16, 24, 32):

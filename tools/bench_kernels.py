@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--h", type=int, default=180)
     ap.add_argument("--w", type=int, default=320)
-    ap.add_argument("--stamps", action="store_true", help="conv only: print per-workgroup phase timings (s_memtime)")
+    ap.add_argument("--stamps", action="store_true", help="conv / satu: print per-workgroup section timings (s_memtime)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     eng = E.HipEngine(synth.synth_state_dict(), SAVSR().cfg, dev)
@@ -85,6 +85,29 @@ def main():
               tuple(np.median(d, axis=0).tolist() + [np.median(st[:, 4] - st[:, 0])]))
         rt = st[:, 5]
         print("workgroup start spread (100 MHz ticks): min %d max %d -> %.2f us" % (rt.min(), rt.max(), (rt.max() - rt.min()) / 100.0))
+    if a.stamps and a.what == "satu":
+        import ctypes as C
+        import numpy as np
+        from savsr_amd import _lib
+        sw = C.byref(eng.satu_w)
+        ax = eng.satu_axes(h, w, (4, 4))
+        lrcat = eng.buf("satu.lrcat", h, w, _lib.SATU_LRCAT)
+        for name, call, nb in (
+            ("LR", lambda: eng.lib.savsr_satu_lr_stage(sw, x.data_ptr(), st.data_ptr(), 64, w, h, w, lrcat.data_ptr(), eng._stream()), ((w + 31) // 32) * ((h + 3) // 4)),
+            ("HR", lambda: eng.lib.savsr_satu_hr_upsample(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
+                                                          ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), H, W, C.byref(ax["tiling"]), out.data_ptr(), plane, eng._stream()),
+             ((W + 31) // 32) * ((H + ax["tiling"].tile_rows - 1) // ax["tiling"].tile_rows))):
+            eng.lib.savsr_debug_satu_stamps(1)
+            call()
+            torch.cuda.synchronize()
+            nb = min(nb, 2048)
+            buf = (C.c_longlong * (8 * nb))()
+            eng.lib.savsr_debug_read_satu_stamps(buf, nb)
+            eng.lib.savsr_debug_satu_stamps(0)
+            stt = np.array(buf[:], dtype=np.int64).reshape(nb, 8)
+            print(name, "section cycles (median over workgroups, wave 0):", np.median(stt, axis=0).astype(int).tolist())
+        t = ax["tiling"]
+        print("HR tiling: rows", t.tile_rows, "cols32", t.tile_cols32, "window", t.lr_rows, "x", t.lr_cols)
     print(f"{a.what} cin={a.cin} cout={a.cout} ks={a.ks} {h}x{w}: {us:.2f} us/iter" + (f"  {flop / us / 1e6:.1f} TFLOP/s fp32-equivalent" if flop else ""))
 
 
