@@ -161,11 +161,12 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
             wbuf[tid + 256] = src[tid + 256];
         }
         LR_MARK(0);                               // prologue: st fragments / x tile / first slab
-        bf16x8 nx0, nx1;                          // slab of tap + 1, in flight
+        // register sets for the slabs in flight: set A holds odd taps, set B even taps (static names: no copies)
+        bf16x8 ra0, ra1, rb0 = wbuf[0], rb1 = rb0;
         {
             const bf16x8* src = kw + (long long)(1 * 2 + cg) * LR_SLAB;
-            nx0 = src[tid];
-            nx1 = src[tid + 256];
+            ra0 = src[tid];
+            ra1 = src[tid + 256];
         }
         __syncthreads();
 
@@ -173,12 +174,12 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 
-        for (int tap = 0; tap < 25; ++tap) {
-            bf16x8 ny0 = nx0, ny1 = nx1;          // slab of tap + 2
+        auto tap_body = [&](int tap, bf16x8& ld0, bf16x8& ld1, const bf16x8& st0, const bf16x8& st1) {
+            // ld*: destination of the load for tap + 2; st*: slab of tap + 1 (loaded one iteration ago) to store
             if (tap + 2 < 25) {
                 const bf16x8* src = kw + (long long)((tap + 2) * 2 + cg) * LR_SLAB;
-                ny0 = src[tid];
-                ny1 = src[tid + 256];
+                ld0 = src[tid];
+                ld1 = src[tid + 256];
             }
             const bf16x8* wl = wbuf + (tap % 3) * LR_SLAB + lane;
             const float* kb = kbl + tap * 64 + cg * 32 + 4 * half;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + 8 * g);
                 acc[4 * g + 0] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
             }
-            LR_MARK(1);                                // slab load issue + bias load
+            LR_MARK(1);                                // slab load issue + bias
             bf16x8 ah[4], al[4];                       // all 8 A fragments of the tap in flight before the first MFMA
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { ah[ks] = wl[(ks * 2 + 0) * 64]; al[ks] = wl[(ks * 2 + 1) * 64]; }
@@ -212,15 +213,18 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
             LR_MARK(3);                                // LeakyReLU * x accumulate
             if (tap + 1 < 25) {
                 bf16x8* dst = wbuf + ((tap + 1) % 3) * LR_SLAB;
-                dst[tid] = nx0;
-                dst[tid + 256] = nx1;
+                dst[tid] = st0;
+                dst[tid + 256] = st1;
             }
-            nx0 = ny0;
-            nx1 = ny1;
             LR_MARK(4);                                // wait for the next slab + LDS write
             __syncthreads();
             LR_MARK(5);                                // barrier
+        };
+        for (int tap = 0; tap < 24; tap += 2) {
+            tap_body(tap, rb0, rb1, ra0, ra1);         // even tap: load tap+2 into B, store A (= tap+1)
+            tap_body(tap + 1, ra0, ra1, rb0, rb1);     // odd tap: load tap+2 into A, store B
         }
+        tap_body(24, rb0, rb1, ra0, ra1);
         sta[cg] = sacc;
     }
 
@@ -469,6 +473,10 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
     const long long t_begin = t_prev;
 #define HR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
     const int ntile = p.ty * p.txw;
+    // per-lane column constants of the first column tile (the only one when txw == 1)
+    const int Xc0 = (X0 + px < p.W) ? X0 + px : p.W - 1;
+    const int iw0 = p.idx_w[Xc0];
+    const float gxn0 = p.gxn[Xc0];
     for (int T = wave; T < ntile; T += 4) {
         const int trow = T / p.txw;
         const int Y = Y0 + trow;
@@ -477,11 +485,13 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
         const int X = Xb + px;
         const bool valid = X < p.W;
         const int Xc = valid ? X : p.W - 1;
-        const long long ent = ((long long)__float_as_int(rowc[trow]) * p.n_uw + p.idx_w[Xc]) * SAVSR_SATU_TABLE;
+        const bool col0 = Xb == X0;                                   // wave-uniform
+        const int iw = col0 ? iw0 : p.idx_w[Xc];
+        const long long ent = ((long long)__float_as_int(rowc[trow]) * p.n_uw + iw) * SAVSR_SATU_TABLE;
         const float* te = tab ? tab + ent : p.table + ent;
         const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
         const f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
-        const float gxn = p.gxn[Xc], gyn = rowc[HR_MAX_ROWS + trow];
+        const float gxn = col0 ? gxn0 : p.gxn[Xc], gyn = rowc[HR_MAX_ROWS + trow];
         if (stamps_on) { asm volatile("" :: "v"(rr[0]), "v"(oo[0])); }
         HR_MARK(0);                                                  // table lookup
         const Taps to = make_taps(gxn, gyn, oo[0], oo[1], p.h, p.w);
