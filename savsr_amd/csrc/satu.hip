@@ -440,14 +440,29 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
         const float bx = ((p.gxn[X0 < p.W ? X0 : p.W - 1] + 1.f) / 2.f) * (float)(p.w - 1) + p.omin_x - 0.01f;
         ly0 = (int)floorf(fminf(fmaxf(by, 0.f), (float)(p.h - 1)));
         lx0 = (int)floorf(fminf(fmaxf(bx, 0.f), (float)(p.w - 1)));
+        // six 16-B loads per thread in flight before their LDS writes (a load -> store loop pays one global
+        // latency per iteration: the staging used to be half of this kernel's time)
         const int nunit = p.lrh * p.lrw * (REC / 4);
-        for (int e = tid; e < nunit; e += 256) {
-            const int r = e / (REC / 4), u = e - r * (REC / 4);
-            const int ry = r / p.lrw, rx = r - ry * p.lrw;
-            const int gy = ly0 + ry, gx = lx0 + rx;
-            if (gy < p.h && gx < p.w)
-                *reinterpret_cast<f32x4*>(lds + r * HR_LDS_REC + 4 * u) =
-                    *reinterpret_cast<const f32x4*>(p.lrcat + ((long long)gy * p.w + gx) * REC + 4 * u);
+        for (int base = 0; base < nunit; base += 256 * 6) {
+            f32x4 v[6];
+            int dst[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int e = base + tid + i * 256;
+                dst[i] = -1;
+                if (e < nunit) {
+                    const int r = e / (REC / 4), u = e - r * (REC / 4);
+                    const int ry = r / p.lrw, rx = r - ry * p.lrw;
+                    const int gy = ly0 + ry, gx = lx0 + rx;
+                    if (gy < p.h && gx < p.w) {
+                        v[i] = *reinterpret_cast<const f32x4*>(p.lrcat + ((long long)gy * p.w + gx) * REC + 4 * u);
+                        dst[i] = r * HR_LDS_REC + 4 * u;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (dst[i] >= 0) *reinterpret_cast<f32x4*>(lds + dst[i]) = v[i];
         }
     }
     {

@@ -37,23 +37,41 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ fea
     for (int c0 = 0; c0 < 64; c0 += TL_CH) {
         __syncthreads();
         if (vec) {
-            // per (channel, row): 8 float4 interior + 2 halo scalars = 10 items
-            for (int e = tid; e < TL_CH * TL_R * 10; e += 256) {
-                const int cr = e / 10, it = e - cr * 10;
+            // interior: 16 ch x 18 rows x 8 float4 = 9 per thread, all in flight before the first LDS write
+            // (a load -> store loop exposes one global latency per iteration); halos: 576 scalars
+            f32x4 v4[9];
+            float hv[3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int e = tid + i * 256;
+                const int cr = e >> 3, it = e & 7;
                 const int ch = cr / TL_R, r = cr - ch * TL_R;
                 const int gy = Y0 - 1 + r;
-                const bool rowok = gy >= 0 && gy < H;
-                const float* src = feat + (long long)(c0 + ch) * FP + (long long)gy * W + X0;
-                float* dst = tile + (ch * TL_R + r) * TL_S;
-                if (it < 8) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (rowok) v = *reinterpret_cast<const f32x4*>(src + 4 * it);
-                    *reinterpret_cast<f32x4*>(dst + 4 + 4 * it) = v;
-                } else if (it == 8) {
-                    dst[3] = (rowok && X0 > 0) ? src[-1] : 0.f;
-                } else {
-                    dst[36] = (rowok && X0 + TL_TW < W) ? src[TL_TW] : 0.f;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < H) v = *reinterpret_cast<const f32x4*>(feat + (long long)(c0 + ch) * FP + (long long)gy * W + X0 + 4 * it);
+                v4[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int e = tid + i * 256;
+                float v = 0.f;
+                if (e < TL_CH * TL_R * 2) {
+                    const int cr = e >> 1, side = e & 1;
+                    const int ch = cr / TL_R, r = cr - ch * TL_R;
+                    const int gy = Y0 - 1 + r, gx = side ? X0 + TL_TW : X0 - 1;
+                    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = feat[(long long)(c0 + ch) * FP + (long long)gy * W + gx];
                 }
+                hv[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int e = tid + i * 256;
+                *reinterpret_cast<f32x4*>(tile + (e >> 3) * TL_S + 4 + 4 * (e & 7)) = v4[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int e = tid + i * 256;
+                if (e < TL_CH * TL_R * 2) tile[(e >> 1) * TL_S + ((e & 1) ? 36 : 3)] = hv[i];
             }
         } else {
             for (int e = tid; e < TL_CH * TL_R * 34; e += 256) {
