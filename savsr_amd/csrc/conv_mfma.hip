@@ -74,9 +74,11 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi,
     }
 }
 
-template <int KS, int NT, int TH, int DB>
-__global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const MultiConvParams mp) {
-    constexpr int STG = 1, NTHR = 64 * TH;
+template <int KS, int NT, int TH, int DB, int PXT>
+__global__ __launch_bounds__(64 * TH / PXT) void conv_bf16x3_kernel(const MultiConvParams mp) {
+    // TH pixel rows per workgroup, PXT rows (32-pixel tiles) per wave: the A (weight) fragments a wave reads from
+    // LDS serve PXT pixel tiles, so LDS reads per MFMA drop from 1 (PXT 1) to 2/3 (PXT 2)
+    constexpr int STG = 1, NTHR = 64 * TH / PXT;
     const ConvParams& p = mp.c[blockIdx.z / mp.ncob];
     constexpr int TAPS = KS * KS, HALO = KS / 2;
     constexpr int KC = conv_kc(KS), KSTEPS = KC / 16;
@@ -180,11 +182,13 @@ __global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const MultiConvPar
         }
     };
 
-    f32x16 acc[NT];
+    f32x16 acc[PXT][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int j = 0; j < PXT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
 
     const int stamps_on = __builtin_amdgcn_readfirstlane(g_conv_stamps_on);
     stamp(stamps_on, 0);
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const MultiConvPar
     __syncthreads();
     stamp(stamps_on, 1);
 
-    struct Frag { bf16x8 ah[NT], al[NT], bh, bl; };
+    struct Frag { bf16x8 ah[NT], al[NT], bh[PXT], bl[PXT]; };
 
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
         const int buf = DB ? (chunk & 1) : 0;
@@ -203,15 +207,18 @@ __global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const MultiConvPar
 
         const bf16x8* bl = smem + buf * B_UNITS;
         const bf16x8* wl = smem + NB * B_UNITS + buf * W_UNITS;
-        const bf16x8* bbase = bl + half * NPX + wave * IC + px;
+        const bf16x8* bbase = bl + half * NPX + (wave * PXT) * IC + px;
         const bf16x8* abase = wl + lane;
 
         auto load_frag = [&](int s, Frag& f) {
             const int tap = s / KSTEPS, ks = s - tap * KSTEPS;
             const int ky = tap / KS, kx = tap - ky * KS;
             const int bo = ks * 2 * NPX + ky * IC + kx;
-            f.bh = bbase[bo];
-            f.bl = bbase[B_PART + bo];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                f.bh[j] = bbase[bo + j * IC];
+                f.bl[j] = bbase[B_PART + bo + j * IC];
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f.ah[t] = abase[((s * NT + t) * 2 + 0) * 64];
@@ -220,11 +227,13 @@ __global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const MultiConvPar
         };
         auto mma = [&](const Frag& f) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[t], f.bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bh, acc[t], 0, 0, 0);
-            }
+            for (int j = 0; j < PXT; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[t], f.bh[j], acc[j][t], 0, 0, 0);
+                    acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bl[j], acc[j][t], 0, 0, 0);
+                    acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bh[j], acc[j][t], 0, 0, 0);
+                }
         };
         // Operand fragments run two (tap, kstep) steps ahead of their MFMAs.  hipcc (ROCm 7.2) otherwise
         // sinks every ds_read to just before its MFMA and re-uses one register quad for all A fragments
@@ -263,61 +272,61 @@ __global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const MultiConvPar
     // residual reads are coalesced the same way.  (All waves passed the K loop's last barrier,
     // so the staging buffers are free.)
     constexpr int COT = 32 * NT, EPS = COT + 4, U = COT / 4;
-    float* ep = reinterpret_cast<float*>(smem_raw) + wave * (32 * EPS);
+    float* ep = reinterpret_cast<float*>(smem_raw) + wave * (PXT * 32 * EPS);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int j = 0; j < PXT; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(ep + px * EPS + 32 * t + 8 * g + 4 * half) = v;
-        }
-    const int y = y0 + wave;
-    if (y < p.h) {
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < U / 2; ++i) {
-            const int unit = lane + 64 * i;
-            const int pl = unit / U, c4 = unit - pl * U;
-            const int x = x0 + pl, co = cob * COT + 4 * c4;
-            if (x >= p.w || co >= p.cout) continue;
-            const long long pidx = (long long)y * p.w + x;
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ep + pl * EPS + 4 * c4);
-            float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-            const bool full = co + 3 < p.cout;
-            const float mul = p.mul_px ? p.mul_px[pidx] : 1.f;
-            if (p.bias) {
-                if (full) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
-                    v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
-                } else {
-                    for (int j = 0; j < 4 && co + j < p.cout; ++j) v[j] += p.bias[co + j];
-                }
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[j][t][4 * g], acc[j][t][4 * g + 1], acc[j][t][4 * g + 2], acc[j][t][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(ep + (j * 32 + px) * EPS + 32 * t + 8 * g + 4 * half) = v;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (p.act == SAVSR_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-                else if (p.act == SAVSR_ACT_LRELU) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
-                else if (p.act == SAVSR_ACT_SIGMOID) v[j] = sigmoidf_(v[j]);
-                v[j] *= mul;
-            }
-            float* o = p.out + pidx * p.out_pix + co;
+    for (int i = 0; i < PXT * U / 2; ++i) {
+        const int unit = lane + 64 * i;
+        const int pl = unit / U, c4 = unit - pl * U;          // pl = row-in-wave * 32 + column
+        const int y = y0 + wave * PXT + (pl >> 5);
+        const int x = x0 + (pl & 31), co = cob * COT + 4 * c4;
+        if (y >= p.h || x >= p.w || co >= p.cout) continue;
+        const long long pidx = (long long)y * p.w + x;
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ep + pl * EPS + 4 * c4);
+        float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+        const bool full = co + 3 < p.cout;
+        const float mul = p.mul_px ? p.mul_px[pidx] : 1.f;
+        if (p.bias) {
             if (full) {
-                if (p.res1) {
-                    const f32x4 r = *reinterpret_cast<const f32x4*>(p.res1 + pidx * p.res1_pix + co);
-                    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
-                }
-                if (p.res2) {
-                    const f32x4 r = *reinterpret_cast<const f32x4*>(p.res2 + pidx * p.res2_pix + co);
-                    v[0] += p.res2_scale * r[0]; v[1] += p.res2_scale * r[1]; v[2] += p.res2_scale * r[2]; v[3] += p.res2_scale * r[3];
-                }
-                const f32x4 ov = {v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(o) = ov;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+                v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
             } else {
-                for (int j = 0; j < 4 && co + j < p.cout; ++j) {
-                    float vv = v[j];
-                    if (p.res1) vv += p.res1[pidx * p.res1_pix + co + j];
-                    if (p.res2) vv += p.res2_scale * p.res2[pidx * p.res2_pix + co + j];
-                    o[j] = vv;
-                }
+                for (int q = 0; q < 4 && co + q < p.cout; ++q) v[q] += p.bias[co + q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (p.act == SAVSR_ACT_RELU) v[q] = fmaxf(v[q], 0.f);
+            else if (p.act == SAVSR_ACT_LRELU) v[q] = v[q] > 0.f ? v[q] : v[q] * p.slope;
+            else if (p.act == SAVSR_ACT_SIGMOID) v[q] = sigmoidf_(v[q]);
+            v[q] *= mul;
+        }
+        float* o = p.out + pidx * p.out_pix + co;
+        if (full) {
+            if (p.res1) {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(p.res1 + pidx * p.res1_pix + co);
+                v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+            }
+            if (p.res2) {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(p.res2 + pidx * p.res2_pix + co);
+                v[0] += p.res2_scale * r[0]; v[1] += p.res2_scale * r[1]; v[2] += p.res2_scale * r[2]; v[3] += p.res2_scale * r[3];
+            }
+            const f32x4 ov = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(o) = ov;
+        } else {
+            for (int q = 0; q < 4 && co + q < p.cout; ++q) {
+                float vv = v[q];
+                if (p.res1) vv += p.res1[pidx * p.res1_pix + co + q];
+                if (p.res2) vv += p.res2_scale * p.res2[pidx * p.res2_pix + co + q];
+                o[q] = vv;
             }
         }
     }
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(64 * TH) void conv_bf16x3_kernel(const MultiConvPar
     }
 }
 
-template <int KS, int NT, int TH, int DB>
+template <int KS, int NT, int TH, int DB, int PXT>
 static int launch_conv_v(const MultiConvParams& mp, int nconv, hipStream_t st) {
     const ConvParams& p = mp.c[0];
     constexpr int TAPS = KS * KS, HALO = KS / 2, KC = conv_kc(KS), KSTEPS = KC / 16;
@@ -337,7 +346,7 @@ static int launch_conv_v(const MultiConvParams& mp, int nconv, hipStream_t st) {
     constexpr size_t lds = stage > epi ? stage : epi;
     static bool attr_done = false;      // benign race: idempotent attribute set
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, TH, DB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, TH, DB, PXT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("conv: hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds, hipGetErrorString(e));
@@ -346,25 +355,32 @@ static int launch_conv_v(const MultiConvParams& mp, int nconv, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid((p.w + CONV_TW - 1) / CONV_TW, (p.h + TH - 1) / TH, mp.ncob * nconv);
-    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, TH, DB>), grid, dim3(64 * TH), lds, st, mp);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, TH, DB, PXT>), grid, dim3(64 * TH / PXT), lds, st, mp);
     return check_launch("conv_bf16x3_kernel");
 }
 
-// SAVSR_CONV_VARIANT (tuning knob, read once): 0 = 8-row tiles, double-buffered staging, 1 workgroup / CU;
-// 1 = 4-row tiles, single-buffered staging, 3 workgroups / CU (default)
+// SAVSR_CONV_VARIANT (tuning knob, read once):
+//   0 = 8-row tiles, 8 waves x 1 row,  double-buffered staging, 1 workgroup / CU
+//   1 = 4-row tiles, 4 waves x 1 row,  single-buffered staging, 2-3 workgroups / CU
+//   2 = 8-row tiles, 4 waves x 2 rows, double-buffered staging, 1 workgroup / CU
+//   3 = 8-row tiles, 4 waves x 2 rows, single-buffered staging, 2 workgroups / CU
 static int conv_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("SAVSR_CONV_VARIANT");
-        v = e ? atoi(e) & 1 : 1;
+        v = e ? atoi(e) & 3 : 3;
     }
     return v;
 }
 
 template <int KS, int NT>
 static int launch_conv(const MultiConvParams& mp, int nconv, hipStream_t st) {
-    if (conv_variant() == 0) return launch_conv_v<KS, NT, 8, 1>(mp, nconv, st);
-    return launch_conv_v<KS, NT, 4, 0>(mp, nconv, st);
+    switch (conv_variant()) {
+        case 0: return launch_conv_v<KS, NT, 8, 1, 1>(mp, nconv, st);
+        case 1: return launch_conv_v<KS, NT, 4, 0, 1>(mp, nconv, st);
+        case 2: return launch_conv_v<KS, NT, 8, 1, 2>(mp, nconv, st);
+        default: return launch_conv_v<KS, NT, 8, 0, 2>(mp, nconv, st);
+    }
 }
 
 }  // namespace savsr
