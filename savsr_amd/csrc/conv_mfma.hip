@@ -62,6 +62,7 @@ constexpr int CONV_MAX_BATCH = 6;
 struct MultiConvParams {
     ConvParams c[CONV_MAX_BATCH];     // convs of identical geometry; blockIdx.z = conv * ncob + cob
     int ncob;
+    int stagger;                      // start delay (x64 cycles) per co-resident workgroup slot, 0 = off
 };
 
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
@@ -190,6 +191,14 @@ __global__ __launch_bounds__(64 * TH / PXT) void conv_bf16x3_kernel(const MultiC
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
 
+    if (mp.stagger > 0) {
+        // workgroups that share a CU start together and would run their staging / MFMA / store phases in lockstep;
+        // delaying the (k mod 3)-th dispatch round by k * stagger * 64 cycles lets one workgroup's MFMA phase overlap
+        // another's memory phases
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int slot = (lin >> 8) % 3;
+        for (int i = 0; i < slot * mp.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     const int stamps_on = __builtin_amdgcn_readfirstlane(g_conv_stamps_on);
     stamp(stamps_on, 0);
     stamp(stamps_on, 5);
@@ -368,7 +377,7 @@ static int conv_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("SAVSR_CONV_VARIANT");
-        v = e ? atoi(e) & 3 : 3;
+        v = e ? atoi(e) & 3 : 1;
     }
     return v;
 }
@@ -464,6 +473,9 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
             return fail_arg("conv: all convs of a batch must share ksize / nsrc / src_ch / h / w / cout");
     }
     for (int i = n; i < CONV_MAX_BATCH; ++i) mp.c[i] = mp.c[0];
+    static int stagger = -1;
+    if (stagger < 0) { const char* e = getenv("SAVSR_CONV_STAGGER"); stagger = e ? atoi(e) : 0; }
+    mp.stagger = stagger;
     const savsr_conv_desc* d = descs;
     const int cot = conv_cot(d->cout);
     mp.ncob = (d->cout + cot - 1) / cot;
