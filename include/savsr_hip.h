@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 6
+#define SAVSR_ABI_VERSION 7
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -85,6 +85,10 @@ typedef struct savsr_conv_desc {
     float        res2_scale;           /* gamma (savsr_arch.py:732)                              */
     float*       out;                  /* channel offset already applied */
     int32_t      out_pix;
+    float*       pool;                 /* optional: fused AdaptiveAvgPool2d(1) partials of the stored tensor,
+                                          row t (t < savsr_conv_pool_blocks(h, w)) = channel sums of pixel tile t,
+                                          written at pool[t * pool_stride + co]; consumers add rows in order */
+    int32_t      pool_stride;
 } savsr_conv_desc;
 
 /* Elements PER PART (hi or lo) of the weight image of a (cout, cin, ksize) conv; the bf16 image
@@ -95,6 +99,7 @@ int64_t savsr_conv_packed_elems(int cout, int cin, int ksize);
  * (p/512)*1024 + p%512, of the lo value (p/512)*1024 + 512 + p%512.  An fp32 kernel bank for
  * savsr_osconv_weights stores W at index p directly.  Unaddressed entries must be zero. */
 int64_t savsr_conv_pack_index(int cout, int cin, int ksize, int co, int ci, int tap);
+int savsr_conv_pool_blocks(int h, int w);
 int savsr_conv2d(const savsr_conv_desc* d, void* stream);
 /* n (1..6) independent convs of identical geometry (ksize, nsrc, src_ch, h, w, cout) in ONE launch
  * (grid.z = n * output-channel blocks): e.g. the per-stream convs of a ResidualBlock (savsr_arch.py:402,413)

@@ -43,6 +43,8 @@ struct ConvParams {
     float res2_scale;
     float* out;
     int out_pix;
+    float* pool;          // optional [tiles][pool_stride]: per-workgroup channel sums of the stored values
+    int pool_stride;
 };
 
 // Diagnostics (not used by the product path): per-workgroup s_memtime stamps of the conv kernel
@@ -62,7 +64,6 @@ constexpr int CONV_MAX_BATCH = 6;
 struct MultiConvParams {
     ConvParams c[CONV_MAX_BATCH];     // convs of identical geometry; blockIdx.z = conv * ncob + cob
     int ncob;
-    int stagger;                      // start delay (x64 cycles) per co-resident workgroup slot, 0 = off
 };
 
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
@@ -191,14 +192,6 @@ __global__ __launch_bounds__(64 * TH / PXT) void conv_bf16x3_kernel(const MultiC
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
 
-    if (mp.stagger > 0) {
-        // workgroups that share a CU start together and would run their staging / MFMA / store phases in lockstep;
-        // delaying the (k mod 3)-th dispatch round by k * stagger * 64 cycles lets one workgroup's MFMA phase overlap
-        // another's memory phases
-        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int slot = (lin >> 8) % 3;
-        for (int i = 0; i < slot * mp.stagger; ++i) __builtin_amdgcn_s_sleep(1);
-    }
     const int stamps_on = __builtin_amdgcn_readfirstlane(g_conv_stamps_on);
     stamp(stamps_on, 0);
     stamp(stamps_on, 5);
@@ -291,6 +284,7 @@ __global__ __launch_bounds__(64 * TH / PXT) void conv_bf16x3_kernel(const MultiC
                 const f32x4 v = {acc[j][t][4 * g], acc[j][t][4 * g + 1], acc[j][t][4 * g + 2], acc[j][t][4 * g + 3]};
                 *reinterpret_cast<f32x4*>(ep + (j * 32 + px) * EPS + 32 * t + 8 * g + 4 * half) = v;
             }
+    f32x4 psum = {0.f, 0.f, 0.f, 0.f};         // pooled sums: lane l always handles channel quad l % U
 #pragma unroll
     for (int i = 0; i < PXT * U / 2; ++i) {
         const int unit = lane + 64 * i;
@@ -330,6 +324,7 @@ __global__ __launch_bounds__(64 * TH / PXT) void conv_bf16x3_kernel(const MultiC
             }
             const f32x4 ov = {v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(o) = ov;
+            psum[0] += v[0]; psum[1] += v[1]; psum[2] += v[2]; psum[3] += v[3];
         } else {
             for (int q = 0; q < 4 && co + q < p.cout; ++q) {
                 float vv = v[q];
@@ -337,6 +332,28 @@ __global__ __launch_bounds__(64 * TH / PXT) void conv_bf16x3_kernel(const MultiC
                 if (p.res2) vv += p.res2_scale * p.res2[pidx * p.res2_pix + co + q];
                 o[q] = vv;
             }
+        }
+    }
+    if (p.pool) {
+        // AdaptiveAvgPool2d(1) of the tensor just produced (savsr_arch.py:146,515), fused: lanes with equal
+        // l % U hold the same channel quad -> butterfly over the 64 / U pixel groups, then the waves of the
+        // workgroup are summed in wave order through LDS (deterministic) and ONE row per workgroup is written.
+#pragma unroll
+        for (int o = U; o < 64; o <<= 1) {
+            psum[0] += __shfl_xor(psum[0], o, 64); psum[1] += __shfl_xor(psum[1], o, 64);
+            psum[2] += __shfl_xor(psum[2], o, 64); psum[3] += __shfl_xor(psum[3], o, 64);
+        }
+        __syncthreads();                         // every wave is done with its transpose slice
+        float* pl_ = reinterpret_cast<float*>(smem_raw);
+        if (lane < U) *reinterpret_cast<f32x4*>(pl_ + wave * COT + 4 * lane) = psum;
+        __syncthreads();
+        constexpr int NW = TH / PXT;
+        if (tid < COT) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) sacc += pl_[wv * COT + tid];
+            if (cob * COT + tid < p.cout)
+                p.pool[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * p.pool_stride + cob * COT + tid] = sacc;
         }
     }
     if (stamps_on) {
@@ -407,6 +424,12 @@ extern "C" int savsr_debug_read_conv_stamps(long long* host, int nblocks) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// Rows of a conv's `pool` output = pixel tiles of its launch (depends on the tile variant in use).
+extern "C" int savsr_conv_pool_blocks(int h, int w) {
+    const int th = (conv_variant() == 1) ? 4 : 8;
+    return ((w + CONV_TW - 1) / CONV_TW) * ((h + th - 1) / th);
+}
+
 extern "C" int64_t savsr_conv_packed_elems(int cout, int cin, int ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return -1;
     const int kc = conv_kc(ksize), cot = conv_cot(cout);
@@ -457,6 +480,8 @@ static int fill_params(const savsr_conv_desc* d, ConvParams& p) {
     p.mul_px = d->mul_px; p.res1 = d->res1; p.res1_pix = d->res1_pix; p.res2 = d->res2; p.res2_pix = d->res2_pix;
     p.res2_scale = d->res2_scale;
     p.out = d->out; p.out_pix = d->out_pix;
+    p.pool = d->pool; p.pool_stride = d->pool_stride;
+    if (d->pool && (d->cout % 4 || d->pool_stride < d->cout)) return fail_arg("conv: pool needs cout % 4 == 0 and pool_stride >= cout");
     return 0;
 }
 
@@ -473,9 +498,6 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
             return fail_arg("conv: all convs of a batch must share ksize / nsrc / src_ch / h / w / cout");
     }
     for (int i = n; i < CONV_MAX_BATCH; ++i) mp.c[i] = mp.c[0];
-    static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("SAVSR_CONV_STAGGER"); stagger = e ? atoi(e) : 0; }
-    mp.stagger = stagger;
     const savsr_conv_desc* d = descs;
     const int cot = conv_cot(d->cout);
     mp.ncob = (d->cout + cot - 1) / cot;

@@ -203,7 +203,6 @@ class HipEngine:
                    kn_w=g(a + ".kernel_fc.weight"), kn_b=g(a + ".kernel_fc.bias"),
                    v1=torch.empty(2 * cin, device=self.dev), v2=torch.empty(cin, device=self.dev),
                    att=torch.empty(cin + cout + 9 + knum, device=self.dev),
-                   partial=torch.empty(MAX_SUM_BLOCKS * cin, device=self.dev),
                    wdyn=torch.empty(2 * elems, device=self.dev, dtype=torch.int16))
         self.osc[key] = ent
 
@@ -319,7 +318,6 @@ class HipEngine:
         self._add_conv(sd, "conv_last")
         self.gamma = float(sd["gamma"].reshape(-1)[0])
         self._pack_satu(sd)
-        self.se_partial = torch.empty(MAX_SUM_BLOCKS * self.nf, device=self.dev)
         self.se_gate = torch.empty(self.nf, device=self.dev)
 
     # ------------------------------------------------------------------ buffers / launch helpers
@@ -342,7 +340,9 @@ class HipEngine:
         return Src(t, c_total - ch_off if ch is None else ch, c_total, ch_off)
 
     def conv_desc(self, key, srcs: List[Src], out: Src, h: int, w: int, act=ACT_NONE, slope=0.0,
-                  mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None) -> ConvDesc:
+                  mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None,
+                  pool: Optional[Tuple[torch.Tensor, int, int]] = None) -> ConvDesc:
+        """pool = (partial tensor, column offset, row stride): fused global-average-pool partials of the output."""
         wpk, bias, cout, cin, ks = weights if weights is not None else self.pw[key]
         d = ConvDesc()
         assert len(srcs) <= _lib.MAX_SRC and all(s.ch == srcs[0].ch for s in srcs)
@@ -360,6 +360,8 @@ class HipEngine:
             d.res2, d.res2_pix = res2.ptr, res2.pix
         d.res2_scale = res2_scale
         d.out, d.out_pix = out.ptr, out.pix
+        if pool is not None:
+            d.pool, d.pool_stride = pool[0].data_ptr() + 4 * pool[1], pool[2]
         return d
 
     def conv_launch(self, descs: List[ConvDesc], label: str = "conv"):
@@ -371,8 +373,8 @@ class HipEngine:
             _lib.check(self.lib.savsr_conv2d_batch(arr, len(chunk), st), f"savsr_conv2d_batch[{label}]")
 
     def conv(self, key, srcs: List[Src], out: Src, h: int, w: int, act=ACT_NONE, slope=0.0,
-             mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None):
-        d = self.conv_desc(key, srcs, out, h, w, act, slope, mul_px, res1, res2, res2_scale, weights)
+             mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None, pool=None):
+        d = self.conv_desc(key, srcs, out, h, w, act, slope, mul_px, res1, res2, res2_scale, weights, pool)
         _lib.check(self.lib.savsr_conv2d(C.byref(d), self._stream()), f"savsr_conv2d[{key}]")
         return out
 
@@ -385,15 +387,26 @@ class HipEngine:
                    "savsr_channel_sums")
         return nblk
 
-    def osconv_weights(self, key: str, srcs: List[Src], h: int, w: int, scale):
-        """Pool -> routing/attention -> aggregated split-bf16 weight image (savsr_arch.py:143-163)."""
+    def pool_rows(self, h: int, w: int) -> int:
+        return int(self.lib.savsr_conv_pool_blocks(h, w))
+
+    def pool_buf(self, key: str, h: int, w: int, cin: int) -> torch.Tensor:
+        """Partial-sum rows for a pooled tensor: one row per conv pixel tile (fused pooling) or per
+        savsr_channel_sums workgroup."""
+        return self.buf("pool." + key, max(self.pool_rows(h, w), MAX_SUM_BLOCKS) * cin)
+
+    def osconv_weights(self, key: str, srcs: List[Src], h: int, w: int, scale, pooled: bool = False):
+        """Pool -> routing/attention -> aggregated split-bf16 weight image (savsr_arch.py:143-163).
+        pooled=True: the producing convs already wrote the pool partials (fused epilogue)."""
         e = self.osc[key]
-        nblk = self.channel_sums(srcs, h * w, e["partial"])
+        partial = self.pool_buf(key, h, w, e["cin"])
+        nblk = self.pool_rows(h, w) if pooled else self.channel_sums(srcs, h * w, partial)
         d = OSConvAttnDesc()
         d.cin, d.cout, d.hidden, d.knum = e["cin"], e["cout"], e["hidden"], e["knum"]
         d.inv_sh, d.inv_sw = 1.0 / scale[0], 1.0 / scale[1]
         d.nblk, d.inv_n, d.nunits = nblk, 1.0 / (h * w), e["nunits"]
-        for k in ("partial", "l1_w", "l1_b", "l2_w", "l2_b", "fc_w", "bn_scale", "bn_shift", "ch_w", "ch_b", "fl_w", "fl_b",
+        d.partial = partial.data_ptr()
+        for k in ("l1_w", "l1_b", "l2_w", "l2_b", "fc_w", "bn_scale", "bn_shift", "ch_w", "ch_b", "fl_w", "fl_b",
                   "sp_w", "sp_b", "kn_w", "kn_b", "v1", "v2", "bank", "att"):
             setattr(d, k, e[k].data_ptr())
         d.wimg_out = e["wdyn"].data_ptr()
@@ -409,15 +422,18 @@ class HipEngine:
         L = ACT_LRELU
         x1s, d0 = [], []
         for pfx, xs, tag in groups:
-            x1 = [self.full(self.buf(f"{tag}.x1.{i}", hp, wp, nf)) for i in range(len(xs))]
-            d0 += [self.conv_desc(f"{pfx}.conv0.{i}", [xs[i]], x1[i], hp, wp, L, 0.2) for i in range(len(xs))]
+            n = len(xs)
+            x1 = [self.full(self.buf(f"{tag}.x1.{i}", hp, wp, nf)) for i in range(n)]
+            pb = self.pool_buf(pfx + ".osconv", hp, wp, n * nf) if use_osconv else None     # OSConv pools cat(x1) (:146)
+            d0 += [self.conv_desc(f"{pfx}.conv0.{i}", [xs[i]], x1[i], hp, wp, L, 0.2,
+                                  pool=(pb, i * nf, n * nf) if use_osconv else None) for i in range(n)]
             x1s.append(x1)
         self.conv_launch(d0, "conv0")
         bases, d1 = [], []
         for (pfx, xs, tag), x1 in zip(groups, x1s):
             base = self.full(self.buf(f"{tag}.base", hp, wp, nf))
             if use_osconv:
-                wd = self.osconv_weights(pfx + ".osconv", x1, hp, wp, scale)
+                wd = self.osconv_weights(pfx + ".osconv", x1, hp, wp, scale, pooled=True)
                 d1.append(self.conv_desc(pfx + ".osconv", x1, base, hp, wp, L, 0.2, weights=wd))
             else:
                 d1.append(self.conv_desc(pfx + ".conv1", x1, base, hp, wp, L, 0.2))
@@ -451,19 +467,21 @@ class HipEngine:
         """savsr_arch.py:527-549."""
         nf = self.nf
         r1 = self.conv(pfx + ".0", [x], self.full(self.buf(f"{tag}.t1", hp, wp, nf)), hp, wp, ACT_RELU)
-        r2 = self.conv(pfx + ".2", [r1], self.full(self.buf(f"{tag}.t2", hp, wp, nf)), hp, wp, ACT_NONE)
-        nblk = self.channel_sums([r2], hp * wp, self.se_partial)
+        part = self.pool_buf("se", hp, wp, nf)
+        r2 = self.conv(pfx + ".2", [r1], self.full(self.buf(f"{tag}.t2", hp, wp, nf)), hp, wp, ACT_NONE, pool=(part, 0, nf))
+        nblk = self.pool_rows(hp, wp)
         w1, b1, w2, b2, cm = self.se[pfx]
         st = self._stream()
-        _lib.check(self.lib.savsr_se_gate(self.se_partial.data_ptr(), nblk, 1.0 / (hp * wp), w1.data_ptr(), b1.data_ptr(),
+        _lib.check(self.lib.savsr_se_gate(part.data_ptr(), nblk, 1.0 / (hp * wp), w1.data_ptr(), b1.data_ptr(),
                                           w2.data_ptr(), b2.data_ptr(), nf, cm, self.se_gate.data_ptr(), st), "savsr_se_gate")
         assert x.pix == nf and out.pix == nf
         _lib.check(self.lib.savsr_scale_residual(r2.ptr, self.se_gate.data_ptr(), x.ptr, out.ptr, nf, hp * wp, st),
                    "savsr_scale_residual")
         return out
 
-    def osadapt(self, g: int, x: Src, share: Optional[Src], out: Src, hp: int, wp: int, scale) -> Src:
-        """savsr_arch.py:186-214 fused with `+ gamma * share` of :732 (share=None: OSAdapt alone)."""
+    def osadapt(self, g: int, x: Src, share: Optional[Src], out: Src, hp: int, wp: int, scale, pooled: bool = False) -> Src:
+        """savsr_arch.py:186-214 fused with `+ gamma * share` of :732 (share=None: OSAdapt alone).
+        pooled=True: the conv that produced x already wrote the pool partials of adapt.{g}.adapt."""
         m = f"adapt.{g}.mask"
         st = self._stream()
         c4 = self.pw[m + ".0"][2]
@@ -477,7 +495,7 @@ class HipEngine:
         _lib.check(self.lib.savsr_upsample2x(m4.ptr, m5.data_ptr(), c4, h2, w2, st), "savsr_upsample2x")
         mask = self.buf("ad.mask", hp, wp, 1)
         self.conv(m + ".11", [self.full(m5)], self.full(mask), hp, wp, ACT_SIGMOID)
-        wd = self.osconv_weights(f"adapt.{g}.adapt", [x], hp, wp, scale)
+        wd = self.osconv_weights(f"adapt.{g}.adapt", [x], hp, wp, scale, pooled=pooled)
         return self.conv(f"adapt.{g}.adapt", [x], out, hp, wp, ACT_NONE, mul_px=mask, res1=x, res2=share,
                          res2_scale=self.gamma, weights=wd)
 
@@ -610,8 +628,9 @@ class HipEngine:
             r = xin
             for k in range(cfg["n_resblocks"]):
                 r = self.rcab(f"RG.{g}.residual_group.{k}.rcab", r, self.full(self.buf(f"rg.r{k & 1}", hp, wp, nf)), hp, wp, "rg")
-            rg = self.conv(f"RG.{g}.conv", [r], self.full(self.buf("rg.out", hp, wp, nf)), hp, wp, res1=xin)
-            hcur = self.osadapt(g, rg, share, self.full(self.buf(f"rg.h{g & 1}", hp, wp, nf)), hp, wp, scale)
+            rg = self.conv(f"RG.{g}.conv", [r], self.full(self.buf("rg.out", hp, wp, nf)), hp, wp, res1=xin,
+                           pool=(self.pool_buf(f"adapt.{g}.adapt", hp, wp, nf), 0, nf))      # OSAdapt's OSConv pools this tensor
+            hcur = self.osadapt(g, rg, share, self.full(self.buf(f"rg.h{g & 1}", hp, wp, nf)), hp, wp, scale, pooled=True)
         hfeat = self.conv("conv_last", [hcur], self.full(self.buf("hfeat", hp, wp, nf)), hp, wp, res1=share)   # :733-734
         H, W = get_hw(h_in, w_in, scale)
         plane = self.hr_plane(H, W)

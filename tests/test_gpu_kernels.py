@@ -112,6 +112,23 @@ def test_osconv_vs_golden(eng, golden, synth_sd, tag, pfx, cin):
         assert _maxerr(att, ref_att) < 1e-5
 
 
+def test_conv_fused_pool(eng):
+    """Fused AdaptiveAvgPool2d(1) partials of the conv epilogue == mean of the stored tensor."""
+    from savsr_amd import engine as E
+    g = np.random.RandomState(5)
+    h, w = 21, 70
+    wt = torch.from_numpy((g.standard_normal((64, 64, 3, 3)) / 24.0).astype(np.float32))
+    x = torch.from_numpy(g.standard_normal((64, h, w)).astype(np.float32))
+    out = torch.empty(h, w, 64, device="cuda:0")
+    rows = eng.pool_rows(h, w)
+    part = torch.full((rows, 128), float("nan"), device="cuda:0")
+    eng.conv("t", [eng.full(cl(x))], eng.full(out), h, w, weights=(_dev(E.pack_conv_weight(wt)), None, 64, 64, 3), pool=(part, 64, 128))
+    torch.cuda.synchronize()
+    mean = part[:, 64:].sum(0).cpu() / (h * w)
+    assert _maxerr(mean, pl(out).mean(dim=(1, 2))) < 1e-5
+    assert bool(torch.isnan(part[:, :64]).all())
+
+
 def test_channel_sums_large(eng):
     """Many-block pooled means against torch."""
     x = rnd((192, 90, 100), 7)
