@@ -394,7 +394,7 @@ static int conv_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("SAVSR_CONV_VARIANT");
-        v = e ? atoi(e) & 3 : 1;
+        v = e ? atoi(e) & 3 : 0;
     }
     return v;
 }
