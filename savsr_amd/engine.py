@@ -145,6 +145,9 @@ class HipEngine:
         self.satu_events: Optional[list] = None     # bench.py: (start, end) HIP events around SATU
         self.use_graphs = os.environ.get("SAVSR_GRAPHS", "1") != "0"
         self._graphs: Dict[tuple, tuple] = {}
+        self.n_streams = max(1, int(os.environ.get("SAVSR_STREAMS", "2")))   # clips of a batch in flight concurrently
+        self._siblings: List["HipEngine"] = []
+        self._streams: List[torch.cuda.Stream] = []
         self._pack_all({k: v.detach() for k, v in state.items()})
 
     # ------------------------------------------------------------------ weight preparation
@@ -319,6 +322,26 @@ class HipEngine:
         self.gamma = float(sd["gamma"].reshape(-1)[0])
         self._pack_satu(sd)
         self.se_gate = torch.empty(self.nf, device=self.dev)
+
+    def clone_for_stream(self) -> "HipEngine":
+        """A sibling engine that shares every read-only packed weight with this one but owns its
+        dynamic state (OSConv scratch / weight images, buffers, SATU tables, graphs), so two clips can be
+        in flight on two HIP streams."""
+        e = HipEngine.__new__(HipEngine)
+        e.lib, e.dev, e.cfg, e.nf = self.lib, self.dev, self.cfg, self.nf
+        e.pw, e.se, e._keep = self.pw, self.se, self._keep
+        e.satu_t, e.satu_w, e.tail_w, e.tail_b, e.gamma, e.n_l2 = self.satu_t, self.satu_w, self.tail_w, self.tail_b, self.gamma, self.n_l2
+        e.osc = {}
+        for k, ent in self.osc.items():
+            c = dict(ent)
+            for name in ("v1", "v2", "att", "wdyn"):
+                c[name] = torch.empty_like(ent[name])
+            e.osc[k] = c
+        e.se_gate = torch.empty_like(self.se_gate)
+        e._bufs, e._satu_axes, e._graphs = {}, {}, {}
+        e.satu_events, e.use_graphs = None, self.use_graphs
+        e._siblings, e._streams = [], []
+        return e
 
     # ------------------------------------------------------------------ buffers / launch helpers
     def buf(self, name: str, *shape: int) -> torch.Tensor:
@@ -712,6 +735,25 @@ class HipEngine:
         b, _, _, h, w = lq.shape
         H, W = get_hw(h, w, scale)
         out = torch.empty(b, 3, H, W, device=self.dev, dtype=torch.float32)
+        if b >= 2 and self.n_streams >= 2 and self.use_graphs and taps is None:
+            # clips are independent (no cross-clip state, savsr_arch.py:705-706): keep n_streams of them in flight
+            # on separate HIP streams so one clip's load/store-bound kernel phases overlap another's MFMA phases
+            ns = min(self.n_streams, b)
+            while len(self._siblings) < ns - 1:
+                self._siblings.append(self.clone_for_stream())
+            while len(self._streams) < ns:
+                self._streams.append(torch.cuda.Stream(device=self.dev))
+            engines = [self] + self._siblings
+            cur = torch.cuda.current_stream()
+            for k in range(ns):
+                self._streams[k].wait_stream(cur)
+                engines[k].satu_events = self.satu_events
+            for i in range(b):
+                with torch.cuda.stream(self._streams[i % ns]):
+                    engines[i % ns]._forward_graphed(lq[i], scale, out[i])
+            for k in range(ns):
+                cur.wait_stream(self._streams[k])
+            return out
         for i in range(b):      # samples are independent (OSConv groups=b, savsr_arch.py:166-167)
             if self.use_graphs and taps is None:
                 self._forward_graphed(lq[i], scale, out[i])
