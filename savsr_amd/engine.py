@@ -145,7 +145,7 @@ class HipEngine:
         self.satu_events: Optional[list] = None     # bench.py: (start, end) HIP events around SATU
         self.use_graphs = os.environ.get("SAVSR_GRAPHS", "1") != "0"
         self._graphs: Dict[tuple, tuple] = {}
-        self.n_streams = max(1, int(os.environ.get("SAVSR_STREAMS", "2")))   # clips of a batch in flight concurrently
+        self.n_streams = max(1, int(os.environ.get("SAVSR_STREAMS", "3")))   # clips of a batch in flight concurrently
         self._siblings: List["HipEngine"] = []
         self._streams: List[torch.cuda.Stream] = []
         self._pack_all({k: v.detach() for k, v in state.items()})
