@@ -183,32 +183,32 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
             }
             const bf16x8* wl = wbuf + (tap % 3) * LR_SLAB + lane;
             const float* kb = kbl + tap * 64 + cg * 32 + 4 * half;
-            const int ky = tap / 5, kx = tap - ky * 5;
-            const float* xp = xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half;
-            // every LDS operand of the tap is requested up front: A fragments first (the MFMAs wait for them),
-            // then bias and x values, which are only consumed after the MFMAs
-            bf16x8 ah[4], al[4];
-            f32x4 bias[4], xv[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { ah[ks] = wl[(ks * 2 + 0) * 64]; al[ks] = wl[(ks * 2 + 1) * 64]; }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) { bias[g] = *reinterpret_cast<const f32x4*>(kb + 8 * g); xv[g] = *reinterpret_cast<const f32x4*>(xp + 8 * g); }
-            __builtin_amdgcn_sched_barrier(0);
-            LR_MARK(1);                                // slab load issue + LDS operand requests
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int g = 0; g < 4; ++g) {            // bias as the initial accumulator
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + 8 * g);
+                acc[4 * g + 0] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
+            }
+            LR_MARK(1);                                // slab load issue + bias
+            bf16x8 ah[4], al[4];                       // all 8 A fragments of the tap in flight before the first MFMA
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { ah[ks] = wl[(ks * 2 + 0) * 64]; al[ks] = wl[(ks * 2 + 1) * 64]; }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) acc = mma3(ah[ks], al[ks], sth[ks], stl[ks], acc);
             if (stamps_on) { asm volatile("" :: "v"(acc[0])); }
-            LR_MARK(2);                                // 12 MFMAs (+ wait for the A fragments)
+            LR_MARK(2);                                // fragment reads + 12 MFMAs
+            const int ky = tap / 5, kx = tap - ky * 5;
+            const float* xp = xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + 8 * g);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float k = acc[4 * g + i] + bias[g][i];
-                    sacc[4 * g + i] += fmaxf(k, 0.1f * k) * xv[g][i];     // LeakyReLU(0.1), :228
+                    const float k = acc[4 * g + i];
+                    sacc[4 * g + i] += fmaxf(k, 0.1f * k) * xv[i];     // LeakyReLU(0.1), :228
                 }
+            }
             if (stamps_on) { asm volatile("" :: "v"(sacc[0])); }
             LR_MARK(3);                                // LeakyReLU * x accumulate
             if (tap + 1 < 25) {
@@ -492,30 +492,20 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
     const int Xc0 = (X0 + px < p.W) ? X0 + px : p.W - 1;
     const int iw0 = p.idx_w[Xc0];
     const float gxn0 = p.gxn[Xc0];
-    // phase-table entry of a tile: (row index from LDS) -> entry (LDS or global); fetched one tile ahead
-    auto fetch_entry = [&](int T, f32x4& r4, f32x4& o4) {
-        const int trow = T / p.txw;
-        const int Xb = X0 + (T - trow * p.txw) * 32;
-        const int Xq = Xb + px < p.W ? Xb + px : p.W - 1;
-        const int iw = (Xb == X0) ? iw0 : p.idx_w[Xq];
-        const long long ent = ((long long)__float_as_int(rowc[trow]) * p.n_uw + iw) * SAVSR_SATU_TABLE;
-        const float* te = tab ? tab + ent : p.table + ent;
-        r4 = *reinterpret_cast<const f32x4*>(te);
-        o4 = *reinterpret_cast<const f32x4*>(te + 4);
-    };
-    f32x4 rr_n = {0.f, 0.f, 0.f, 0.f}, oo_n = rr_n;
-    if (wave < ntile) fetch_entry(wave, rr_n, oo_n);
     for (int T = wave; T < ntile; T += 4) {
         const int trow = T / p.txw;
         const int Y = Y0 + trow;
         const int Xb = X0 + (T - trow * p.txw) * 32;
-        const f32x4 rr = rr_n, oo = oo_n;
-        if (T + 4 < ntile) fetch_entry(T + 4, rr_n, oo_n);
         if (Y >= p.H || Xb >= p.W) continue;                      // wave-uniform
         const int X = Xb + px;
         const bool valid = X < p.W;
         const int Xc = valid ? X : p.W - 1;
         const bool col0 = Xb == X0;                                   // wave-uniform
+        const int iw = col0 ? iw0 : p.idx_w[Xc];
+        const long long ent = ((long long)__float_as_int(rowc[trow]) * p.n_uw + iw) * SAVSR_SATU_TABLE;
+        const float* te = tab ? tab + ent : p.table + ent;
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
+        const f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
         const float gxn = col0 ? gxn0 : p.gxn[Xc], gyn = rowc[HR_MAX_ROWS + trow];
         if (stamps_on) { asm volatile("" :: "v"(rr[0]), "v"(oo[0])); }
         HR_MARK(0);                                                  // table lookup
