@@ -25,6 +25,9 @@ import torch  # noqa: E402
 
 LR_H, LR_W, SCALE = 180, 320, (4, 4)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM bytes of one SATU stage from rocprofv3 PMC passes (FETCH_SIZE x 2 for 16-B/lane streaming reads on gfx950,
+# WRITE_SIZE as read; separate passes): profiles/r01_satu_pmc_traffic.csv.  Config 2 only.
+SATU_PMC_TRAFFIC_BYTES = 391458368
 
 
 def effective_cpus():
@@ -156,7 +159,7 @@ def main():
                        "frames_per_step": cps, "streams_per_gpu": min(cps, eng.n_streams), "parallelism": f"clip-sharded dp{world}"},
             "psnr_y_vs_synthetic_gt": round(float(psnr), 4),
             "roofline": {"kernel": "SATU (phase table + LR stage + HR upsample)", "bound": "hbm", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": SATU_PMC_TRAFFIC_BYTES,
                          "algorithmic_bytes": alg_bytes, "avg_ms": round(1e3 * satu_avg_s, 4),
                          "note": "timed-region figure: the other in-flight clips' kernels share the GPU with these launches",
                          "solo_avg_ms": round(sum(solo_ms) / len(solo_ms), 4), "solo_frac": round(alg_bytes / (sum(solo_ms) / len(solo_ms) / 1e3) / 1e9 / HBM_PEAK_GBS, 4)},
