@@ -74,14 +74,13 @@ def main():
         eng.lib.savsr_debug_conv_stamps(1)
         run()
         torch.cuda.synchronize()
-        th = 8 if os.environ.get('SAVSR_CONV_VARIANT') == '0' else 4
-        nb = min(1024, ((w + 31) // 32) * ((h + th - 1) // th))
+        nb = min(256, ((w + 31) // 32) * ((h + 7) // 8))
         buf = (C.c_longlong * (6 * nb))()
         eng.lib.savsr_debug_read_conv_stamps(buf, nb)
         eng.lib.savsr_debug_conv_stamps(0)
         st = np.array(buf[:], dtype=np.int64).reshape(nb, 6)
         d = np.diff(st[:, :5], axis=1)
-        print("stamps (shader cycles, median over workgroups): prologue %d  phase0 %d  remaining phases %d  epilogue+drain %d  total %d" %
+        print("stamps (shader cycles, median over workgroups): first staging %d  phase0 %d  rest of the first tile K loop %d  later tiles + epilogues + drain %d  total %d" %
               tuple(np.median(d, axis=0).tolist() + [np.median(st[:, 4] - st[:, 0])]))
         rt = st[:, 5]
         print("workgroup start spread (100 MHz ticks): min %d max %d -> %.2f us" % (rt.min(), rt.max(), (rt.max() - rt.min()) / 100.0))
