@@ -37,8 +37,6 @@ namespace savsr {
 struct ConvParams {
     const float* src[SAVSR_MAX_SRC];
     int src_pix[SAVSR_MAX_SRC];      // floats between pixels of source s
-    int nsrc, src_ch;
-    int h, w, cout, nchunk;
     const unsigned short* wimg;
     const float* bias;
     int act;
@@ -58,7 +56,8 @@ struct ConvParams {
 constexpr int CONV_MAX_BATCH = 6;
 constexpr int CONV_PERSISTENT_BLOCKS = 256;   // one resident workgroup per CU (117-154 KB of LDS each)
 struct MultiConvParams {
-    ConvParams c[CONV_MAX_BATCH];     // convs of identical geometry
+    ConvParams c[CONV_MAX_BATCH];     // convs of identical geometry:
+    int h, w, cout, nchunk, src_ch;   //   shared shape (fixed kernarg offsets: read once, not per tile)
     int nconv, ncob, ntx, nty;        // tile id = ((conv * ncob + cob) * nty + ty) * ntx + tx
 };
 
@@ -104,41 +103,75 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     f32x4 b_reg[B_IT];
     f32x4 w_reg[W_IT];
 
-    // phase `chunk` of tile `tile`: global -> registers
-    auto stage_load = [&](int tile, int chunk) {
+    struct TileInfo { int conv, cob, x0, y0, tix; };
+    auto decode = [&](int tile) {
         const int cc = tile / tiles_per_cob, rem = tile - cc * tiles_per_cob;
-        const int conv = cc / mp.ncob, cob = cc - conv * mp.ncob;
         const int ty = rem / mp.ntx, tx = rem - ty * mp.ntx;
-        const ConvParams& p = mp.c[conv];
-        const int x0 = tx * CONV_TW, y0 = ty * TH;
-        const int per_src = p.src_ch / KC;
-        const int s = chunk / per_src;
-        const int cb = (chunk - s * per_src) * KC;
-        const float* base = p.src[0];
-        int pix = p.src_pix[0];
-        if (s == 1) { base = p.src[1]; pix = p.src_pix[1]; }
-        if (s == 2) { base = p.src[2]; pix = p.src_pix[2]; }
-        if (s == 3) { base = p.src[3]; pix = p.src_pix[3]; }
-        if (s == 4) { base = p.src[4]; pix = p.src_pix[4]; }
+        TileInfo ti;
+        ti.conv = cc / mp.ncob;
+        ti.cob = cc - ti.conv * mp.ncob;
+        ti.x0 = tx * CONV_TW;
+        ti.y0 = ty * TH;
+        ti.tix = rem;
+        return ti;
+    };
+    // Staging, global -> registers.  A cursor walks the phases: (tile, source, channel base); per tile it keeps each
+    // thread's pixel offsets (they do not change over the K loop), per source the base pointer and pixel pitch, and
+    // the weight slab pointer just advances.  Descriptor fields with a run-time conv / source index are therefore
+    // read once per tile / source, not per phase (15 dependent s_loads per phase cost ~3 k cycles, stamps mode 3).
+    // stage_issue(j) issues load j; the loads of one phase are spread over the MFMA steps of the previous one.
+    const int H = mp.h, W = mp.w;
+    const float* st_base = nullptr;
+    const f32x4* st_w = nullptr;
+    int st_pix = 0, st_cb = 0, st_src = 0, st_conv = 0;
+    int st_pixoff[B_IT], st_off[B_IT];
+    auto stage_begin_tile = [&](const TileInfo& ti) {
+        st_conv = ti.conv;
+        st_src = 0;
+        st_cb = 0;
+        st_base = mp.c[ti.conv].src[0];
+        st_pix = mp.c[ti.conv].src_pix[0];
+        st_w = reinterpret_cast<const f32x4*>(mp.c[ti.conv].wimg) + (long long)ti.cob * mp.nchunk * W_UNITS;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int e = tid + i * NTHR;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            int off = -1;
             if (e < B_ITEMS) {
-                const int pl = e / PER, c8 = e - pl * PER;          // pixel of the tile, float4 of the chunk
+                const int pl = e / PER;                             // pixel of the tile
                 const int r = pl / IC, c = pl - r * IC;
-                const int gy = y0 - HALO + r, gx = x0 - HALO + c;
-                if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w)
-                    v = *reinterpret_cast<const f32x4*>(base + ((long long)gy * p.w + gx) * pix + cb + c8 * 4);
+                const int gy = ti.y0 - HALO + r, gx = ti.x0 - HALO + c;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) off = gy * W + gx;
             }
-            b_reg[i] = v;
+            st_pixoff[i] = off;
         }
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wimg) + ((long long)cob * p.nchunk + chunk) * W_UNITS;
+    };
+    auto stage_advance = [&]() {
+        st_cb += KC;
+        st_w += W_UNITS;
+        if (st_cb >= mp.src_ch) {
+            st_cb = 0;
+            ++st_src;
+            st_base = mp.c[st_conv].src[st_src];
+            st_pix = mp.c[st_conv].src_pix[st_src];
+        }
+    };
+    auto stage_offsets = [&]() {
 #pragma unroll
-        for (int i = 0; i < W_IT; ++i) {
+        for (int i = 0; i < B_IT; ++i) {
             const int e = tid + i * NTHR;
+            const int c8 = e % PER;                                 // float4 of the chunk
+            st_off[i] = st_pixoff[i] >= 0 ? st_pixoff[i] * st_pix + st_cb + c8 * 4 : -1;
+        }
+    };
+    auto stage_issue = [&](int j) {
+        if (j < B_IT) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < W_UNITS) v = wsrc[e];
+            if (st_off[j] >= 0) v = *reinterpret_cast<const f32x4*>(st_base + st_off[j]);
+            b_reg[j] = v;
+        } else if (j < B_IT + W_IT) {
+            const int i = j - B_IT, e = tid + i * NTHR;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < W_UNITS) v = st_w[e];
             w_reg[i] = v;
         }
     };
@@ -172,24 +205,31 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 
     struct Frag { bf16x8 ah[NT], al[NT], bh, bl; };
 
+    // diagnostics: accumulated section times of this wave (stamps mode 3): load issue | MFMA loop | wait+store | barrier | epilogue
+    long long sec[5] = {0, 0, 0, 0, 0};
+    long long t_prev = (stamps_on == 3) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define CV_MARK(i) do { if (stamps_on == 3) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); sec[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+
     stamp(stamps_on, 0);
     stamp(stamps_on, 5);
     int tile = blockIdx.x;
     int buf = 0;
+    TileInfo cur = decode(tile < total ? tile : 0);
     if (tile < total) {
-        stage_load(tile, 0);
+        stage_begin_tile(cur);
+        stage_offsets();
+#pragma unroll
+        for (int j = 0; j < B_IT + W_IT; ++j) stage_issue(j);
         stage_store(0);
     }
     __syncthreads();
     stamp(stamps_on, 1);
 
     for (; tile < total; tile += gridDim.x) {
-        const int cc = tile / tiles_per_cob, rem = tile - cc * tiles_per_cob;
-        const int conv = cc / mp.ncob, cob = cc - conv * mp.ncob;
-        const int ty = rem / mp.ntx, tx = rem - ty * mp.ntx;
-        const ConvParams& p = mp.c[conv];
-        const int x0 = tx * CONV_TW, y0 = ty * TH;
+        const ConvParams& p = mp.c[cur.conv];
+        const int cob = cur.cob, x0 = cur.x0, y0 = cur.y0, tix = cur.tix;
         const int next_tile = tile + gridDim.x;
+        const TileInfo nxt = decode(next_tile < total ? next_tile : tile);
 
         f32x16 acc[NT];
 #pragma unroll
@@ -197,12 +237,10 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-        for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+        for (int chunk = 0; chunk < mp.nchunk; ++chunk) {
             // what to stage while this phase computes: the tile's next phase, or the next tile's first
-            const bool more = chunk + 1 < p.nchunk;
+            const bool more = chunk + 1 < mp.nchunk;
             const bool stage = more || next_tile < total;
-            if (more) stage_load(tile, chunk + 1);
-            else if (next_tile < total) stage_load(next_tile, 0);
 
             const bf16x8* bl = smem + buf * B_UNITS;
             const bf16x8* wl = smem + 2 * B_UNITS + buf * W_UNITS;
@@ -229,26 +267,55 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bh, acc[t], 0, 0, 0);
                 }
             };
+            if (more) stage_advance();
+            else if (stage) stage_begin_tile(nxt);
+            stage_offsets();
+            constexpr int N_LD = B_IT + W_IT;
+            constexpr int LD_STEPS = STEPS > 1 ? STEPS - 1 : 1;           // keep the last step free: its loads would land right on the wait
+            constexpr int LD_PER = (N_LD + LD_STEPS - 1) / LD_STEPS;
             Frag f[3];
             load_frag(0, f[0]);
             if (STEPS > 1) load_frag(1, f[1]);
+            CV_MARK(0);
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 if (s + 2 < STEPS) load_frag(s + 2, f[(s + 2) % 3]);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(f[s % 3]);
                 __builtin_amdgcn_sched_barrier(0);
+                if (stage) {
+#pragma unroll
+                    for (int j = s * LD_PER; j < (s + 1) * LD_PER && j < N_LD; ++j) stage_issue(j);
+                }
             }
+            if (stamps_on == 3) { asm volatile("" :: "v"(acc[0][0])); }
+            CV_MARK(1);
             if (chunk == 0 && tile == (int)blockIdx.x) stamp(stamps_on, 2);
             if (stage) stage_store(buf ^ 1);
+            CV_MARK(2);
             __syncthreads();
+            CV_MARK(3);
             buf ^= 1;
         }
         if (tile == (int)blockIdx.x) stamp(stamps_on, 3);
+        const int ty_tx = tix;
 
         // ---- epilogue: transpose through the wave's private LDS slice, 32 channels at a time ----------------
+        // The descriptor fields are read ONCE per tile into pinned scalars: left to the compiler, every use below
+        // re-issued its s_load from the run-time-indexed descriptor (144 dependent scalar loads, ~14 k cycles per tile).
+        const float* e_bias = p.bias;
+        const float* e_mul = p.mul_px;
+        const float* e_r1 = p.res1;
+        const float* e_r2 = p.res2;
+        float* e_out = p.out;
+        int e_act = p.act, e_opix = p.out_pix, e_r1pix = p.res1_pix, e_r2pix = p.res2_pix;
+        float e_slope = p.slope, e_r2s = p.res2_scale;
+        asm volatile("" : "+s"(e_bias), "+s"(e_mul), "+s"(e_r1), "+s"(e_r2), "+s"(e_out));
+        asm volatile("" : "+s"(e_act), "+s"(e_opix), "+s"(e_r1pix), "+s"(e_r2pix), "+s"(e_slope), "+s"(e_r2s));
+        const int COUT = mp.cout;
         float* ep = ep_base + wave * (32 * EPS);
         const int y = y0 + wave;
+        const int c4 = lane & 7;                                // lane l always handles channel quad l % 8
         f32x4 psum[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -258,55 +325,64 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 *reinterpret_cast<f32x4*>(ep + px * EPS + 8 * g + 4 * half) = v;
             }
             psum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int co = cob * COT + 32 * t + 4 * c4;
+            const bool full = co + 3 < COUT;
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (e_bias) {
+                if (full) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(e_bias + co);
+                    b4[0] = bv[0]; b4[1] = bv[1]; b4[2] = bv[2]; b4[3] = bv[3];
+                } else {
+                    for (int q = 0; q < 4 && co + q < COUT; ++q) b4[q] = e_bias[co + q];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                       // 32 px x 8 channel quads = 256 units, 4 per lane
-                const int unit = lane + 64 * i;
-                const int pl = unit >> 3, c4 = unit & 7;        // lane l always handles channel quad l % 8
-                const int x = x0 + pl, co = cob * COT + 32 * t + 4 * c4;
-                if (y >= p.h || x >= p.w || co >= p.cout) continue;
-                const long long pidx = (long long)y * p.w + x;
+                const int pl = (lane >> 3) + 8 * i;
+                const int x = x0 + pl;
+                if (y >= H || x >= W || co >= COUT) continue;
+                const int pidx = y * W + x;
                 const f32x4 a4 = *reinterpret_cast<const f32x4*>(ep + pl * EPS + 4 * c4);
-                float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-                const bool full = co + 3 < p.cout;
-                const float mul = p.mul_px ? p.mul_px[pidx] : 1.f;
-                if (p.bias) {
-                    if (full) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
-                        v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
-                    } else {
-                        for (int q = 0; q < 4 && co + q < p.cout; ++q) v[q] += p.bias[co + q];
-                    }
-                }
+                float v[4] = {a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
+                if (e_act == SAVSR_ACT_RELU) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (p.act == SAVSR_ACT_RELU) v[q] = fmaxf(v[q], 0.f);
-                    else if (p.act == SAVSR_ACT_LRELU) v[q] = v[q] > 0.f ? v[q] : v[q] * p.slope;
-                    else if (p.act == SAVSR_ACT_SIGMOID) v[q] = sigmoidf_(v[q]);
-                    v[q] *= mul;
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                } else if (e_act == SAVSR_ACT_LRELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * e_slope;
+                } else if (e_act == SAVSR_ACT_SIGMOID) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = sigmoidf_(v[q]);
                 }
-                float* o = p.out + pidx * p.out_pix + co;
+                if (e_mul) {
+                    const float mul = e_mul[pidx];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] *= mul;
+                }
+                float* o = e_out + (long long)pidx * e_opix + co;
                 if (full) {
-                    if (p.res1) {
-                        const f32x4 r = *reinterpret_cast<const f32x4*>(p.res1 + pidx * p.res1_pix + co);
+                    if (e_r1) {
+                        const f32x4 r = *reinterpret_cast<const f32x4*>(e_r1 + (long long)pidx * e_r1pix + co);
                         v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
                     }
-                    if (p.res2) {
-                        const f32x4 r = *reinterpret_cast<const f32x4*>(p.res2 + pidx * p.res2_pix + co);
-                        v[0] += p.res2_scale * r[0]; v[1] += p.res2_scale * r[1]; v[2] += p.res2_scale * r[2]; v[3] += p.res2_scale * r[3];
+                    if (e_r2) {
+                        const f32x4 r = *reinterpret_cast<const f32x4*>(e_r2 + (long long)pidx * e_r2pix + co);
+                        v[0] += e_r2s * r[0]; v[1] += e_r2s * r[1]; v[2] += e_r2s * r[2]; v[3] += e_r2s * r[3];
                     }
                     const f32x4 ov = {v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(o) = ov;
                     psum[t][0] += v[0]; psum[t][1] += v[1]; psum[t][2] += v[2]; psum[t][3] += v[3];
                 } else {
-                    for (int q = 0; q < 4 && co + q < p.cout; ++q) {
+                    for (int q = 0; q < 4 && co + q < COUT; ++q) {
                         float vv = v[q];
-                        if (p.res1) vv += p.res1[pidx * p.res1_pix + co + q];
-                        if (p.res2) vv += p.res2_scale * p.res2[pidx * p.res2_pix + co + q];
+                        if (e_r1) vv += e_r1[(long long)pidx * e_r1pix + co + q];
+                        if (e_r2) vv += e_r2s * e_r2[(long long)pidx * e_r2pix + co + q];
                         o[q] = vv;
                     }
                 }
             }
         }
+        CV_MARK(4);
         if (p.pool) {
             // AdaptiveAvgPool2d(1) of the tensor just produced (savsr_arch.py:146,515), fused: lanes with equal
             // l % 8 hold the same channel quad -> butterfly over the 8 pixel groups, then the waves are summed in
@@ -328,15 +404,18 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 float sacc = 0.f;
 #pragma unroll
                 for (int wv = 0; wv < TH; ++wv) sacc += pl_[wv * COT + tid];
-                if (cob * COT + tid < p.cout) p.pool[(long long)(ty * mp.ntx + tx) * p.pool_stride + cob * COT + tid] = sacc;
+                if (cob * COT + tid < mp.cout) p.pool[(long long)ty_tx * p.pool_stride + cob * COT + tid] = sacc;
             }
             __syncthreads();                         // the slices are reused by the next tile's epilogue
         }
+        cur = nxt;
     }
     if (stamps_on == 1) {
         __builtin_amdgcn_s_waitcnt(0);              // diagnostics: include the store drain in the last stamp
         stamp(stamps_on, 4);
     }
+    if (stamps_on == 3 && tid == 0 && blockIdx.x < STAMP_BLOCKS)
+        for (int i = 0; i < 5; ++i) g_conv_stamps[blockIdx.x * STAMP_N + i] = sec[i];
 }
 
 template <int KS, int NT>
@@ -423,9 +502,6 @@ static int fill_params(const savsr_conv_desc* d, ConvParams& p) {
         set_error("conv: sources / residuals / bias / out / weights must be 16-byte aligned with pixel strides multiple of 4 floats");
         return SAVSR_E_ALIGN;
     }
-    p.nsrc = d->nsrc; p.src_ch = d->src_ch;
-    p.h = d->h; p.w = d->w; p.cout = d->cout;
-    p.nchunk = d->cin / kc;
     p.wimg = reinterpret_cast<const unsigned short*>(d->wpacked);
     p.bias = d->bias; p.act = d->act; p.slope = d->slope;
     p.mul_px = d->mul_px; p.res1 = d->res1; p.res1_pix = d->res1_pix; p.res2 = d->res2; p.res2_pix = d->res2_pix;
@@ -451,6 +527,9 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
     for (int i = n; i < CONV_MAX_BATCH; ++i) mp.c[i] = mp.c[0];
     const savsr_conv_desc* d = descs;
     const int cot = conv_cot(d->cout);
+    mp.h = d->h; mp.w = d->w; mp.cout = d->cout;
+    mp.nchunk = d->cin / conv_kc(d->ksize);
+    mp.src_ch = d->src_ch;
     mp.nconv = n;
     mp.ncob = (d->cout + cot - 1) / cot;
     mp.ntx = (d->w + CONV_TW - 1) / CONV_TW;
