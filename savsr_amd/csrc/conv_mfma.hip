@@ -205,31 +205,75 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 
     struct Frag { bf16x8 ah[NT], al[NT], bh, bl; };
 
-    // diagnostics: accumulated section times of this wave (stamps mode 3): load issue | MFMA loop | wait+store | barrier | epilogue
+    // diagnostics: accumulated section times of this wave (stamps mode 3): steps after the barrier (+ load issue) | steps before it | wait+split+store | barrier | epilogue
     long long sec[5] = {0, 0, 0, 0, 0};
     long long t_prev = (stamps_on == 3) ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define CV_MARK(i) do { if (stamps_on == 3) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); sec[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     stamp(stamps_on, 0);
     stamp(stamps_on, 5);
+
+    // ---- software pipeline over the block's phases (tiles x chunks, walked linearly by the staging cursor) ----
+    //   LDS buffer c%2 holds phase c.  While phase c computes: phase c+1 sits in (or is arriving into) the staging
+    //   registers; at step SB it is split + stored to the other buffer, ONE barrier publishes it, the cursor moves to
+    //   phase c+2 and its global loads are issued (a full phase of latency budget).  All fragment reads of phase c are
+    //   issued before that barrier (they run two steps ahead), so the last two steps already read phase c+1's first
+    //   fragments: the MFMA stream does not stop at phase or tile boundaries.
+    constexpr int SB = STEPS >= 2 ? STEPS - 2 : 0;           // the step whose fragment prefetch is the first of the next phase
+    constexpr int N_LD = B_IT + W_IT;
+    constexpr int LD_PER = (N_LD + (STEPS - SB) - 1) / (STEPS - SB);
+    int st_tile = blockIdx.x, st_chunk = 0;
+    auto stage_next = [&]() -> bool {                        // cursor -> following phase; false when the block has no more
+        if (st_chunk + 1 < mp.nchunk) { ++st_chunk; stage_advance(); return true; }
+        st_tile += gridDim.x;
+        if (st_tile >= total) return false;
+        st_chunk = 0;
+        stage_begin_tile(decode(st_tile));
+        return true;
+    };
+    auto load_frag = [&](int buf, int s, Frag& f) {
+        const bf16x8* bbase = smem + buf * B_UNITS + half * NPX + wave * IC + px;
+        const bf16x8* abase = smem + 2 * B_UNITS + buf * W_UNITS + lane;
+        const int tap = s / KSTEPS, ks = s - tap * KSTEPS;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int bo = ks * 2 * NPX + ky * IC + kx;
+        f.bh = bbase[bo];
+        f.bl = bbase[B_PART + bo];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f.ah[t] = abase[((s * NT + t) * 2 + 0) * 64];
+            f.al[t] = abase[((s * NT + t) * 2 + 1) * 64];
+        }
+    };
+
     int tile = blockIdx.x;
     int buf = 0;
-    TileInfo cur = decode(tile < total ? tile : 0);
+    bool pend = false;                                       // phase c+1 exists (staging registers hold / are receiving it)
+    Frag f[3];
     if (tile < total) {
-        stage_begin_tile(cur);
+        stage_begin_tile(decode(tile));
         stage_offsets();
 #pragma unroll
-        for (int j = 0; j < B_IT + W_IT; ++j) stage_issue(j);
+        for (int j = 0; j < N_LD; ++j) stage_issue(j);
         stage_store(0);
     }
     __syncthreads();
+    if (tile < total) {
+        pend = stage_next();
+        if (pend) {
+            stage_offsets();
+#pragma unroll
+            for (int j = 0; j < N_LD; ++j) stage_issue(j);
+        }
+        load_frag(0, 0, f[0]);
+        if (STEPS > 1) load_frag(0, 1, f[1]);
+    }
     stamp(stamps_on, 1);
 
     for (; tile < total; tile += gridDim.x) {
+        const TileInfo cur = decode(tile);
         const ConvParams& p = mp.c[cur.conv];
         const int cob = cur.cob, x0 = cur.x0, y0 = cur.y0, tix = cur.tix;
-        const int next_tile = tile + gridDim.x;
-        const TileInfo nxt = decode(next_tile < total ? next_tile : tile);
 
         f32x16 acc[NT];
 #pragma unroll
@@ -238,63 +282,46 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
         for (int chunk = 0; chunk < mp.nchunk; ++chunk) {
-            // what to stage while this phase computes: the tile's next phase, or the next tile's first
-            const bool more = chunk + 1 < mp.nchunk;
-            const bool stage = more || next_tile < total;
-
-            const bf16x8* bl = smem + buf * B_UNITS;
-            const bf16x8* wl = smem + 2 * B_UNITS + buf * W_UNITS;
-            const bf16x8* bbase = bl + half * NPX + wave * IC + px;
-            const bf16x8* abase = wl + lane;
-
-            auto load_frag = [&](int s, Frag& f) {
-                const int tap = s / KSTEPS, ks = s - tap * KSTEPS;
-                const int ky = tap / KS, kx = tap - ky * KS;
-                const int bo = ks * 2 * NPX + ky * IC + kx;
-                f.bh = bbase[bo];
-                f.bl = bbase[B_PART + bo];
+            auto mma = [&](const Frag& fr) {                  // per accumulator: lo*hi, hi*lo, hi*hi (the order is part of the numerics)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    f.ah[t] = abase[((s * NT + t) * 2 + 0) * 64];
-                    f.al[t] = abase[((s * NT + t) * 2 + 1) * 64];
-                }
-            };
-            auto mma = [&](const Frag& f) {
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.al[t], fr.bh, acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[t], f.bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bh, acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.ah[t], fr.bl, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.ah[t], fr.bh, acc[t], 0, 0, 0);
             };
-            if (more) stage_advance();
-            else if (stage) stage_begin_tile(nxt);
-            stage_offsets();
-            constexpr int N_LD = B_IT + W_IT;
-            constexpr int LD_STEPS = STEPS > 1 ? STEPS - 1 : 1;           // keep the last step free: its loads would land right on the wait
-            constexpr int LD_PER = (N_LD + LD_STEPS - 1) / LD_STEPS;
-            Frag f[3];
-            load_frag(0, f[0]);
-            if (STEPS > 1) load_frag(1, f[1]);
-            CV_MARK(0);
+            bool pend2 = false;                               // phase c+2 exists (decided at the barrier)
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
-                if (s + 2 < STEPS) load_frag(s + 2, f[(s + 2) % 3]);
+                if (s == SB) {
+                    if (stamps_on == 3) { asm volatile("" :: "v"(acc[0][0])); }
+                    CV_MARK(1);
+                    if (pend) stage_store(buf ^ 1);
+                    CV_MARK(2);
+                    __syncthreads();
+                    CV_MARK(3);
+                    pend2 = pend && stage_next();
+                    if (pend2) stage_offsets();
+                }
+                if (s + 2 < STEPS) load_frag(buf, s + 2, f[(s + 2) % 3]);
+                else if (pend) load_frag(buf ^ 1, s + 2 - STEPS, f[(s + 2) % 3]);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(f[s % 3]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (stage) {
+                if (s >= SB && pend2) {
 #pragma unroll
-                    for (int j = s * LD_PER; j < (s + 1) * LD_PER && j < N_LD; ++j) stage_issue(j);
+                    for (int j = (s - SB) * LD_PER; j < (s - SB + 1) * LD_PER && j < N_LD; ++j) stage_issue(j);
                 }
             }
+            if (STEPS % 3 != 0) {                             // keep the ring aligned: the next phase starts at slots 0, 1
+                const Frag n0 = f[STEPS % 3], n1 = f[(STEPS + 1) % 3];
+                f[0] = n0;
+                f[1] = n1;
+            }
             if (stamps_on == 3) { asm volatile("" :: "v"(acc[0][0])); }
-            CV_MARK(1);
+            CV_MARK(0);
             if (chunk == 0 && tile == (int)blockIdx.x) stamp(stamps_on, 2);
-            if (stage) stage_store(buf ^ 1);
-            CV_MARK(2);
-            __syncthreads();
-            CV_MARK(3);
+            pend = pend2;
             buf ^= 1;
         }
         if (tile == (int)blockIdx.x) stamp(stamps_on, 3);
@@ -408,7 +435,6 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             }
             __syncthreads();                         // the slices are reused by the next tile's epilogue
         }
-        cur = nxt;
     }
     if (stamps_on == 1) {
         __builtin_amdgcn_s_waitcnt(0);              // diagnostics: include the store drain in the last stamp

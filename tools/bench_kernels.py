@@ -88,7 +88,7 @@ def main():
         eng.lib.savsr_debug_read_conv_stamps(buf, nb)
         eng.lib.savsr_debug_conv_stamps(0)
         s3 = np.array(buf[:], dtype=np.int64).reshape(nb, 6)[:, :5]
-        print("wave-0 section cycles summed over the K phases (median): load issue %d | fragment reads + MFMAs %d | wait + split + LDS store %d | barrier %d | epilogue %d" % tuple(np.median(s3, axis=0).tolist()))
+        print("wave-0 section cycles summed over the K phases (median): steps after the barrier (+ global load issue) %d | steps before the barrier %d | wait + split + LDS store %d | barrier %d | epilogue %d" % tuple(np.median(s3, axis=0).tolist()))
         rt = st[:, 5]
         print("workgroup start spread (100 MHz ticks): min %d max %d -> %.2f us" % (rt.min(), rt.max(), (rt.max() - rt.min()) / 100.0))
     if a.stamps and a.what == "satu":
