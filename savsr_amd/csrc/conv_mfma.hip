@@ -54,6 +54,7 @@ struct ConvParams {
 };
 
 constexpr int CONV_MAX_BATCH = 6;
+constexpr int CONV_WIDE_MIN_TILES = 200;       // 16-row tiles are used when a launch has at least this many of them
 constexpr int CONV_PERSISTENT_BLOCKS = 256;   // one resident workgroup per CU (117-154 KB of LDS each)
 struct MultiConvParams {
     ConvParams c[CONV_MAX_BATCH];     // convs of identical geometry:
@@ -68,15 +69,25 @@ struct MultiConvParams {
 constexpr int STAMP_BLOCKS = 1024, STAMP_N = 6;
 __device__ long long g_conv_stamps[STAMP_BLOCKS * STAMP_N];
 __device__ int g_conv_stamps_on = 0;
+__device__ __attribute__((aligned(16))) const float g_conv_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // what padding lanes load
 
 __device__ __forceinline__ void stamp(int on, int slot) {
     if (on == 1 && threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS)
         g_conv_stamps[blockIdx.x * STAMP_N + slot] = (slot == 5) ? (long long)__builtin_amdgcn_s_memrealtime() : (long long)__builtin_amdgcn_s_memtime();
 }
 
-template <int KS, int NT>
+// global accesses as (uniform base, 32-bit byte offset): one VGPR per address instead of a 64-bit pair
+// (savsr_conv2d validates that every tensor of a launch spans < 4 GiB)
+__device__ __forceinline__ f32x4 ldg4(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void stg4(float* base, unsigned byte_off, const f32x4& v) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+template <int KS, int NT, int PXT>
 __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams mp) {
-    constexpr int TH = CONV_TH, NTHR = 64 * TH;
+    constexpr int TH = CONV_TH * PXT, NTHR = 64 * CONV_TH;   // wave w owns tile rows w, w + 8, .. (PXT of them)
     constexpr int TAPS = KS * KS, HALO = KS / 2;
     constexpr int KC = conv_kc(KS), KSTEPS = KC / 16;
     constexpr int IR = TH + 2 * HALO, IC = CONV_TW + 2 * HALO, NPX = IR * IC;
@@ -93,17 +104,21 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16x8* smem = reinterpret_cast<bf16x8*>(smem_raw);      // 16-B units: [2][B_UNITS] | [2][W_UNITS] | epilogue slices
-    float* ep_base = reinterpret_cast<float*>(smem + 2 * B_UNITS + 2 * W_UNITS);
+    // PXT == 2 has no LDS left for dedicated epilogue slices: they alias the staging buffer the tile's last phase
+    // has just released (free until the store of the phase after next; see the barrier after the epilogue)
+    constexpr bool EP_ALIAS = PXT > 1;
+    static_assert(!EP_ALIAS || B_UNITS * 16 >= CONV_TH * 32 * EPS * 4, "aliased epilogue slices must fit one input buffer");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int tiles_per_cob = mp.ntx * mp.nty;
     const int total = mp.nconv * mp.ncob * tiles_per_cob;
-    const int stamps_on = __builtin_amdgcn_readfirstlane(g_conv_stamps_on);
+    const int dbg_all = __builtin_amdgcn_readfirstlane(g_conv_stamps_on);
+    const int stamps_on = dbg_all & 15;
+    const bool dbg_nostage = dbg_all & 16, dbg_nofrag = dbg_all & 32;   // timing experiments only (results are wrong)
 
     f32x4 b_reg[B_IT];
-    f32x4 w_reg[W_IT];
 
-    struct TileInfo { int conv, cob, x0, y0, tix; };
+    struct TileInfo { int conv, cob, x0, y0, tx, ty; };
     auto decode = [&](int tile) {
         const int cc = tile / tiles_per_cob, rem = tile - cc * tiles_per_cob;
         const int ty = rem / mp.ntx, tx = rem - ty * mp.ntx;
@@ -112,19 +127,19 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         ti.cob = cc - ti.conv * mp.ncob;
         ti.x0 = tx * CONV_TW;
         ti.y0 = ty * TH;
-        ti.tix = rem;
+        ti.tx = tx;
+        ti.ty = ty;
         return ti;
     };
     // Staging, global -> registers.  A cursor walks the phases: (tile, source, channel base); per tile it keeps each
     // thread's pixel offsets (they do not change over the K loop), per source the base pointer and pixel pitch, and
     // the weight slab pointer just advances.  Descriptor fields with a run-time conv / source index are therefore
     // read once per tile / source, not per phase (15 dependent s_loads per phase cost ~3 k cycles, stamps mode 3).
-    // stage_issue(j) issues load j; the loads of one phase are spread over the MFMA steps of the previous one.
     const int H = mp.h, W = mp.w;
     const float* st_base = nullptr;
     const f32x4* st_w = nullptr;
     int st_pix = 0, st_cb = 0, st_src = 0, st_conv = 0;
-    int st_pixoff[B_IT], st_off[B_IT];
+    int st_pixoff[B_IT];
     auto stage_begin_tile = [&](const TileInfo& ti) {
         st_conv = ti.conv;
         st_src = 0;
@@ -155,32 +170,36 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             st_pix = mp.c[st_conv].src_pix[st_src];
         }
     };
-    auto stage_offsets = [&]() {
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int e = tid + i * NTHR;
-            const int c8 = e % PER;                                 // float4 of the chunk
-            st_off[i] = st_pixoff[i] >= 0 ? st_pixoff[i] * st_pix + st_cb + c8 * 4 : -1;
+    // Loads of the cursor's phase.  issue_w(g, wbuf): 1 KiB per wave of the weight slab straight into LDS buffer `wbuf`
+    // (LDS-DMA: the packed image IS the LDS image, so no registers and no ds_write).  hipcc does not count an asm load:
+    // the wait is the explicit counted vmcnt in front of the publishing barrier.  issue_b(i): one activation float4 per
+    // lane into registers -- always exactly one load instruction (out-of-image pixels read a 16-B block of zeros), so
+    // that count is exact, and nothing touches the value before its store.
+    auto issue_w = [&](int g, int wbuf) {
+        const int e = tid + g * NTHR;
+        if (e < W_UNITS) {                                              // wave-uniform (W_UNITS is a multiple of 64)
+            const unsigned dst = __builtin_amdgcn_readfirstlane(
+                (unsigned)(uintptr_t)(smem + 2 * B_UNITS + wbuf * W_UNITS + g * NTHR + wave * 64));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(st_w + e), "s"(dst) : "memory");
         }
     };
-    auto stage_issue = [&](int j) {
-        if (j < B_IT) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (st_off[j] >= 0) v = *reinterpret_cast<const f32x4*>(st_base + st_off[j]);
-            b_reg[j] = v;
-        } else if (j < B_IT + W_IT) {
-            const int i = j - B_IT, e = tid + i * NTHR;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < W_UNITS) v = st_w[e];
-            w_reg[i] = v;
-        }
+    auto issue_b = [&](int i) {
+        const int e = tid + i * NTHR;
+        const int c8 = e % PER;                                         // float4 of the chunk
+        const int po = st_pixoff[i];
+        const float* src = po < 0 ? g_conv_zero16 : st_base + (po * st_pix + st_cb + c8 * 4);   // padding reads 16 B of zeros
+        b_reg[i] = *reinterpret_cast<const f32x4*>(src);
+    };
+    auto stage_issue = [&](int j, int wbuf) {
+        if (j < W_IT) issue_w(j, wbuf);
+        else if (j < W_IT + B_IT) issue_b(j - W_IT);
     };
     // registers -> LDS buffer `buf`, splitting the activations to (hi, lo) bf16
-    auto stage_store = [&](int buf) {
+    auto stage_store_item = [&](int i, int buf) {
         bf16x8* bl = smem + buf * B_UNITS;
-        f32x4* wl = reinterpret_cast<f32x4*>(smem + 2 * B_UNITS + buf * W_UNITS);
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
+        {
             const int e = tid + i * NTHR;
             if (e < B_ITEMS) {
                 const int pl = e / PER, c8 = e - pl * PER, q = c8 >> 1, sub = c8 & 1;   // q = kstep * 2 + khalf
@@ -196,30 +215,44 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 dst[B_PART * 2] = lo;
             }
         }
+    };
+    auto stage_store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < W_IT; ++i) {
-            const int e = tid + i * NTHR;
-            if (e < W_UNITS) wl[e] = w_reg[i];
-        }
+        for (int i = 0; i < B_IT; ++i) stage_store_item(i, buf);
     };
 
-    struct Frag { bf16x8 ah[NT], al[NT], bh, bl; };
+    struct Frag { bf16x8 ah[NT], al[NT], bh[PXT], bl[PXT]; };
 
     // diagnostics: accumulated section times of this wave (stamps mode 3): steps after the barrier (+ load issue) | steps before it | wait+split+store | barrier | epilogue
     long long sec[5] = {0, 0, 0, 0, 0};
-    long long t_prev = (stamps_on == 3) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-#define CV_MARK(i) do { if (stamps_on == 3) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); sec[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+    long long t_prev = (stamps_on >= 3) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define CV_MARK(i) do { if (stamps_on >= 3) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); sec[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     stamp(stamps_on, 0);
     stamp(stamps_on, 5);
 
+    if (dbg_all & 64) {                                      // experiment: stagger the workgroups so their epilogue bursts do not coincide
+        const long long t_end = (long long)__builtin_amdgcn_s_memtime() + 3000ll * ((blockIdx.x >> 3) & 3);
+        while ((long long)__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(4);
+    }
     // ---- software pipeline over the block's phases (tiles x chunks, walked linearly by the staging cursor) ----
     //   LDS buffer c%2 holds phase c.  While phase c computes: phase c+1 sits in (or is arriving into) the staging
     //   registers; at step SB it is split + stored to the other buffer, ONE barrier publishes it, the cursor moves to
     //   phase c+2 and its global loads are issued (a full phase of latency budget).  All fragment reads of phase c are
     //   issued before that barrier (they run two steps ahead), so the last two steps already read phase c+1's first
     //   fragments: the MFMA stream does not stop at phase or tile boundaries.
-    constexpr int SB = STEPS >= 2 ? STEPS - 2 : 0;           // the step whose fragment prefetch is the first of the next phase
+    constexpr int RING = PXT > 1 ? 2 : 3;                    // fragment sets in registers; reads run RING - 1 steps ahead
+    constexpr int LEAD = RING - 1;
+    constexpr int SB = STEPS >= LEAD ? STEPS - LEAD : 0;     // the step whose fragment prefetch is the first of the next phase
+    // FINE schedule (3x3): the staging traffic is spread over the steps, at most one store and two loads per wave and
+    // step -- issued in one burst after the barrier, the 8 waves queue 80 KiB on the CU's 64 B/clk address path and
+    // every wave stalls ~1.3 k cycles in front of its next MFMAs.  In phase c: steps 0 .. B_IT-1 split + store the
+    // activations of phase c+1 (loaded during phase c-1); steps LB0 .. load those of phase c+2; the weight DMA of phase
+    // c+2 starts right after barrier(c) (its LDS buffer is free from there) and continues in the first steps of c+1.
+    constexpr bool FINE = KS == 3;
+    constexpr int LB0 = STEPS - B_IT;                        // first activation-load step (the cursor advances there)
+    constexpr int NB = B_IT - LEAD;                          // activation loads younger than the last weight DMA at the barrier
+    static_assert(!FINE || (LB0 < SB && W_IT - LEAD <= LB0 && B_IT <= LB0 + 1), "FINE staging schedule");
     constexpr int N_LD = B_IT + W_IT;
     constexpr int LD_PER = (N_LD + (STEPS - SB) - 1) / (STEPS - SB);
     int st_tile = blockIdx.x, st_chunk = 0;
@@ -237,8 +270,11 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         const int tap = s / KSTEPS, ks = s - tap * KSTEPS;
         const int ky = tap / KS, kx = tap - ky * KS;
         const int bo = ks * 2 * NPX + ky * IC + kx;
-        f.bh = bbase[bo];
-        f.bl = bbase[B_PART + bo];
+#pragma unroll
+        for (int r = 0; r < PXT; ++r) {
+            f.bh[r] = bbase[bo + r * CONV_TH * IC];
+            f.bl[r] = bbase[B_PART + bo + r * CONV_TH * IC];
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f.ah[t] = abase[((s * NT + t) * 2 + 0) * 64];
@@ -249,83 +285,113 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     int tile = blockIdx.x;
     int buf = 0;
     bool pend = false;                                       // phase c+1 exists (staging registers hold / are receiving it)
-    Frag f[3];
+    Frag f[RING];
     if (tile < total) {
         stage_begin_tile(decode(tile));
-        stage_offsets();
 #pragma unroll
-        for (int j = 0; j < N_LD; ++j) stage_issue(j);
+        for (int j = 0; j < N_LD; ++j) stage_issue(j, 0);
         stage_store(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight DMA has landed
     }
     __syncthreads();
     if (tile < total) {
         pend = stage_next();
         if (pend) {
-            stage_offsets();
 #pragma unroll
-            for (int j = 0; j < N_LD; ++j) stage_issue(j);
+            for (int j = 0; j < N_LD; ++j)
+                if (!FINE || j >= W_IT || j < LEAD) stage_issue(j, 1);   // FINE: the rest of the weight DMA follows in phase 0's steps
         }
         load_frag(0, 0, f[0]);
-        if (STEPS > 1) load_frag(0, 1, f[1]);
+        if (LEAD > 1 && STEPS > 1) load_frag(0, 1, f[1]);
     }
     stamp(stamps_on, 1);
 
     for (; tile < total; tile += gridDim.x) {
         const TileInfo cur = decode(tile);
         const ConvParams& p = mp.c[cur.conv];
-        const int cob = cur.cob, x0 = cur.x0, y0 = cur.y0, tix = cur.tix;
+        const int cob = cur.cob, x0 = cur.x0, y0 = cur.y0;
 
-        f32x16 acc[NT];
+        f32x16 acc[PXT][NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int r = 0; r < PXT; ++r)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
 
         for (int chunk = 0; chunk < mp.nchunk; ++chunk) {
-            auto mma = [&](const Frag& fr) {                  // per accumulator: lo*hi, hi*lo, hi*hi (the order is part of the numerics)
+            // per accumulator: lo*hi, hi*lo, hi*hi (the order is part of the numerics), as three MFMA groups so that the
+            // staging work of a step can be issued BETWEEN them and run under matrix-pipe time (both waves of a SIMD leave
+            // the barrier in lockstep: work placed after the whole MFMA burst is serial to it)
+            auto mma_part = [&](const Frag& fr, int part) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.al[t], fr.bh, acc[t], 0, 0, 0);
+                for (int r = 0; r < PXT; ++r)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.ah[t], fr.bl, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.ah[t], fr.bh, acc[t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) {
+                        if (part == 0) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.al[t], fr.bh[r], acc[r][t], 0, 0, 0);
+                        if (part == 1) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.ah[t], fr.bl[r], acc[r][t], 0, 0, 0);
+                        if (part == 2) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.ah[t], fr.bh[r], acc[r][t], 0, 0, 0);
+                    }
             };
             bool pend2 = false;                               // phase c+2 exists (decided at the barrier)
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
+                if (FINE && s == LB0) pend2 = pend && stage_next();
                 if (s == SB) {
-                    if (stamps_on == 3) { asm volatile("" :: "v"(acc[0][0])); }
+                    if (stamps_on >= 3) { asm volatile("" :: "v"(acc[0][0][0])); }
                     CV_MARK(1);
-                    if (pend) stage_store(buf ^ 1);
+                    if (pend) {
+                        if (!FINE) stage_store(buf ^ 1);
+                        // the weight DMA of phase c+1 has landed (FINE: the NB activation loads of phase c+2 behind it may fly on)
+                        if (FINE && pend2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NB) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
                     CV_MARK(2);
                     __syncthreads();
                     CV_MARK(3);
-                    pend2 = pend && stage_next();
-                    if (pend2) stage_offsets();
+                    if (!FINE) pend2 = pend && stage_next();
                 }
-                if (s + 2 < STEPS) load_frag(buf, s + 2, f[(s + 2) % 3]);
-                else if (pend) load_frag(buf ^ 1, s + 2 - STEPS, f[(s + 2) % 3]);
+                if (dbg_nofrag) {
+                } else if (s + LEAD < STEPS) load_frag(buf, s + LEAD, f[(s + LEAD) % RING]);
+                else if (pend) load_frag(buf ^ 1, s + LEAD - STEPS, f[(s + LEAD) % RING]);
                 __builtin_amdgcn_sched_barrier(0);
-                mma(f[s % 3]);
+                // The two waves of a SIMD alternate issue priority step by step.  Left to the oldest-first arbiter, waves
+                // 0-3 run every step ahead, then idle ~2 k cycles per phase at the barrier while waves 4-7 finish alone
+                // (a lone wave cannot cover its own staging work with MFMAs): stamps, 80 k vs 99 k cycles of steps.
+                if (((s ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                mma_part(f[s % RING], 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (s >= SB && pend2) {
+                if (FINE && s < B_IT && pend && !dbg_nostage) stage_store_item(s, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_part(f[s % RING], 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (FINE && !dbg_nostage) {
+                    if (s < SB) {
+                        if (LEAD + s < W_IT && pend) issue_w(LEAD + s, buf ^ 1);
+                    } else {
+                        if (s - SB < W_IT && pend2) issue_w(s - SB, buf);
+                    }
+                    if (s >= LB0 && pend2) issue_b(s - LB0);
+                } else if (s >= SB && pend2) {
 #pragma unroll
-                    for (int j = (s - SB) * LD_PER; j < (s - SB + 1) * LD_PER && j < N_LD; ++j) stage_issue(j);
+                    for (int j = (s - SB) * LD_PER; j < (s - SB + 1) * LD_PER && j < N_LD; ++j) stage_issue(j, buf);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_part(f[s % RING], 2);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (STEPS % 3 != 0) {                             // keep the ring aligned: the next phase starts at slots 0, 1
-                const Frag n0 = f[STEPS % 3], n1 = f[(STEPS + 1) % 3];
+            if (STEPS % RING != 0) {                          // keep the ring aligned: the next phase starts at slots 0 ..
+                const Frag n0 = f[STEPS % RING], n1 = f[(STEPS + 1) % RING];
                 f[0] = n0;
-                f[1] = n1;
+                if (LEAD > 1) f[1] = n1;
             }
-            if (stamps_on == 3) { asm volatile("" :: "v"(acc[0][0])); }
+            if (stamps_on >= 3) { asm volatile("" :: "v"(acc[0][0][0])); }
             CV_MARK(0);
             if (chunk == 0 && tile == (int)blockIdx.x) stamp(stamps_on, 2);
             pend = pend2;
             buf ^= 1;
         }
         if (tile == (int)blockIdx.x) stamp(stamps_on, 3);
-        const int ty_tx = tix;
 
         // ---- epilogue: transpose through the wave's private LDS slice, 32 channels at a time ----------------
         // The descriptor fields are read ONCE per tile into pinned scalars: left to the compiler, every use below
@@ -340,18 +406,102 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         asm volatile("" : "+s"(e_bias), "+s"(e_mul), "+s"(e_r1), "+s"(e_r2), "+s"(e_out));
         asm volatile("" : "+s"(e_act), "+s"(e_opix), "+s"(e_r1pix), "+s"(e_r2pix), "+s"(e_slope), "+s"(e_r2s));
         const int COUT = mp.cout;
+        float* ep_base = reinterpret_cast<float*>(EP_ALIAS ? smem + (buf ^ 1) * B_UNITS : smem + 2 * B_UNITS + 2 * W_UNITS);
         float* ep = ep_base + wave * (32 * EPS);
-        const int y = y0 + wave;
         const int c4 = lane & 7;                                // lane l always handles channel quad l % 8
-        f32x4 psum[NT];
+        f32x4 psum[PXT][NT];
+        // Interior tiles (all but the image's last band / column and a partial channel block) take a path without
+        // per-unit bounds tests and with one activation / residual branch per 32-channel group instead of per unit
+        // (the epilogue's ~10 scalar branches per unit were a third of its time).
+        const bool chan_full = (cob + 1) * COT <= COUT;       // the 16-row variant is only launched with cout % 64 == 0
+        const bool x_inside = x0 + CONV_TW <= W;
+        if (PXT > 1 || chan_full) {
+#pragma unroll
+            for (int r = 0; r < PXT; ++r) {
+                const int y = y0 + wave + CONV_TH * r;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) psum[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (y >= H) continue;                                                    // wave-uniform
+                const int pbase = y * W + x0 + (lane >> 3);                              // unit i is pixel pbase + 8 i
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {acc[r][t][4 * g], acc[r][t][4 * g + 1], acc[r][t][4 * g + 2], acc[r][t][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(ep + px * EPS + 8 * g + 4 * half) = v;
+                    }
+                    const int co = cob * COT + 32 * t + 4 * c4;
+                    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                    if (e_bias) b4 = *reinterpret_cast<const f32x4*>(e_bias + co);
+                    f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ih = 0; ih < 2; ++ih) {                  // two units (pixels pbase + 16 ih, + 8) at a time: register budget
+                        const int p0 = pbase + 16 * ih;
+                        const bool ok0 = x_inside || x0 + (lane >> 3) + 16 * ih < W, ok1 = x_inside || x0 + (lane >> 3) + 16 * ih + 8 < W;
+                        f32x4 v[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ep + ((lane >> 3) + 16 * ih + 8 * i) * EPS + 4 * c4);
+                            v[i] = f32x4{a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
+                        }
+                        if (e_act == SAVSR_ACT_RELU) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[i][q] = fmaxf(v[i][q], 0.f);
+                        } else if (e_act == SAVSR_ACT_LRELU) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[i][q] = v[i][q] > 0.f ? v[i][q] : v[i][q] * e_slope;
+                        } else if (e_act == SAVSR_ACT_SIGMOID) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[i][q] = sigmoidf_(v[i][q]);
+                        }
+                        if (e_mul) {
+                            const float m0 = ok0 ? e_mul[p0] : 0.f, m1 = ok1 ? e_mul[p0 + 8] : 0.f;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { v[0][q] *= m0; v[1][q] *= m1; }
+                        }
+                        if (e_r1) {
+                            f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+                            if (ok0) ra = ldg4(e_r1, 4u * (unsigned)(p0 * e_r1pix + co));
+                            if (ok1) rb = ldg4(e_r1, 4u * (unsigned)((p0 + 8) * e_r1pix + co));
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { v[0][q] += ra[q]; v[1][q] += rb[q]; }
+                        }
+                        if (e_r2) {
+                            f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+                            if (ok0) ra = ldg4(e_r2, 4u * (unsigned)(p0 * e_r2pix + co));
+                            if (ok1) rb = ldg4(e_r2, 4u * (unsigned)((p0 + 8) * e_r2pix + co));
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { v[0][q] += e_r2s * ra[q]; v[1][q] += e_r2s * rb[q]; }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            if (i == 0 ? ok0 : ok1) {
+                                stg4(e_out, 4u * (unsigned)((p0 + 8 * i) * e_opix + co), v[i]);
+                                ps[0] += v[i][0]; ps[1] += v[i][1]; ps[2] += v[i][2]; ps[3] += v[i][3];
+                            }
+                        }
+                    }
+                    psum[r][t] = ps;
+                }
+            }
+        } else if constexpr (PXT == 1) {
+#pragma unroll
+        for (int r = 0; r < PXT; ++r) {
+        const int y = y0 + wave + CONV_TH * r;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                const f32x4 v = {acc[r][t][4 * g], acc[r][t][4 * g + 1], acc[r][t][4 * g + 2], acc[r][t][4 * g + 3]};
                 *reinterpret_cast<f32x4*>(ep + px * EPS + 8 * g + 4 * half) = v;
             }
-            psum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            psum[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int co = cob * COT + 32 * t + 4 * c4;
             const bool full = co + 3 < COUT;
             float b4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -386,73 +536,85 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] *= mul;
                 }
-                float* o = e_out + (long long)pidx * e_opix + co;
+                float* o = e_out + (unsigned)(pidx * e_opix + co);
                 if (full) {
                     if (e_r1) {
-                        const f32x4 r = *reinterpret_cast<const f32x4*>(e_r1 + (long long)pidx * e_r1pix + co);
+                        const f32x4 r = ldg4(e_r1, 4u * (unsigned)(pidx * e_r1pix + co));
                         v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
                     }
                     if (e_r2) {
-                        const f32x4 r = *reinterpret_cast<const f32x4*>(e_r2 + (long long)pidx * e_r2pix + co);
+                        const f32x4 r = ldg4(e_r2, 4u * (unsigned)(pidx * e_r2pix + co));
                         v[0] += e_r2s * r[0]; v[1] += e_r2s * r[1]; v[2] += e_r2s * r[2]; v[3] += e_r2s * r[3];
                     }
                     const f32x4 ov = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(o) = ov;
-                    psum[t][0] += v[0]; psum[t][1] += v[1]; psum[t][2] += v[2]; psum[t][3] += v[3];
+                    stg4(e_out, 4u * (unsigned)(pidx * e_opix + co), ov);
+                    psum[r][t][0] += v[0]; psum[r][t][1] += v[1]; psum[r][t][2] += v[2]; psum[r][t][3] += v[3];
                 } else {
                     for (int q = 0; q < 4 && co + q < COUT; ++q) {
                         float vv = v[q];
-                        if (e_r1) vv += e_r1[(long long)pidx * e_r1pix + co + q];
-                        if (e_r2) vv += e_r2s * e_r2[(long long)pidx * e_r2pix + co + q];
+                        if (e_r1) vv += e_r1[(unsigned)(pidx * e_r1pix + co + q)];
+                        if (e_r2) vv += e_r2s * e_r2[(unsigned)(pidx * e_r2pix + co + q)];
                         o[q] = vv;
                     }
                 }
             }
         }
+        }
+        }
         CV_MARK(4);
         if (p.pool) {
             // AdaptiveAvgPool2d(1) of the tensor just produced (savsr_arch.py:146,515), fused: lanes with equal
             // l % 8 hold the same channel quad -> butterfly over the 8 pixel groups, then the waves are summed in
-            // wave order through LDS (deterministic) and ONE row per tile is written.
+            // wave order through LDS (deterministic) and one row per 8-row band of the tile is written (the row
+            // numbering of savsr_conv_pool_blocks does not depend on the kernel variant).
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int r = 0; r < PXT; ++r)
 #pragma unroll
-                for (int o = 8; o < 64; o <<= 1) {
-                    psum[t][0] += __shfl_xor(psum[t][0], o, 64); psum[t][1] += __shfl_xor(psum[t][1], o, 64);
-                    psum[t][2] += __shfl_xor(psum[t][2], o, 64); psum[t][3] += __shfl_xor(psum[t][3], o, 64);
-                }
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) {
+                        psum[r][t][0] += __shfl_xor(psum[r][t][0], o, 64); psum[r][t][1] += __shfl_xor(psum[r][t][1], o, 64);
+                        psum[r][t][2] += __shfl_xor(psum[r][t][2], o, 64); psum[r][t][3] += __shfl_xor(psum[r][t][3], o, 64);
+                    }
             __syncthreads();                         // every wave is done with its transpose slice
             float* pl_ = ep_base;
             if (lane < 8)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(pl_ + wave * COT + 32 * t + 4 * lane) = psum[t];
+                for (int r = 0; r < PXT; ++r)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(pl_ + (r * CONV_TH + wave) * COT + 32 * t + 4 * lane) = psum[r][t];
             __syncthreads();
-            if (tid < COT) {
+            if (tid < COT * PXT) {
+                const int r = tid / COT, ch = tid - r * COT;
                 float sacc = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < TH; ++wv) sacc += pl_[wv * COT + tid];
-                if (cob * COT + tid < mp.cout) p.pool[(long long)ty_tx * p.pool_stride + cob * COT + tid] = sacc;
+                for (int wv = 0; wv < CONV_TH; ++wv) sacc += pl_[(r * CONV_TH + wv) * COT + ch];
+                const int band = cur.ty * PXT + r;                       // 8-row band of the image
+                if (cob * COT + ch < COUT && band * CONV_TH < H)
+                    p.pool[(long long)(band * mp.ntx + cur.tx) * p.pool_stride + cob * COT + ch] = sacc;
             }
             __syncthreads();                         // the slices are reused by the next tile's epilogue
+        } else if (EP_ALIAS) {
+            __syncthreads();                         // the aliased slices become a staging buffer again
         }
     }
     if (stamps_on == 1) {
         __builtin_amdgcn_s_waitcnt(0);              // diagnostics: include the store drain in the last stamp
         stamp(stamps_on, 4);
     }
-    if (stamps_on == 3 && tid == 0 && blockIdx.x < STAMP_BLOCKS)
+    if (stamps_on >= 3 && tid == (stamps_on - 3) * 64 && blockIdx.x < STAMP_BLOCKS)   // mode 3 + w: sections of wave w
         for (int i = 0; i < 5; ++i) g_conv_stamps[blockIdx.x * STAMP_N + i] = sec[i];
 }
 
-template <int KS, int NT>
+template <int KS, int NT, int PXT>
 static int launch_conv(const MultiConvParams& mp, hipStream_t st) {
     constexpr int TAPS = KS * KS, HALO = KS / 2, KC = conv_kc(KS), KSTEPS = KC / 16;
-    constexpr int NPX = (CONV_TH + 2 * HALO) * (CONV_TW + 2 * HALO);
-    constexpr size_t lds = 16ull * 2 * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64) + 4ull * CONV_TH * 32 * 36;
+    constexpr int NPX = (CONV_TH * PXT + 2 * HALO) * (CONV_TW + 2 * HALO);
+    constexpr size_t lds = 16ull * 2 * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64) + (PXT > 1 ? 0ull : 4ull * CONV_TH * 32 * 36);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;      // benign race: idempotent attribute set
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("conv: hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds, hipGetErrorString(e));
@@ -462,7 +624,7 @@ static int launch_conv(const MultiConvParams& mp, hipStream_t st) {
     }
     const int total = mp.nconv * mp.ncob * mp.ntx * mp.nty;
     const int grid = total < CONV_PERSISTENT_BLOCKS ? total : CONV_PERSISTENT_BLOCKS;   // one resident workgroup per CU
-    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT>), dim3(grid), dim3(64 * CONV_TH), lds, st, mp);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, PXT>), dim3(grid), dim3(64 * CONV_TH), lds, st, mp);
     return check_launch("conv_bf16x3_kernel");
 }
 
@@ -535,6 +697,13 @@ static int fill_params(const savsr_conv_desc* d, ConvParams& p) {
     p.out = d->out; p.out_pix = d->out_pix;
     p.pool = d->pool; p.pool_stride = d->pool_stride;
     if (d->pool && (d->cout % 4 || d->pool_stride < d->cout)) return fail_arg("conv: pool needs cout % 4 == 0 and pool_stride >= cout");
+    {   // the kernel addresses every tensor with 32-bit offsets
+        int64_t max_pix = d->out_pix;
+        for (int i = 0; i < d->nsrc; ++i) max_pix = d->src_pix[i] > max_pix ? d->src_pix[i] : max_pix;
+        if (d->res1 && d->res1_pix > max_pix) max_pix = d->res1_pix;
+        if (d->res2 && d->res2_pix > max_pix) max_pix = d->res2_pix;
+        if ((int64_t)d->h * d->w * max_pix * 4 >= (int64_t)1 << 31) return fail_arg("conv: tensors of 2 GiB or more are not supported");
+    }
     return 0;
 }
 
@@ -562,8 +731,18 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
     mp.nty = (d->h + CONV_TH - 1) / CONV_TH;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool wide = cot == 64;
-    if (d->ksize == 3) return wide ? launch_conv<3, 2>(mp, st) : launch_conv<3, 1>(mp, st);
-    return wide ? launch_conv<1, 2>(mp, st) : launch_conv<1, 1>(mp, st);
+    if (d->ksize == 3 && wide) {
+        // 16-row tiles (each wave 64 channels x 2 rows: one weight-fragment read feeds two pixel rows, 2/3 of the LDS
+        // traffic per MFMA and half the barriers) once they still fill the chip; 8-row tiles for small launches
+        const int nty2 = (d->h + 2 * CONV_TH - 1) / (2 * CONV_TH);
+        if (d->cout % 64 == 0 && n * mp.ncob * mp.ntx * nty2 >= CONV_WIDE_MIN_TILES) {
+            mp.nty = nty2;
+            return launch_conv<3, 2, 2>(mp, st);
+        }
+        return launch_conv<3, 2, 1>(mp, st);
+    }
+    if (d->ksize == 3) return launch_conv<3, 1, 1>(mp, st);
+    return wide ? launch_conv<1, 2, 1>(mp, st) : launch_conv<1, 1, 1>(mp, st);
 }
 
 extern "C" int savsr_conv2d(const savsr_conv_desc* d, void* stream) { return savsr_conv2d_batch(d, 1, stream); }

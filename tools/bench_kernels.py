@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--h", type=int, default=180)
     ap.add_argument("--w", type=int, default=320)
+    ap.add_argument("--batch", type=int, default=1, help="conv: convs per launch (savsr_conv2d_batch)")
     ap.add_argument("--stamps", action="store_true", help="conv / satu: print per-workgroup section timings (s_memtime)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -38,9 +39,10 @@ def main():
         weights = (E.pack_conv_weight(wt).to(dev), torch.randn(a.cout, generator=g).to(dev), a.cout, a.cin, a.ks)
         nsrc = max(1, a.cin // 64)
         xs = [torch.randn(h, w, a.cin // nsrc, generator=g).to(dev) for _ in range(nsrc)]
-        out = torch.empty(h, w, a.cout, device=dev)
-        run = lambda: eng.conv("bench", [eng.full(x) for x in xs], eng.full(out), h, w, ACT_LRELU, 0.2, weights=weights)
-        flop = 2.0 * a.cin * a.cout * a.ks * a.ks * h * w
+        outs = [torch.empty(h, w, a.cout, device=dev) for _ in range(a.batch)]
+        descs = [eng.conv_desc("bench", [eng.full(x) for x in xs], eng.full(o), h, w, ACT_LRELU, 0.2, weights=weights) for o in outs]
+        run = lambda: eng.conv_launch(descs)
+        flop = 2.0 * a.batch * a.cin * a.cout * a.ks * a.ks * h * w
     elif a.what == "satu":
         g = torch.Generator().manual_seed(0)
         x, st = torch.randn(h, w, 64, generator=g).to(dev), torch.randn(h, w, 64, generator=g).to(dev)
@@ -74,7 +76,7 @@ def main():
         eng.lib.savsr_debug_conv_stamps(1)
         run()
         torch.cuda.synchronize()
-        nb = min(256, ((w + 31) // 32) * ((h + 7) // 8))
+        nb = min(256, a.batch * ((w + 31) // 32) * ((h + 7) // 8))
         buf = (C.c_longlong * (6 * nb))()
         eng.lib.savsr_debug_read_conv_stamps(buf, nb)
         eng.lib.savsr_debug_conv_stamps(0)
@@ -82,13 +84,28 @@ def main():
         d = np.diff(st[:, :5], axis=1)
         print("stamps (shader cycles, median over workgroups): first staging %d  phase0 %d  rest of the first tile K loop %d  later tiles + epilogues + drain %d  total %d" %
               tuple(np.median(d, axis=0).tolist() + [np.median(st[:, 4] - st[:, 0])]))
-        eng.lib.savsr_debug_conv_stamps(3)
-        run()
-        torch.cuda.synchronize()
-        eng.lib.savsr_debug_read_conv_stamps(buf, nb)
-        eng.lib.savsr_debug_conv_stamps(0)
-        s3 = np.array(buf[:], dtype=np.int64).reshape(nb, 6)[:, :5]
-        print("wave-0 section cycles summed over the K phases (median): steps after the barrier (+ global load issue) %d | steps before the barrier %d | wait + split + LDS store %d | barrier %d | epilogue %d" % tuple(np.median(s3, axis=0).tolist()))
+        for wv in (0, 3, 4, 7):
+            eng.lib.savsr_debug_conv_stamps(3 + wv)
+            run()
+            torch.cuda.synchronize()
+            eng.lib.savsr_debug_read_conv_stamps(buf, nb)
+            eng.lib.savsr_debug_conv_stamps(0)
+            s3 = np.array(buf[:], dtype=np.int64).reshape(nb, 6)[:, :5]
+            print("wave-%d section cycles summed over the phases (median): steps after the barrier (+ staging issue) %d | steps before the barrier %d | wait %d | barrier %d | epilogue %d"
+                  % tuple([wv] + np.median(s3, axis=0).tolist()))
+        for flag, name in ((16, "no staging"), (32, "no fragment reads"), (48, "MFMAs only"), (64, "staggered start")):
+            eng.lib.savsr_debug_conv_stamps(7 + flag)
+            run()
+            torch.cuda.synchronize()
+            eng.lib.savsr_debug_read_conv_stamps(buf, nb)
+            s3 = np.array(buf[:], dtype=np.int64).reshape(nb, 6)[:, :5]
+            ev0.record()
+            for _ in range(5):
+                run()
+            ev1.record()
+            torch.cuda.synchronize()
+            eng.lib.savsr_debug_conv_stamps(0)
+            print("experiment (%s; results invalid): %.2f us/iter; wave-4 sections %s" % (name, 1e3 * ev0.elapsed_time(ev1) / 5, np.median(s3, axis=0).astype(int).tolist()))
         rt = st[:, 5]
         print("workgroup start spread (100 MHz ticks): min %d max %d -> %.2f us" % (rt.min(), rt.max(), (rt.max() - rt.min()) / 100.0))
     if a.stamps and a.what == "satu":
