@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 7
+#define SAVSR_ABI_VERSION 9
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -143,6 +143,9 @@ typedef struct savsr_osconv_attn_desc {
     float* att;                              /* optional [cin + cout + 9 + knum] = ca | fa | sa | ka */
 } savsr_osconv_attn_desc;
 int savsr_osconv_weights(const savsr_osconv_attn_desc* d, void* stream);
+/* n (1..6) independent OSConvs of identical cin / cout / hidden / knum in one set of launches (the two
+ * propagation directions of a ResidualBlock pair, savsr_arch.py:399-415). */
+int savsr_osconv_weights_batch(const savsr_osconv_attn_desc* descs, int n, void* stream);
 
 /* RCAN ChannelAttention gate (savsr_arch.py:514-520): gate = sigmoid(W2 ReLU(W1 mean + b1) + b2) */
 int savsr_se_gate(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
@@ -219,13 +222,19 @@ int savsr_tail_residual(const float* feat, int64_t feat_plane, const float* tail
                         const float* center, int h, int w, int H, int W, float* out, void* stream);
 
 /* ---- diagnostics (synchronous, never called by the product path) ----------------------------
- * Per-workgroup s_memtime stamps of the conv kernel: [blk][6] = entry, after prologue, after the
- * first K phase, after the K loop, after the stores drained, s_memrealtime at entry. */
+ * Conv kernel, savsr_debug_conv_stamps(mode): 0 off; 1 per-workgroup s_memtime stamps [blk][6] = entry, after
+ * the prologue, after the first K phase, after the first tile's K loop, after the stores drained,
+ * s_memrealtime at entry; 3 + w: accumulated section times of wave w ([blk][0..4] = steps after the barrier,
+ * steps before it, wait, barrier, epilogue); + 16 / + 32: timing experiments that skip the staging / the
+ * fragment reads (results invalid). */
 int savsr_debug_conv_stamps(int enable);
 int savsr_debug_read_conv_stamps(long long* host, int nblocks);
 /* SATU LR / HR kernels: [blk][8] accumulated section times of wave 0 (see satu.hip), last = total. */
 int savsr_debug_satu_stamps(int enable);
 int savsr_debug_read_satu_stamps(long long* host, int nblocks);
+/* Resident workgroups per CU predicted by the runtime for the SATU HR (which = 0) / LR (1) kernel with
+ * lds_bytes of dynamic LDS; < 0 = -hipError_t. */
+int savsr_debug_satu_occupancy(int which, int lds_bytes);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 7
+ABI_VERSION = 9
 
 fptr = C.c_void_p   # raw device pointers travel as integers
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     "savsr_conv2d_batch": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "savsr_channel_sums": (C.c_int, [C.POINTER(fptr), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int64, C.c_int, fptr, C.c_void_p]),
     "savsr_osconv_weights": (C.c_int, [C.POINTER(OSConvAttnDesc), C.c_void_p]),
+    "savsr_osconv_weights_batch": (C.c_int, [C.POINTER(OSConvAttnDesc), C.c_int, C.c_void_p]),
     "savsr_se_gate": (C.c_int, [fptr, C.c_int, C.c_float, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, C.c_void_p]),
     "savsr_scale_residual": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int64, C.c_void_p]),
     "savsr_avgpool2": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "savsr_debug_conv_stamps": (C.c_int, [C.c_int]),
     "savsr_debug_satu_stamps": (C.c_int, [C.c_int]),
     "savsr_debug_read_satu_stamps": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
+    "savsr_debug_satu_occupancy": (C.c_int, [C.c_int, C.c_int]),
     "savsr_debug_read_conv_stamps": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
     "savsr_tail_residual": (C.c_int, [fptr, C.c_int64, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
 }

@@ -56,26 +56,33 @@ __device__ __forceinline__ float wave_dot(const float* __restrict__ w, const flo
     return wave_sum(acc);
 }
 
+// Up to OSC_MAX_BATCH OSConvs of identical geometry per launch (blockIdx.y picks one): the two propagation
+// directions' OSConvs are independent, and these kernels are launch/latency-bound (a few dozen workgroups each).
+constexpr int OSC_MAX_BATCH = 6;
+struct OscBatch { savsr_osconv_attn_desc d[OSC_MAX_BATCH]; };
+constexpr int OSC_PARTS = 32;      // interleaved row slices of the pooled-sum reduction
+
 // scale routing layer 1 (savsr_arch.py:123-125,143-146): v1 = ReLU(L1 [1/sh, 1/sw, mean] + c1)
-__global__ __launch_bounds__(512) void osconv_l1_kernel(const savsr_osconv_attn_desc d) {
-    extern __shared__ float v0[];           // [cin + 2] then scratch [8][cin]
+__global__ __launch_bounds__(512) void osconv_l1_kernel(const OscBatch bt) {
+    const savsr_osconv_attn_desc& d = bt.d[blockIdx.y];
+    extern __shared__ float v0[];           // [cin + 2] then scratch [OSC_PARTS][cin]
     float* scr = v0 + d.cin + 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { v0[0] = d.inv_sh; v0[1] = d.inv_sw; }
-    // pooled mean from the block-ordered partial sums: 8 interleaved slices per channel, then a
-    // fixed-order 8-way add (deterministic)
-    for (int i = tid; i < d.cin * 8; i += 512) {
+    // pooled mean from the block-ordered partial sums: OSC_PARTS interleaved row slices per channel (short, fully
+    // unrolled chains of independent loads), then a fixed-order add over the slices (deterministic)
+    for (int i = tid; i < d.cin * OSC_PARTS; i += 512) {
         const int c = i % d.cin, part = i / d.cin;
         float s = 0.f;
 #pragma unroll 8
-        for (int b = part; b < d.nblk; b += 8) s += d.partial[(long long)b * d.cin + c];
+        for (int b = part; b < d.nblk; b += OSC_PARTS) s += d.partial[(long long)b * d.cin + c];
         scr[part * d.cin + c] = s;
     }
     __syncthreads();
     for (int c = tid; c < d.cin; c += 512) {
         float s = 0.f;
 #pragma unroll
-        for (int part = 0; part < 8; ++part) s += scr[part * d.cin + c];
+        for (int part = 0; part < OSC_PARTS; ++part) s += scr[part * d.cin + c];
         v0[2 + c] = s * d.inv_n;
     }
     __syncthreads();
@@ -86,7 +93,8 @@ __global__ __launch_bounds__(512) void osconv_l1_kernel(const savsr_osconv_attn_
 }
 
 // scale routing layer 2 (savsr_arch.py:126-127): v2 = ReLU(L2 v1 + c2)
-__global__ __launch_bounds__(512) void osconv_l2_kernel(const savsr_osconv_attn_desc d) {
+__global__ __launch_bounds__(512) void osconv_l2_kernel(const OscBatch bt) {
+    const savsr_osconv_attn_desc& d = bt.d[blockIdx.y];
     extern __shared__ float v1[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 2 * d.cin; i += 512) v1[i] = d.v1[i];
@@ -101,7 +109,8 @@ __global__ __launch_bounds__(512) void osconv_l2_kernel(const savsr_osconv_attn_
 // then  W''[co][ci][tap] = fa[co] ca[ci] sa[tap] sum_k ka[k] W[k][co][ci][tap]  (:156-163,171
 // folded, :148-149) for this workgroup's slice, split to (hi, lo) bf16 and written in the conv
 // weight-image order.
-__global__ __launch_bounds__(512) void osconv_aggregate_kernel(const savsr_osconv_attn_desc d) {
+__global__ __launch_bounds__(512) void osconv_aggregate_kernel(const OscBatch bt) {
+    const savsr_osconv_attn_desc& d = bt.d[blockIdx.y];
     extern __shared__ float sm[];
     float* v2 = sm;                        // [cin]
     float* a = v2 + d.cin;                 // [hidden]
@@ -179,25 +188,27 @@ __global__ __launch_bounds__(512) void osconv_aggregate_kernel(const savsr_oscon
     img[group * 128 + 64 + ln] = lo;
 }
 
-// RCAN ChannelAttention MLP (savsr_arch.py:514-520); one workgroup of 256 threads.
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
+// RCAN ChannelAttention MLP (savsr_arch.py:514-520); one workgroup of 1024 threads (latency-bound: the pooled-sum
+// reduction runs as 16 short interleaved row slices per channel).
+constexpr int SE_PARTS = 16;
+__global__ __launch_bounds__(1024) void se_gate_kernel(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
                                                      const float* w2, const float* b2, int c, int cmid, float* gate) {
-    __shared__ float scr[8 * 128];
+    __shared__ float scr[SE_PARTS * 128];
     __shared__ float m[128];
     __shared__ float z[64];
     const int t = threadIdx.x;
-    for (int i = t; i < c * 8; i += 256) {
+    for (int i = t; i < c * SE_PARTS; i += 1024) {
         const int ch = i % c, part = i / c;
         float s = 0.f;
 #pragma unroll 8
-        for (int b = part; b < nblk; b += 8) s += partial[(long long)b * c + ch];
+        for (int b = part; b < nblk; b += SE_PARTS) s += partial[(long long)b * c + ch];
         scr[part * c + ch] = s;
     }
     __syncthreads();
-    for (int ch = t; ch < c; ch += 256) {
+    for (int ch = t; ch < c; ch += 1024) {
         float s = 0.f;
 #pragma unroll
-        for (int part = 0; part < 8; ++part) s += scr[part * c + ch];
+        for (int part = 0; part < SE_PARTS; ++part) s += scr[part * c + ch];
         m[ch] = s * inv_n;
     }
     __syncthreads();
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* partial, int 
         z[t] = fmaxf(acc, 0.f);
     }
     __syncthreads();
-    for (int o = t; o < c; o += 256) {
+    for (int o = t; o < c; o += 1024) {
         float acc = b2[o];
         for (int k = 0; k < cmid; ++k) acc += w2[o * cmid + k] * z[k];
         gate[o] = sigmoidf_(acc);
@@ -247,8 +258,7 @@ extern "C" int savsr_channel_sums(const float* const* src, const int32_t* src_pi
     return check_launch("channel_sums_kernel");
 }
 
-extern "C" int savsr_osconv_weights(const savsr_osconv_attn_desc* d, void* stream) {
-    if (!d) return fail_arg("osconv_weights: null descriptor");
+static int check_osconv_desc(const savsr_osconv_attn_desc* d) {
     if (d->cin < 16 || (d->cin % 16) || d->cout < 1 || d->hidden < 1 || d->knum < 1 || d->knum > 64 || d->nblk < 1)
         return fail_arg("osconv_weights: shape (cin multiple of 16)");
     if (!d->partial || !d->l1_w || !d->l1_b || !d->l2_w || !d->l2_b || !d->fc_w || !d->bn_scale || !d->bn_shift || !d->ch_w ||
@@ -259,23 +269,42 @@ extern "C" int savsr_osconv_weights(const savsr_osconv_attn_desc* d, void* strea
         set_error("osconv_weights: bank / wimg_out must be 16-byte aligned");
         return SAVSR_E_ALIGN;
     }
+    return 0;
+}
+
+extern "C" int savsr_osconv_weights_batch(const savsr_osconv_attn_desc* descs, int n, void* stream) {
+    if (!descs) return fail_arg("osconv_weights: null descriptor");
+    if (n < 1 || n > OSC_MAX_BATCH) return fail_arg("osconv_weights: batch size must be 1..6");
+    OscBatch bt;
+    for (int i = 0; i < n; ++i) {
+        const int rc = check_osconv_desc(descs + i);
+        if (rc) return rc;
+        if (descs[i].cin != descs[0].cin || descs[i].cout != descs[0].cout || descs[i].hidden != descs[0].hidden ||
+            descs[i].knum != descs[0].knum || descs[i].nunits != descs[0].nunits)
+            return fail_arg("osconv_weights: all OSConvs of a batch must share cin / cout / hidden / knum");
+        bt.d[i] = descs[i];
+    }
+    for (int i = n; i < OSC_MAX_BATCH; ++i) bt.d[i] = descs[0];
+    const savsr_osconv_attn_desc* d = descs;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(osconv_l1_kernel, dim3((2 * d->cin + 7) / 8), dim3(512), sizeof(float) * (9 * d->cin + 2), st, *d);
+    hipLaunchKernelGGL(osconv_l1_kernel, dim3((2 * d->cin + 7) / 8, n), dim3(512), sizeof(float) * ((OSC_PARTS + 1) * d->cin + 2), st, bt);
     int rc = check_launch("osconv_l1_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(osconv_l2_kernel, dim3((d->cin + 7) / 8), dim3(512), sizeof(float) * 2 * d->cin, st, *d);
+    hipLaunchKernelGGL(osconv_l2_kernel, dim3((d->cin + 7) / 8, n), dim3(512), sizeof(float) * 2 * d->cin, st, bt);
     rc = check_launch("osconv_l2_kernel");
     if (rc) return rc;
     const size_t lds = sizeof(float) * ((size_t)d->cin + d->hidden + d->cin + d->cout + 9 + d->knum);
-    hipLaunchKernelGGL(osconv_aggregate_kernel, dim3((unsigned)((d->nunits + 511) / 512)), dim3(512), lds, st, *d);
+    hipLaunchKernelGGL(osconv_aggregate_kernel, dim3((unsigned)((d->nunits + 511) / 512), n), dim3(512), lds, st, bt);
     return check_launch("osconv_aggregate_kernel");
 }
+
+extern "C" int savsr_osconv_weights(const savsr_osconv_attn_desc* d, void* stream) { return savsr_osconv_weights_batch(d, 1, stream); }
 
 extern "C" int savsr_se_gate(const float* partial, int nblk, float inv_n, const float* w1, const float* b1, const float* w2,
                              const float* b2, int c, int cmid, float* gate, void* stream) {
     if (!partial || !w1 || !b1 || !w2 || !b2 || !gate) return fail_arg("se_gate: null pointer");
     if (c < 1 || c > 128 || cmid < 1 || cmid > 64 || nblk < 1) return fail_arg("se_gate: shape");
-    hipLaunchKernelGGL(se_gate_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partial, nblk, inv_n, w1, b1, w2, b2, c, cmid, gate);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), partial, nblk, inv_n, w1, b1, w2, b2, c, cmid, gate);
     return check_launch("se_gate_kernel");
 }
 

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
 // (half 0 / half 1) per pixel, each owning 32 of the 64 output channels in MFMA accumulator
 // order.  grid_sample (zeros padding, align_corners=True) semantics of savsr_arch.py:262-295.
 //
-// A workgroup (4 waves) owns an HR tile of TY rows x 32*TXW columns and first stages the LRcat
+// A workgroup (HR_WAVES waves) owns an HR tile of TY rows x 32*TXW columns and first stages the LRcat
 // records its taps can touch (tile footprint + the offset range of the phase table) into LDS
 // with a 656-B record pitch (conflict-free b128 reads).  A wave whose 8 taps all fall inside the
 // staged window gathers from LDS (256 B/clk/CU); any other wave -- and every wave when the
@@ -427,10 +427,12 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
     }
 }
 
-__global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
+constexpr int HR_WAVES = 4;       // waves per workgroup (the kernel needs ~250 VGPRs: 2 waves per SIMD; at 128 it spills 516 B and runs 3.6x slower)
+__global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int X0 = blockIdx.x * 32 * p.txw, Y0 = blockIdx.y * p.ty;
+    const long long t_entry = SATU_T();
 
     // ---- stage the LRcat window of this tile, the expert-MFMA A operands, the bias and the phase table -------
     float* cst = lds + p.lrh * p.lrw * HR_LDS_REC;
@@ -440,37 +442,28 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
         const float bx = ((p.gxn[X0 < p.W ? X0 : p.W - 1] + 1.f) / 2.f) * (float)(p.w - 1) + p.omin_x - 0.01f;
         ly0 = (int)floorf(fminf(fmaxf(by, 0.f), (float)(p.h - 1)));
         lx0 = (int)floorf(fminf(fmaxf(bx, 0.f), (float)(p.w - 1)));
-        // six 16-B loads per thread in flight before their LDS writes (a load -> store loop pays one global
-        // latency per iteration: the staging used to be half of this kernel's time)
-        const int nunit = p.lrh * p.lrw * (REC / 4);
-        for (int base = 0; base < nunit; base += 256 * 6) {
-            f32x4 v[6];
-            int dst[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int e = base + tid + i * 256;
-                dst[i] = -1;
-                if (e < nunit) {
-                    const int r = e / (REC / 4), u = e - r * (REC / 4);
-                    const int ry = r / p.lrw, rx = r - ry * p.lrw;
-                    const int gy = ly0 + ry, gx = lx0 + rx;
-                    if (gy < p.h && gx < p.w) {
-                        v[i] = *reinterpret_cast<const f32x4*>(p.lrcat + ((long long)gy * p.w + gx) * REC + 4 * u);
-                        dst[i] = r * HR_LDS_REC + 4 * u;
-                    }
-                }
+        // one LDS-DMA per record: lanes 0..39 move its 640 B straight into the 656-B-pitch slot (no registers, no
+        // ds_write, every record of the wave in flight at once; the register-staged loop this replaces was a third
+        // of the kernel).  Records outside the image are never read (taps are clamped into it) and stay unwritten.
+        const int nrec = p.lrh * p.lrw;
+        for (int r = wave; r < nrec; r += HR_WAVES) {
+            const int ry = r / p.lrw, rx = r - ry * p.lrw;
+            const int gy = ly0 + ry, gx = lx0 + rx;
+            if (gy < p.h && gx < p.w && lane < REC / 4) {
+                const float* src = p.lrcat + ((long long)gy * p.w + gx) * REC + 4 * lane;
+                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds + r * HR_LDS_REC));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
             }
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                if (dst[i] >= 0) *reinterpret_cast<f32x4*>(lds + dst[i]) = v[i];
         }
     }
     {
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wt.wbe_w);
-        for (int e = tid; e < 2 * 2 * 2 * 64; e += 256) reinterpret_cast<f32x4*>(cst)[e] = wsrc[e];
+        for (int e = tid; e < 2 * 2 * 2 * 64; e += 64 * HR_WAVES) reinterpret_cast<f32x4*>(cst)[e] = wsrc[e];
         if (tid < 16) reinterpret_cast<f32x4*>(cst + 2 * 2 * 2 * 64 * 4)[tid] = reinterpret_cast<const f32x4*>(p.wt.fusion_b)[tid];
         if (p.n_table <= HR_TABLE_LDS)
-            for (int e = tid; e < p.n_table * 2; e += 256)
+            for (int e = tid; e < p.n_table * 2; e += 64 * HR_WAVES)
                 reinterpret_cast<f32x4*>(cst + 2 * 2 * 2 * 64 * 4 + 64)[e] = reinterpret_cast<const f32x4*>(p.table)[e];
     }
     const float* tab = (p.n_table <= HR_TABLE_LDS) ? cst + 2 * 2 * 2 * 64 * 4 + 64 : nullptr;
@@ -480,26 +473,30 @@ __global__ __launch_bounds__(256, 2) void satu_hr_kernel(const HrParams p) {
         rowc[tid] = __int_as_float(p.idx_h[Yc]);
         rowc[HR_MAX_ROWS + tid] = p.gyn[Yc];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the window DMA (not counted by the compiler)
     __syncthreads();
 
-    const int stamps_on = __builtin_amdgcn_readfirstlane(g_satu_stamps_on);
+    const int dbg_all = __builtin_amdgcn_readfirstlane(g_satu_stamps_on);
+    const int stamps_on = dbg_all & 1;
+    const bool dbg_nostore = dbg_all & 2;                            // timing experiment only: skip the output stores
     long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t_prev = stamps_on ? SATU_T() : 0;
-    const long long t_begin = t_prev;
+    const long long t_begin = t_entry;
+    tacc[4] = t_prev - t_entry;                                      // staging of the LDS window + constants
 #define HR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
     const int ntile = p.ty * p.txw;
     // per-lane column constants of the first column tile (the only one when txw == 1)
     const int Xc0 = (X0 + px < p.W) ? X0 + px : p.W - 1;
     const int iw0 = p.idx_w[Xc0];
     const float gxn0 = p.gxn[Xc0];
-    for (int T = wave; T < ntile; T += 4) {
+    for (int T = wave; T < ntile; T += HR_WAVES) {
         const int trow = T / p.txw;
         const int Y = Y0 + trow;
         const int Xb = X0 + (T - trow * p.txw) * 32;
         if (Y >= p.H || Xb >= p.W) continue;                      // wave-uniform
         const int X = Xb + px;
-        const bool valid = X < p.W;
-        const int Xc = valid ? X : p.W - 1;
+        const bool valid = X < p.W && !dbg_nostore;
+        const int Xc = X < p.W ? X : p.W - 1;
         const bool col0 = Xb == X0;                                   // wave-uniform
         const int iw = col0 ? iw0 : p.idx_w[Xc];
         const long long ent = ((long long)__float_as_int(rowc[trow]) * p.n_uw + iw) * SAVSR_SATU_TABLE;
@@ -545,6 +542,14 @@ using namespace savsr;
 extern "C" int savsr_debug_satu_stamps(int enable) {
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_satu_stamps_on), &enable, sizeof(int));
     return e == hipSuccess ? 0 : (int)e;
+}
+
+// Diagnostics: resident workgroups per CU the runtime predicts for the HR / LR kernels with `lds_bytes` of dynamic LDS.
+extern "C" int savsr_debug_satu_occupancy(int which, int lds_bytes) {
+    int n = -1;
+    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel, 64 * HR_WAVES, (size_t)lds_bytes)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_kernel, 256, (size_t)lds_bytes);
+    return e == hipSuccess ? n : -(int)e;
 }
 
 extern "C" int savsr_debug_read_satu_stamps(long long* host, int nblocks) {
@@ -616,6 +621,6 @@ extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float*
         attr_done = true;
     }
     dim3 grid((W + 32 * p.txw - 1) / (32 * p.txw), (H + p.ty - 1) / p.ty);
-    hipLaunchKernelGGL(satu_hr_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(satu_hr_kernel, grid, dim3(64 * HR_WAVES), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_hr_kernel");
 }

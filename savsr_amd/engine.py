@@ -418,9 +418,10 @@ class HipEngine:
         savsr_channel_sums workgroup."""
         return self.buf("pool." + key, max(self.pool_rows(h, w), MAX_SUM_BLOCKS) * cin)
 
-    def osconv_weights(self, key: str, srcs: List[Src], h: int, w: int, scale, pooled: bool = False):
-        """Pool -> routing/attention -> aggregated split-bf16 weight image (savsr_arch.py:143-163).
-        pooled=True: the producing convs already wrote the pool partials (fused epilogue)."""
+    def osconv_desc(self, key: str, srcs: List[Src], h: int, w: int, scale, pooled: bool = False) -> OSConvAttnDesc:
+        """Descriptor of one OSConv's weight generation (pool -> routing/attention -> aggregated split-bf16 image,
+        savsr_arch.py:143-163).  pooled=True: the producing convs already wrote the pool partials (fused epilogue);
+        otherwise the pooling kernel is launched here."""
         e = self.osc[key]
         partial = self.pool_buf(key, h, w, e["cin"])
         nblk = self.pool_rows(h, w) if pooled else self.channel_sums(srcs, h * w, partial)
@@ -433,8 +434,20 @@ class HipEngine:
                   "sp_w", "sp_b", "kn_w", "kn_b", "v1", "v2", "bank", "att"):
             setattr(d, k, e[k].data_ptr())
         d.wimg_out = e["wdyn"].data_ptr()
-        _lib.check(self.lib.savsr_osconv_weights(C.byref(d), self._stream()), f"savsr_osconv_weights[{key}]")
-        return (e["wdyn"], None, e["cout"], e["cin"], 3)
+        return d
+
+    def osconv_launch(self, keys: List[str], descs: List[OSConvAttnDesc]):
+        """Weight generation of independent OSConvs of identical geometry, up to 6 per set of launches
+        (savsr_osconv_weights_batch); returns the conv `weights` tuples."""
+        st = self._stream()
+        for i in range(0, len(descs), 6):
+            chunk = descs[i:i + 6]
+            arr = (OSConvAttnDesc * len(chunk))(*chunk)
+            _lib.check(self.lib.savsr_osconv_weights_batch(arr, len(chunk), st), f"savsr_osconv_weights_batch[{keys[i]}]")
+        return [(self.osc[k]["wdyn"], None, self.osc[k]["cout"], self.osc[k]["cin"], 3) for k in keys]
+
+    def osconv_weights(self, key: str, srcs: List[Src], h: int, w: int, scale, pooled: bool = False):
+        return self.osconv_launch([key], [self.osconv_desc(key, srcs, h, w, scale, pooled)])[0]
 
     # ------------------------------------------------------------------ network pieces
     def residual_blocks(self, groups: List[Tuple[str, List[Src], str]], hp: int, wp: int, scale, use_osconv: bool) -> List[List[Src]]:
@@ -453,11 +466,13 @@ class HipEngine:
             x1s.append(x1)
         self.conv_launch(d0, "conv0")
         bases, d1 = [], []
-        for (pfx, xs, tag), x1 in zip(groups, x1s):
+        if use_osconv:                                   # the groups' OSConvs are independent: one batched weight generation
+            keys = [pfx + ".osconv" for pfx, _, _ in groups]
+            wds = self.osconv_launch(keys, [self.osconv_desc(k, x1, hp, wp, scale, pooled=True) for k, x1 in zip(keys, x1s)])
+        for gi, ((pfx, xs, tag), x1) in enumerate(zip(groups, x1s)):
             base = self.full(self.buf(f"{tag}.base", hp, wp, nf))
             if use_osconv:
-                wd = self.osconv_weights(pfx + ".osconv", x1, hp, wp, scale, pooled=True)
-                d1.append(self.conv_desc(pfx + ".osconv", x1, base, hp, wp, L, 0.2, weights=wd))
+                d1.append(self.conv_desc(pfx + ".osconv", x1, base, hp, wp, L, 0.2, weights=wds[gi]))
             else:
                 d1.append(self.conv_desc(pfx + ".conv1", x1, base, hp, wp, L, 0.2))
             bases.append(base)

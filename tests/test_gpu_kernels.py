@@ -75,6 +75,43 @@ def test_conv2d(eng, cin, cout, ks, nsrc, h, w):
     assert _maxerr(got, ref) < 1e-4
 
 
+def test_conv2d_batch_wide_tiles(eng):
+    """savsr_conv2d_batch big enough for the 16-row-tile kernel variant (ragged 90x330: partial last band and
+    column): each conv vs F.conv2d, and bit-identical -- outputs AND fused pool rows -- to the same convs launched
+    one by one (8-row-tile variant)."""
+    from savsr_amd import engine as E
+    from savsr_amd._lib import ACT_LRELU
+    g = np.random.RandomState(77)
+    h, w, cin, cout, n = 90, 330, 128, 64, 4
+    rows = eng.pool_rows(h, w)
+    xs, descs, singles, outs, outs1, parts, parts1, refs = [], [], [], [], [], [], [], []
+    for k in range(n):
+        wt = torch.from_numpy((g.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
+        bias = torch.from_numpy(g.standard_normal(cout).astype(np.float32))
+        x = torch.from_numpy(g.standard_normal((cin, h, w)).astype(np.float32))
+        res = torch.from_numpy(g.standard_normal((cout, h, w)).astype(np.float32))
+        refs.append(F.leaky_relu(F.conv2d(x[None], wt, bias, padding=1), 0.2)[0] + res)
+        xall, rcl = cl(x), cl(res)
+        srcs = [eng.full(xall, 64, 0), eng.full(xall, 64, 64)]
+        weights = (_dev(E.pack_conv_weight(wt)), _dev(bias), cout, cin, 3)
+        xs.append((xall, rcl, weights))              # the descriptors hold raw pointers: keep every tensor alive
+        for outl, partl, dl in ((outs, parts, descs), (outs1, parts1, singles)):
+            o = torch.full((h, w, cout), float("nan"), device="cuda:0")
+            pt = torch.full((rows, cout), float("nan"), device="cuda:0")
+            outl.append(o)
+            partl.append(pt)
+            dl.append(eng.conv_desc("t", srcs, eng.full(o), h, w, ACT_LRELU, 0.2, res1=eng.full(rcl), weights=weights, pool=(pt, 0, cout)))
+    eng.conv_launch(descs)
+    for d in singles:
+        eng.conv_launch([d])
+    torch.cuda.synchronize()
+    for k in range(n):
+        assert _maxerr(pl(outs[k]), refs[k]) < 1e-4
+        assert torch.equal(outs[k], outs1[k])
+        assert torch.equal(parts[k], parts1[k])
+        assert _maxerr(parts[k].sum(0).cpu() / (h * w), refs[k].mean(dim=(1, 2))) < 1e-4
+
+
 def test_conv2d_rejects_bad_args(eng):
     from savsr_amd._lib import ConvDesc
     d = ConvDesc()

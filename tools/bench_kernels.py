@@ -129,6 +129,22 @@ def main():
             eng.lib.savsr_debug_satu_stamps(0)
             stt = np.array(buf[:], dtype=np.int64).reshape(nb, 8)
             print(name, "section cycles (median over workgroups, wave 0):", np.median(stt, axis=0).astype(int).tolist())
+            tot = stt[:, 7]
+            print(name, "workgroup totals: mean %d  p10 %d  p50 %d  p90 %d  p99 %d  max %d  (n = %d)" %
+                  (tot.mean(), np.percentile(tot, 10), np.percentile(tot, 50), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), nb))
+        for flag, nm in ((0, "normal"), (2, "no output stores (invalid results)")):
+            eng.lib.savsr_debug_satu_stamps(flag)
+            hr = lambda: eng.lib.savsr_satu_hr_upsample(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
+                                                        ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), H, W, C.byref(ax["tiling"]), out.data_ptr(), plane, eng._stream())
+            for _ in range(3):
+                hr()
+            ev0.record()
+            for _ in range(10):
+                hr()
+            ev1.record()
+            torch.cuda.synchronize()
+            print("HR kernel alone, %s: %.1f us" % (nm, 1e2 * ev0.elapsed_time(ev1)))
+        eng.lib.savsr_debug_satu_stamps(0)
         t = ax["tiling"]
         print("HR tiling: rows", t.tile_rows, "cols32", t.tile_cols32, "window", t.lr_rows, "x", t.lr_cols)
     print(f"{a.what} cin={a.cin} cout={a.cout} ks={a.ks} {h}x{w}: {us:.2f} us/iter" + (f"  {flop / us / 1e6:.1f} TFLOP/s fp32-equivalent" if flop else ""))
