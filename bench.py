@@ -64,6 +64,46 @@ def cpu_baseline(sd, threads):
             "sample": f"{n} frame(s) of the workload clip (7x3x180x320, x4 -> 720x1280) through oracle/savsr_oracle.py, {dt:.2f} s"}, out, lq
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (sustained under load: ~1870, tools/micro/mfma_rate.hip)
+
+
+def conv_roofline(eng, dev, iters=20):
+    """The kernel that dominates GPU time (conv_bf16x3_kernel, ~80 % of a frame) on its most frequent launch
+    geometry: one savsr_conv2d_batch of six 128->64 3x3 convs at 180x320 with bias, LeakyReLU and a residual
+    (the ResidualBlock conv2 launches, savsr_arch.py:412-414; 20 of them per frame).  HIP events on the launch
+    stream.  The frame's launches replay inside a hipGraph, which cannot hold timing events, so this times the
+    same launch right after the timed region; the rocprofv3 summary of the bench command holds the in-graph
+    average of this kernel (profiles/)."""
+    from savsr_amd import engine as E
+    from savsr_amd._lib import ACT_LRELU
+    g = torch.Generator().manual_seed(1)
+    n, cin, cout = 6, 128, 64
+    keep, descs = [], []
+    for _ in range(n):
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        weights = (E.pack_conv_weight(wt).to(dev), torch.randn(cout, generator=g).to(dev), cout, cin, 3)
+        xs = [torch.randn(LR_H, LR_W, 64, generator=g).to(dev) for _ in range(2)]
+        res, out = torch.randn(LR_H, LR_W, cout, generator=g).to(dev), torch.empty(LR_H, LR_W, cout, device=dev)
+        keep.append((weights, xs, res, out))
+        descs.append(eng.conv_desc("bench", [eng.full(x) for x in xs], eng.full(out), LR_H, LR_W, ACT_LRELU, 0.2,
+                                   res1=eng.full(res), weights=weights))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        eng.conv_launch(descs)
+    ev0.record()
+    for _ in range(iters):
+        eng.conv_launch(descs)
+    ev1.record()
+    torch.cuda.synchronize()
+    sec = ev0.elapsed_time(ev1) / 1e3 / iters
+    alg = 2.0 * n * cin * cout * 9 * LR_H * LR_W            # fp32-equivalent flops (SURVEY 8(d): 2 x MACs)
+    issued = 3.0 * alg                                      # split-bf16: three bf16 MFMA products per fp32 product
+    return {"kernel": "conv_bf16x3_kernel<3,2,2> (6 x conv3x3 128->64 + bias + LeakyReLU + residual, 180x320)", "bound": "mfma",
+            "achieved": round(issued / sec / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(issued / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "traffic": None, "algorithmic_flops": alg, "fp32_equivalent_tflops": round(alg / sec / 1e12, 1), "avg_ms": round(1e3 * sec, 4),
+            "note": "achieved counts the bf16 MFMA flops issued (3 per fp32-equivalent product); launch timed solo after the timed region"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,12 +198,13 @@ def main():
             "config": {"workload": "BASELINE config 2: synthetic 7x3x180x320 clips, scale x4 -> 720x1280, key-seeded random-init weights",
                        "frames_per_step": cps, "streams_per_gpu": min(cps, eng.n_streams), "parallelism": f"clip-sharded dp{world}"},
             "psnr_y_vs_synthetic_gt": round(float(psnr), 4),
-            "roofline": {"kernel": "SATU (phase table + LR stage + HR upsample)", "bound": "hbm", "achieved": round(achieved, 1),
+            "roofline": {"kernel": "SATU = satu_lr_kernel + satu_hr_kernel (the phase table is evaluated once per size / scale / weights)", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": SATU_PMC_TRAFFIC_BYTES,
                          "algorithmic_bytes": alg_bytes, "avg_ms": round(1e3 * satu_avg_s, 4),
                          "note": "timed-region figure: the other in-flight clips' kernels share the GPU with these launches",
                          "solo_avg_ms": round(sum(solo_ms) / len(solo_ms), 4), "solo_frac": round(alg_bytes / (sum(solo_ms) / len(solo_ms) / 1e3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        line["roofline_conv"] = conv_roofline(eng, dev)
         if world == 1 and not args.no_cpu_baseline:
             threads = effective_cpus()
             cb, ref, lq_c = cpu_baseline(sd, threads)

@@ -416,23 +416,45 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         const bool chan_full = (cob + 1) * COT <= COUT;       // the 16-row variant is only launched with cout % 64 == 0
         const bool x_inside = x0 + CONV_TW <= W;
         if (PXT > 1 || chan_full) {
+            // loads that do not depend on the accumulators go out first: the bias quads of both channel groups, and the
+            // residual quads one (row, channel-group) step ahead of their use (issued next to their use they exposed one
+            // global-load latency per step)
+            f32x4 bias4[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                bias4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (e_bias) bias4[t] = *reinterpret_cast<const f32x4*>(e_bias + cob * COT + 32 * t + 4 * c4);
+            }
+            f32x4 rr[2][4];
+            auto load_r1 = [&](int r, int t, f32x4 (&dst)[4]) {
+                const int y = y0 + wave + CONV_TH * r;
+                const int co = cob * COT + 32 * t + 4 * c4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (y < H && (x_inside || x0 + (lane >> 3) + 8 * i < W))
+                        dst[i] = ldg4(e_r1, 4u * (unsigned)((y * W + x0 + (lane >> 3) + 8 * i) * e_r1pix + co));
+                }
+            };
+            if (e_r1) load_r1(0, 0, rr[0]);
 #pragma unroll
             for (int r = 0; r < PXT; ++r) {
                 const int y = y0 + wave + CONV_TH * r;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) psum[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (y >= H) continue;                                                    // wave-uniform
                 const int pbase = y * W + x0 + (lane >> 3);                              // unit i is pixel pbase + 8 i
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
+                    const int gi = r * NT + t;
+                    if (e_r1 && gi + 1 < PXT * NT) load_r1((gi + 1) / NT, (gi + 1) % NT, rr[(gi + 1) & 1]);
+                    if (y >= H) continue;                                                // wave-uniform
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 v = {acc[r][t][4 * g], acc[r][t][4 * g + 1], acc[r][t][4 * g + 2], acc[r][t][4 * g + 3]};
                         *reinterpret_cast<f32x4*>(ep + px * EPS + 8 * g + 4 * half) = v;
                     }
                     const int co = cob * COT + 32 * t + 4 * c4;
-                    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-                    if (e_bias) b4 = *reinterpret_cast<const f32x4*>(e_bias + co);
+                    const f32x4 b4 = bias4[t];
                     f32x4 ps = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ih = 0; ih < 2; ++ih) {                  // two units (pixels pbase + 16 ih, + 8) at a time: register budget
@@ -466,9 +488,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                             for (int q = 0; q < 4; ++q) { v[0][q] *= m0; v[1][q] *= m1; }
                         }
                         if (e_r1) {
-                            f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
-                            if (ok0) ra = ldg4(e_r1, 4u * (unsigned)(p0 * e_r1pix + co));
-                            if (ok1) rb = ldg4(e_r1, 4u * (unsigned)((p0 + 8) * e_r1pix + co));
+                            const f32x4 ra = rr[gi & 1][2 * ih], rb = rr[gi & 1][2 * ih + 1];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { v[0][q] += ra[q]; v[1][q] += rb[q]; }
                         }

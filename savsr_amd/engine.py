@@ -606,11 +606,9 @@ class HipEngine:
     def satu(self, x: Src, st: Src, row_px: int, h: int, w: int, scale, out: torch.Tensor, out_plane: Optional[int] = None):
         """STAUpsample.forward (savsr_arch.py:315-376).  x, st: channel-last crops (row pitch row_px
         pixels) of [..][..][64] maps; out: [64][H][W] planar."""
-        ax = self.satu_axes(h, w, scale)
+        ax = self.satu_axes(h, w, scale)       # incl. the phase table: a function of (size, scale, weights) only, evaluated once
         s = self._stream()
         sw = C.byref(self.satu_w)
-        _lib.check(self.lib.savsr_satu_phase_table(sw, ax["uh"].data_ptr(), ax["n_uh"], ax["uw"].data_ptr(), ax["n_uw"],
-                                                   1.0 / scale[1], 1.0 / scale[0], ax["table"].data_ptr(), s), "savsr_satu_phase_table")
         assert x.pix == st.pix
         lrcat = self.buf("satu.lrcat", h, w, _lib.SATU_LRCAT)
         _lib.check(self.lib.savsr_satu_lr_stage(sw, x.ptr, st.ptr, x.pix, row_px, h, w, lrcat.data_ptr(), s), "savsr_satu_lr_stage")
