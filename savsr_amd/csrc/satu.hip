@@ -78,12 +78,13 @@ struct LrParams {
     float* lrcat;
 };
 
-constexpr int LR_TH = 4, LR_TW = 32, LR_HALO = 2;
-constexpr int LR_XR = LR_TH + 2 * LR_HALO;     // 8
+constexpr int LR_TH = 8, LR_TW = 32, LR_HALO = 2;   // workgroup = 8 waves = 8 rows x 32 cols of LR pixels
+constexpr int LR_XR = LR_TH + 2 * LR_HALO;     // 12
 constexpr int LR_XC = LR_TW + 2 * LR_HALO;     // 36
-constexpr int LR_NPX = LR_XR * LR_XC;          // 288 pixels in the x tile
+constexpr int LR_NPX = LR_XR * LR_XC;          // 432 pixels in the x tile
 constexpr int LR_XS = 36;                      // floats per pixel record in LDS (32 used; 144 B keeps b128 reads conflict-free)
 constexpr int LR_SLAB = 4 * 2 * 64;            // 16-B units of one (tap, cg) weight slab: [ks][part][lane]
+constexpr int LR_PHASE = 5 * LR_SLAB;          // one phase = the 5 taps of a kernel row (40 KB of weights)
 
 __device__ __forceinline__ void split8v(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
     const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -101,11 +102,20 @@ __device__ __forceinline__ f32x16 mma3(const bf16x8 ah, const bf16x8 al, const b
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
+// 16 B per lane, global -> LDS without registers (LDS-DMA); `lds_dst` = wave-uniform LDS address of lane 0's 16 B.
+// hipcc does not count this load: the consumer waits with an explicit s_waitcnt vmcnt(0) before its barrier.
+__device__ __forceinline__ void glds16(const void* gsrc, const void* lds_dst) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xt = smem;                                                   // [288][36]
-    bf16x8* wbuf = reinterpret_cast<bf16x8*>(smem + LR_NPX * LR_XS);    // [3][LR_SLAB]
-    float* kbl = smem + LR_NPX * LR_XS + 3 * LR_SLAB * 4;               // [25][64] kernel_conv bias
+    float* xt = smem;                                                   // [432][36]: replicate-padded x tile of one channel group
+    bf16x8* wbuf = reinterpret_cast<bf16x8*>(smem + LR_NPX * LR_XS);    // [2][LR_PHASE]: weight slabs of a kernel row, double buffered
+    float* kbl = smem + LR_NPX * LR_XS + 2 * LR_PHASE * 4;              // [25][64] kernel_conv bias
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int x0 = blockIdx.x * LR_TW, y0 = blockIdx.y * LR_TH;
@@ -114,12 +124,46 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
     const int cy = gy < p.h ? gy : p.h - 1, cx = gx < p.w ? gx : p.w - 1;
     const long long cpix = ((long long)cy * p.row_px + cx) * p.pix + 8 * half;
 
-    const int stamps_on = __builtin_amdgcn_readfirstlane(g_satu_stamps_on);
+    const int stamps_on = __builtin_amdgcn_readfirstlane(g_satu_stamps_on) & 1;
     long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t_prev = stamps_on ? SATU_T() : 0;
     const long long t_begin = t_prev;
 #define LR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
+    const bf16x8* kw = reinterpret_cast<const bf16x8*>(p.wt.kconv_w);
+    // weight slabs of phase ph (= channel group ph / 5, kernel row ph % 5) -> LDS buffer b: 40 pieces of 1 KiB, 5 per wave
+    auto dma_phase = [&](int ph, int b) {
+        const int cg = ph / 5, ky = ph - 5 * cg;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            glds16(kw + (long long)((ky * 5 + i) * 2 + cg) * LR_SLAB + wave * 64 + lane, wbuf + b * LR_PHASE + i * LR_SLAB + wave * 64);
+    };
+    // replicate-padded x tile of channel group cg (F.pad replicate, :302): global -> registers ...
+    constexpr int XT_IT = (LR_NPX * 8 + 511) / 512;                    // 7 float4 per thread
+    f32x4 xv[XT_IT];
+    auto xt_load = [&](int cg) {
+#pragma unroll
+        for (int i = 0; i < XT_IT; ++i) {
+            const int e = tid + i * 512;
+            const int pl = (e < LR_NPX * 8 ? e : 0) >> 3, c4 = e & 7;
+            const int r = pl / LR_XC, c = pl - r * LR_XC;
+            int sy = y0 - LR_HALO + r, sx = x0 - LR_HALO + c;
+            sy = sy < 0 ? 0 : (sy > p.h - 1 ? p.h - 1 : sy);
+            sx = sx < 0 ? 0 : (sx > p.w - 1 ? p.w - 1 : sx);
+            xv[i] = *reinterpret_cast<const f32x4*>(p.x + ((long long)sy * p.row_px + sx) * p.pix + 32 * cg + 4 * c4);
+        }
+    };
+    auto xt_store = [&]() {                                             // ... -> LDS
+#pragma unroll
+        for (int i = 0; i < XT_IT; ++i) {
+            const int e = tid + i * 512;
+            if (e < LR_NPX * 8) *reinterpret_cast<f32x4*>(xt + (e >> 3) * LR_XS + 4 * (e & 7)) = xv[i];
+        }
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------
+    dma_phase(0, 0);
+    xt_load(0);
     // B operand of the kernel-prediction GEMM: st[16 ks + 8 half + j][pixel], resident for all 50 tiles
     bf16x8 sth[4], stl[4];
 #pragma unroll
@@ -127,111 +171,116 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
         const f32x4* g = reinterpret_cast<const f32x4*>(p.st + cpix + 16 * ks);
         split8v(g[0], g[1], sth[ks], stl[ks]);
     }
-    const bf16x8* kw = reinterpret_cast<const bf16x8*>(p.wt.kconv_w);
-    for (int e = tid; e < 25 * 64 / 4; e += 256) reinterpret_cast<f32x4*>(kbl)[e] = reinterpret_cast<const f32x4*>(p.wt.kconv_b)[e];
+    for (int e = tid; e < 25 * 64 / 4; e += 512) reinterpret_cast<f32x4*>(kbl)[e] = reinterpret_cast<const f32x4*>(p.wt.kconv_b)[e];
+    xt_store();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    LR_MARK(0);                                       // prologue: first slabs, x tile, st fragments
 
+    struct AFrag { bf16x8 ah[4], al[4]; };
     f32x16 sta[2];
 #pragma unroll
-    for (int cg = 0; cg < 2; ++cg) {
-        __syncthreads();                    // previous group's readers are done with xt / wbuf
-        // replicate-padded x tile of this channel group (F.pad replicate, :302): all 9 loads of a thread in
-        // flight before the first LDS write (a load->store loop exposes 9 global latencies: 14 k cycles measured)
-        {
-            f32x4 xv[LR_NPX * 8 / 256];
-#pragma unroll
-            for (int i = 0; i < LR_NPX * 8 / 256; ++i) {
-                const int e = tid + i * 256;
-                const int pl = e >> 3, c4 = e & 7;
-                const int r = pl / LR_XC, c = pl - r * LR_XC;
-                int sy = y0 - LR_HALO + r, sx = x0 - LR_HALO + c;
-                sy = sy < 0 ? 0 : (sy > p.h - 1 ? p.h - 1 : sy);
-                sx = sx < 0 ? 0 : (sx > p.w - 1 ? p.w - 1 : sx);
-                xv[i] = *reinterpret_cast<const f32x4*>(p.x + ((long long)sy * p.row_px + sx) * p.pix + 32 * cg + 4 * c4);
-            }
-#pragma unroll
-            for (int i = 0; i < LR_NPX * 8 / 256; ++i) {
-                const int e = tid + i * 256;
-                *reinterpret_cast<f32x4*>(xt + (e >> 3) * LR_XS + 4 * (e & 7)) = xv[i];
-            }
-        }
-        // weight slabs: 3-deep LDS ring, global loads issued two taps ahead of their use
-        {
-            const bf16x8* src = kw + (long long)(0 * 2 + cg) * LR_SLAB;
-            wbuf[tid] = src[tid];
-            wbuf[tid + 256] = src[tid + 256];
-        }
-        LR_MARK(0);                               // prologue: st fragments / x tile / first slab
-        // register sets for the slabs in flight: set A holds odd taps, set B even taps (static names: no copies)
-        bf16x8 ra0, ra1, rb0 = wbuf[0], rb1 = rb0;
-        {
-            const bf16x8* src = kw + (long long)(1 * 2 + cg) * LR_SLAB;
-            ra0 = src[tid];
-            ra1 = src[tid + 256];
-        }
-        __syncthreads();
-
+    for (int cg = 0; cg < 2; ++cg) {                  // unrolled: sta[cg] must stay in registers
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll 1
+        for (int ky = 0; ky < 5; ++ky) {
+            const int ph = cg * 5 + ky, buf = ph & 1;
+            // staged under this phase: the next kernel row's slabs; at the end of a channel group also the next x tile;
+            // under the very last phase the projection weights (same 40 KB) and the centre pixel's x
+            if (ph + 1 < 10) dma_phase(ph + 1, buf ^ 1);
+            else {
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                    glds16(reinterpret_cast<const bf16x8*>(p.wt.proj_w) + (i * 8 + wave) * 64 + lane, wbuf + (buf ^ 1) * LR_PHASE + (i * 8 + wave) * 64);
+            }
 
-        auto tap_body = [&](int tap, bf16x8& ld0, bf16x8& ld1, const bf16x8& st0, const bf16x8& st1) {
-            // ld*: destination of the load for tap + 2; st*: slab of tap + 1 (loaded one iteration ago) to store
-            if (tap + 2 < 25) {
-                const bf16x8* src = kw + (long long)((tap + 2) * 2 + cg) * LR_SLAB;
-                ld0 = src[tid];
-                ld1 = src[tid + 256];
-            }
-            const bf16x8* wl = wbuf + (tap % 3) * LR_SLAB + lane;
-            const float* kb = kbl + tap * 64 + cg * 32 + 4 * half;
-            f32x16 acc;
+            const bf16x8* wl = wbuf + buf * LR_PHASE + lane;
+            auto load_frag = [&](int kx, AFrag& f) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {            // bias as the initial accumulator
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + 8 * g);
-                acc[4 * g + 0] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
-            }
-            LR_MARK(1);                                // slab load issue + bias
-            bf16x8 ah[4], al[4];                       // all 8 A fragments of the tap in flight before the first MFMA
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { ah[ks] = wl[(ks * 2 + 0) * 64]; al[ks] = wl[(ks * 2 + 1) * 64]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = mma3(ah[ks], al[ks], sth[ks], stl[ks], acc);
-            if (stamps_on) { asm volatile("" :: "v"(acc[0])); }
-            LR_MARK(2);                                // fragment reads + 12 MFMAs
-            const int ky = tap / 5, kx = tap - ky * 5;
-            const float* xp = xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + 8 * g);
+                for (int ks = 0; ks < 4; ++ks) { f.ah[ks] = wl[kx * LR_SLAB + (ks * 2 + 0) * 64]; f.al[ks] = wl[kx * LR_SLAB + (ks * 2 + 1) * 64]; }
+            };
+            // LDS operands of the VALU work are read ONE group ahead of their use (a read next to its use exposes the LDS
+            // latency in every group: the wave cannot issue its next MFMAs while it waits)
+            auto bias_read = [&](int kx, int g) -> f32x4 {       // kernel_conv bias (the initial accumulator), quad g
+                return *reinterpret_cast<const f32x4*>(kbl + (ky * 5 + kx) * 64 + cg * 32 + 4 * half + 8 * g);
+            };
+            auto x_read = [&](int kx, int g) -> f32x4 {          // x_pad at tap (ky, kx), channel quad g of this half
+                return *reinterpret_cast<const f32x4*>(xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half + 8 * g);
+            };
+            auto lrelu_x = [&](int g, const f32x16& acc, const f32x4 xq) {   // sta += LeakyReLU_0.1(K) * x_pad   (:228, :297-313)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float k = acc[4 * g + i];
-                    sacc[4 * g + i] += fmaxf(k, 0.1f * k) * xv[i];     // LeakyReLU(0.1), :228
+                    // max(k, 0.1 k) as one v_med3_f32 against +inf: fmaxf costs two v_max_f32 (NaN canonicalisation) and this
+                    // loop is VALU-issue-bound beside the MFMAs (6 VALU per MFMA)
+                    sacc[4 * g + i] += __builtin_amdgcn_fmed3f(k, 0.1f * k, __builtin_inff()) * xq[i];
+                }
+            };
+            AFrag fr;                                 // ONE fragment set: a k-step's pair is reloaded for the next tap as soon as its
+            f32x16 acc[2];                            // MFMAs are issued (they have consumed their operands); two sets spill
+            load_frag(0, fr);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = bias_read(0, g);
+                acc[0][4 * g] = b4[0]; acc[0][4 * g + 1] = b4[1]; acc[0][4 * g + 2] = b4[2]; acc[0][4 * g + 3] = b4[3];
+            }
+            f32x4 b_pf = bias_read(1, 0), x_pf = b_pf;
+            // 20 groups of 3 MFMAs (tap kx = G / 4, k-step ks = G % 4).  The VALU work of the previous tap and the next tap's
+            // bias go BETWEEN the groups: both waves of a SIMD run in lockstep, so VALU work placed after a tap's 12 MFMAs is
+            // serial to them (7.9 k cycles per phase for 4.0 k of MFMAs, stamps).
+#pragma unroll
+            for (int G = 0; G < 20; ++G) {
+                const int kx = G / 4, ks = G % 4;
+                __builtin_amdgcn_sched_barrier(0);
+                acc[kx & 1] = mma3(fr.ah[ks], fr.al[ks], sth[ks], stl[ks], acc[kx & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kx + 1 < 5) { fr.ah[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 0) * 64]; fr.al[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 1) * 64]; }
+                if (kx > 0) lrelu_x(ks, acc[(kx - 1) & 1], x_pf);
+                if (kx + 1 < 5) {
+                    f32x16& an = acc[(kx + 1) & 1];
+                    an[4 * ks] = b_pf[0]; an[4 * ks + 1] = b_pf[1]; an[4 * ks + 2] = b_pf[2]; an[4 * ks + 3] = b_pf[3];
+                }
+                const int G1 = G + 1, kx1 = G1 / 4, ks1 = G1 % 4;
+                if (G1 < 20) {
+                    if (kx1 > 0) x_pf = x_read(kx1 - 1, ks1);
+                    if (kx1 + 1 < 5) b_pf = bias_read(kx1 + 1, ks1);
                 }
             }
-            if (stamps_on) { asm volatile("" :: "v"(sacc[0])); }
-            LR_MARK(3);                                // LeakyReLU * x accumulate
-            if (tap + 1 < 25) {
-                bf16x8* dst = wbuf + ((tap + 1) % 3) * LR_SLAB;
-                dst[tid] = st0;
-                dst[tid + 256] = st1;
+            {
+                f32x4 xq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xq[g] = x_read(4, g);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) lrelu_x(g, acc[0], xq[g]);
             }
-            LR_MARK(4);                                // wait for the next slab + LDS write
+            LR_MARK(1);                               // 5 taps: fragment reads, 60 MFMAs, LeakyReLU * x
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the staged slabs (and x loads) have landed
+            LR_MARK(2);
             __syncthreads();
-            LR_MARK(5);                                // barrier
-        };
-        for (int tap = 0; tap < 24; tap += 2) {
-            tap_body(tap, rb0, rb1, ra0, ra1);         // even tap: load tap+2 into B, store A (= tap+1)
-            tap_body(tap + 1, ra0, ra1, rb0, rb1);     // odd tap: load tap+2 into A, store B
+            if (ky == 4 && cg == 0) {                 // every wave is done with the old x tile: swap it (once per workgroup; loading
+                xt_load(1);                           // it under phase 4 would hold 28 registers across the loop and spills)
+                xt_store();
+                __syncthreads();
+            }
+            LR_MARK(3);                               // barrier(s)
         }
-        tap_body(24, rb0, rb1, ra0, ra1);
         sta[cg] = sacc;
     }
 
-    // ---- LR-side projections (bf16x3): proj image = A [t][kidx 4][part][lane] | B [t][ks 4][part][lane] | C [ks 4][part][lane]
-    const bf16x8* pa = reinterpret_cast<const bf16x8*>(p.wt.proj_w) + lane;
+    // ---- LR-side projections (bf16x3): proj image = A [t][kidx 4][part][lane] | B [t][ks 4][part][lane] | C [ks 4][part][lane],
+    // now in LDS buffer 0 (phase 9 ran from buffer 1)
+    const bf16x8* pa = wbuf + lane;
     const bf16x8* pb = pa + 2 * 4 * 2 * 64;
     const bf16x8* pc = pb + 2 * 4 * 2 * 64;
+    f32x4 xc[8];                                      // the centre pixel's x: B operand of the Wb / C projections
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.x + cpix + 16 * ks);
+        xc[2 * ks] = g[0];
+        xc[2 * ks + 1] = g[1];
+    }
     f32x16 accA[2], accB[2], accC;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accA[0][r] = 0.f; accA[1][r] = 0.f; accB[0][r] = 0.f; accB[1][r] = 0.f; accC[r] = 0.f; }
@@ -251,15 +300,14 @@ __global__ __launch_bounds__(256, 2) void satu_lr_kernel(const LrParams p) {
         }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const f32x4* g = reinterpret_cast<const f32x4*>(p.x + cpix + 16 * ks);
         bf16x8 xh, xl;
-        split8v(g[0], g[1], xh, xl);
+        split8v(xc[2 * ks], xc[2 * ks + 1], xh, xl);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
             accB[t] = mma3(pb[((t * 4 + ks) * 2 + 0) * 64], pb[((t * 4 + ks) * 2 + 1) * 64], xh, xl, accB[t]);
         accC = mma3(pc[(ks * 2 + 0) * 64], pc[(ks * 2 + 1) * 64], xh, xl, accC);
     }
-    LR_MARK(6);                                        // projections
+    LR_MARK(4);                                        // projections
     if (stamps_on && tid == 0) {
         const int b = blockIdx.x + gridDim.x * blockIdx.y;
         if (b < SSTAMP_BLOCKS) {
@@ -548,7 +596,7 @@ extern "C" int savsr_debug_satu_stamps(int enable) {
 extern "C" int savsr_debug_satu_occupancy(int which, int lds_bytes) {
     int n = -1;
     hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel, 64 * HR_WAVES, (size_t)lds_bytes)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_kernel, 256, (size_t)lds_bytes);
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_kernel, 512, (size_t)lds_bytes);
     return e == hipSuccess ? n : -(int)e;
 }
 
@@ -584,9 +632,16 @@ extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x,
     }
     LrParams p;
     p.wt = *wt; p.x = x; p.st = st; p.pix = pix; p.row_px = row_px; p.h = h; p.w = w; p.lrcat = lrcat;
-    const size_t lds = LR_NPX * LR_XS * sizeof(float) + 3 * LR_SLAB * 16 + 25 * 64 * sizeof(float);
+    constexpr size_t lds = LR_NPX * LR_XS * sizeof(float) + 2 * LR_PHASE * 16 + 25 * 64 * sizeof(float);     // 150.5 KB
+    static_assert(lds <= 160 * 1024, "LR stage LDS budget");
+    static bool attr_done = false;      // benign race: idempotent attribute set
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_lr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("satu_lr_stage: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
     dim3 grid((w + LR_TW - 1) / LR_TW, (h + LR_TH - 1) / LR_TH);
-    hipLaunchKernelGGL(satu_lr_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(satu_lr_kernel, grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_lr_kernel");
 }
 

@@ -116,7 +116,7 @@ def main():
         ax = eng.satu_axes(h, w, (4, 4))
         lrcat = eng.buf("satu.lrcat", h, w, _lib.SATU_LRCAT)
         for name, call, nb in (
-            ("LR", lambda: eng.lib.savsr_satu_lr_stage(sw, x.data_ptr(), st.data_ptr(), 64, w, h, w, lrcat.data_ptr(), eng._stream()), ((w + 31) // 32) * ((h + 3) // 4)),
+            ("LR", lambda: eng.lib.savsr_satu_lr_stage(sw, x.data_ptr(), st.data_ptr(), 64, w, h, w, lrcat.data_ptr(), eng._stream()), ((w + 31) // 32) * ((h + 7) // 8)),
             ("HR", lambda: eng.lib.savsr_satu_hr_upsample(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
                                                           ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), H, W, C.byref(ax["tiling"]), out.data_ptr(), plane, eng._stream()),
              ((W + 31) // 32) * ((H + ax["tiling"].tile_rows - 1) // ax["tiling"].tile_rows))):
