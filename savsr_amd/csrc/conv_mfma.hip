@@ -77,12 +77,21 @@ __device__ __forceinline__ void stamp(int on, int slot) {
 }
 
 // global accesses as (uniform base, 32-bit byte offset): one VGPR per address instead of a 64-bit pair
-// (savsr_conv2d validates that every tensor of a launch spans < 4 GiB)
+// (savsr_conv2d validates that every tensor of a launch spans < 2 GiB).  The explicit global address space matters: the
+// epilogue's pointers pass through an asm pin, after which hipcc no longer knows their address space and emits FLAT
+// loads / stores, which also count on lgkmcnt and so tie every LDS wait of the transpose to the outstanding stores.
+#define SAVSR_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ f32x4 ldg4(const float* base, unsigned byte_off) {
-    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+    return *(const SAVSR_GLOBAL f32x4*)((const SAVSR_GLOBAL char*)base + byte_off);
+}
+__device__ __forceinline__ float ldg1(const float* base, unsigned idx) {
+    return *((const SAVSR_GLOBAL float*)base + idx);
 }
 __device__ __forceinline__ void stg4(float* base, unsigned byte_off, const f32x4& v) {
-    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+    *(SAVSR_GLOBAL f32x4*)((SAVSR_GLOBAL char*)base + byte_off) = v;
+}
+__device__ __forceinline__ void stg1(float* base, unsigned idx, float v) {
+    *((SAVSR_GLOBAL float*)base + idx) = v;
 }
 
 template <int KS, int NT, int PXT>
@@ -189,8 +198,11 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         const int e = tid + i * NTHR;
         const int c8 = e % PER;                                         // float4 of the chunk
         const int po = st_pixoff[i];
-        const float* src = po < 0 ? g_conv_zero16 : st_base + (po * st_pix + st_cb + c8 * 4);   // padding reads 16 B of zeros
-        b_reg[i] = *reinterpret_cast<const f32x4*>(src);
+        // padding reads 16 B of zeros; explicit global address space (a select between two pointers makes hipcc emit a FLAT
+        // load, which counts on lgkmcnt and ties the fragment-read waits to these loads)
+        const SAVSR_GLOBAL float* src = po < 0 ? (const SAVSR_GLOBAL float*)g_conv_zero16
+                                               : (const SAVSR_GLOBAL float*)st_base + (po * st_pix + st_cb + c8 * 4);
+        b_reg[i] = *(const SAVSR_GLOBAL f32x4*)src;
     };
     auto stage_issue = [&](int j, int wbuf) {
         if (j < W_IT) issue_w(j, wbuf);
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 bias4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (e_bias) bias4[t] = *reinterpret_cast<const f32x4*>(e_bias + cob * COT + 32 * t + 4 * c4);
+                if (e_bias) bias4[t] = ldg4(e_bias, 4u * (unsigned)(cob * COT + 32 * t + 4 * c4));
             }
             f32x4 rr[2][4];
             auto load_r1 = [&](int r, int t, f32x4 (&dst)[4]) {
@@ -483,7 +495,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                                 for (int q = 0; q < 4; ++q) v[i][q] = sigmoidf_(v[i][q]);
                         }
                         if (e_mul) {
-                            const float m0 = ok0 ? e_mul[p0] : 0.f, m1 = ok1 ? e_mul[p0 + 8] : 0.f;
+                            const float m0 = ok0 ? ldg1(e_mul, (unsigned)p0) : 0.f, m1 = ok1 ? ldg1(e_mul, (unsigned)(p0 + 8)) : 0.f;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { v[0][q] *= m0; v[1][q] *= m1; }
                         }
@@ -527,10 +539,10 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             float b4[4] = {0.f, 0.f, 0.f, 0.f};
             if (e_bias) {
                 if (full) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(e_bias + co);
+                    const f32x4 bv = ldg4(e_bias, 4u * (unsigned)co);
                     b4[0] = bv[0]; b4[1] = bv[1]; b4[2] = bv[2]; b4[3] = bv[3];
                 } else {
-                    for (int q = 0; q < 4 && co + q < COUT; ++q) b4[q] = e_bias[co + q];
+                    for (int q = 0; q < 4 && co + q < COUT; ++q) b4[q] = ldg1(e_bias, (unsigned)(co + q));
                 }
             }
 #pragma unroll
@@ -552,11 +564,10 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                     for (int q = 0; q < 4; ++q) v[q] = sigmoidf_(v[q]);
                 }
                 if (e_mul) {
-                    const float mul = e_mul[pidx];
+                    const float mul = ldg1(e_mul, (unsigned)pidx);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] *= mul;
                 }
-                float* o = e_out + (unsigned)(pidx * e_opix + co);
                 if (full) {
                     if (e_r1) {
                         const f32x4 r = ldg4(e_r1, 4u * (unsigned)(pidx * e_r1pix + co));
@@ -572,9 +583,9 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 } else {
                     for (int q = 0; q < 4 && co + q < COUT; ++q) {
                         float vv = v[q];
-                        if (e_r1) vv += e_r1[(unsigned)(pidx * e_r1pix + co + q)];
-                        if (e_r2) vv += e_r2s * e_r2[(unsigned)(pidx * e_r2pix + co + q)];
-                        o[q] = vv;
+                        if (e_r1) vv += ldg1(e_r1, (unsigned)(pidx * e_r1pix + co + q));
+                        if (e_r2) vv += e_r2s * ldg1(e_r2, (unsigned)(pidx * e_r2pix + co + q));
+                        stg1(e_out, (unsigned)(pidx * e_opix + co + q), vv);
                     }
                 }
             }
