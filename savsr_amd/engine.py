@@ -573,18 +573,24 @@ class HipEngine:
         rx = float(ox.max() - ox.min())
         ry = float(oy.max() - oy.min())
         budget = (78 * 1024 - 17152) // (164 * 4)                      # records per workgroup at 2 workgroups / CU (16.6 KB of constants)
+        H, W = ent["H"], ent["W"]
+        slots = 2 * torch.cuda.get_device_properties(self.dev).multi_processor_count     # resident workgroups (2 per CU)
         best = None
         for tcols in (1, 2, 4):
-            for trows in (1, 2, 4, 6, 8, 12, 16, 24, 32):
+            for trows in (4, 6, 8, 10, 12, 14, 15, 16, 18, 20, 22, 24, 28, 32):
                 lr_c = int(np.ceil(32 * tcols / scale[1] + rx)) + 2
                 lr_r = int(np.ceil(trows / scale[0] + ry)) + 2
                 if lr_c * lr_r > budget:
                     continue
-                hr_px = trows * 32 * tcols
-                amp = lr_c * lr_r / max(hr_px / (scale[0] * scale[1]), 1e-9)
-                cand = (hr_px >= 256, -amp, hr_px)                     # enough work per workgroup first, then least re-staging
-                if best is None or cand > best[0]:
-                    best = (cand, trows, tcols, lr_r, lr_c)
+                # measured cost model of one workgroup (tools/bench_kernels.py satu --stamps): ~155 cycles per staged
+                # record + ~6.9 k cycles per 32-pixel tile of a wave (4 waves), times the number of rounds the grid
+                # needs on the resident slots -- the round quantisation (1 800 workgroups = 3.5 -> 4 rounds at 16 rows)
+                # matters as much as the re-staging
+                nblk = -(-H // trows) * -(-W // (32 * tcols))
+                rounds = -(-nblk // slots)
+                cost = rounds * (155 * lr_c * lr_r + 6900 * -(-(trows * tcols) // 4))
+                if best is None or cost < best[0]:
+                    best = (cost, trows, tcols, lr_r, lr_c)
         t = SatuTiling()
         if best is None:                                               # no window fits: gathers go to global memory
             t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = 8, 1, 0, 0
