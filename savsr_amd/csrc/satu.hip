@@ -374,10 +374,11 @@ struct Taps {
     float wgt[4];      // bilinear weights, 0 for taps outside the image
 };
 
-__device__ __forceinline__ Taps make_taps(float gxn, float gyn, float offx, float offy, int h, int w) {
+// onx, ony: the sampling offset already normalised as the reference does, (off * 2) / (size - 1)  (:285-287)
+__device__ __forceinline__ Taps make_taps(float gxn, float gyn, float onx, float ony, int h, int w) {
     const float fw1 = (float)(w - 1), fh1 = (float)(h - 1);
-    const float gx = gxn + (offx * 2.f) / fw1;           // :285,287
-    const float gy = gyn + (offy * 2.f) / fh1;           // :286,287
+    const float gx = gxn + onx;
+    const float gy = gyn + ony;
     float ix = ((gx + 1.f) / 2.f) * fw1;                 // grid_sampler_unnormalize, align_corners=True
     float iy = ((gy + 1.f) / 2.f) * fh1;
     ix = fminf(fmaxf(ix, -2.f), (float)w + 1.f);         // keeps every in-range tap intact
@@ -402,7 +403,7 @@ __device__ __forceinline__ Taps make_taps(float gxn, float gyn, float offx, floa
 
 template <bool FROM_LDS>
 __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int ly0, int lx0, const Taps& to, const Taps& ts,
-                                        const f32x4 rr, int half, int lane, bool valid, float* o, const float* cst) {
+                                        const f32x4 rr, int half, int lane, bool valid, unsigned o_off, const float* cst) {
     auto rec_of = [&](int ty, int tx) -> const f32x4* {
         if (FROM_LDS) return reinterpret_cast<const f32x4*>(lds + ((ty - ly0) * p.lrw + (tx - lx0)) * HR_LDS_REC);
         return reinterpret_cast<const f32x4*>(p.lrcat + ((long long)ty * p.w + tx) * REC);
@@ -410,19 +411,27 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
     const f32x4* ro[4] = {rec_of(to.ty[0], to.tx[0]), rec_of(to.ty[1], to.tx[1]), rec_of(to.ty[2], to.tx[2]), rec_of(to.ty[3], to.tx[3])};
     const f32x4* rs[4] = {rec_of(ts.ty[0], ts.tx[0]), rec_of(ts.ty[1], ts.tx[1]), rec_of(ts.ty[2], ts.tx[2]), rec_of(ts.ty[3], ts.tx[3])};
     // ---- the 32 compressed channels G(C x, off); t_j = sum_m r_m (C_m f0)_j -------------------------
-    float tj[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) tj[j] = 0.f;
+    // Both lanes of a pixel need all 8 t_j: each computes 4 of them (j = 4 half .. 4 half + 3: half the LDS reads
+    // and FMAs of this part) and the halves are exchanged with v_permlane32_swap.
+    float tjh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float wk = to.wgt[k];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const f32x4 v0 = ro[k][32 + 2 * m], v1 = ro[k][32 + 2 * m + 1];
+            const f32x4 v = ro[k][32 + 2 * m + half];
             const float wr = wk * rr[m];
-            tj[0] += wr * v0[0]; tj[1] += wr * v0[1]; tj[2] += wr * v0[2]; tj[3] += wr * v0[3];
-            tj[4] += wr * v1[0]; tj[5] += wr * v1[1]; tj[6] += wr * v1[2]; tj[7] += wr * v1[3];
+            tjh[0] += wr * v[0]; tjh[1] += wr * v[1]; tjh[2] += wr * v[2]; tjh[3] += wr * v[3];
         }
+    }
+    float tj[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned own = __float_as_uint(tjh[j]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(own, own, false, false);   // [0]: upper lanes get the lower half's value; [1]: lower lanes get the upper's
+        const float other = __uint_as_float(half ? sw[0] : sw[1]);
+        tj[j] = half ? other : tjh[j];
+        tj[4 + j] = half ? tjh[j] : other;
     }
     // ---- B operand of the expert MFMA: v[(n, j)] = r_n t_j, k = 16 ks + 8 half + j <-> n = 2 ks + half ----
     bf16x8 bh[2], bl[2];
@@ -470,7 +479,8 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
         }
         if (valid) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[(long long)(32 * t + acc_row(r, half)) * HW] = acc[r];
+            for (int r = 0; r < 16; ++r)       // uniform plane base (scalar arithmetic) + one per-lane 32-bit byte offset: no 64-bit VALU add per store
+                *(__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)(p.out + (long long)(32 * t + acc_row(r, 0)) * HW) + o_off) = acc[r];
         }
     }
 }
@@ -511,8 +521,14 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
         for (int e = tid; e < 2 * 2 * 2 * 64; e += 64 * HR_WAVES) reinterpret_cast<f32x4*>(cst)[e] = wsrc[e];
         if (tid < 16) reinterpret_cast<f32x4*>(cst + 2 * 2 * 2 * 64 * 4)[tid] = reinterpret_cast<const f32x4*>(p.wt.fusion_b)[tid];
         if (p.n_table <= HR_TABLE_LDS)
-            for (int e = tid; e < p.n_table * 2; e += 64 * HR_WAVES)
-                reinterpret_cast<f32x4*>(cst + 2 * 2 * 2 * 64 * 4 + 64)[e] = reinterpret_cast<const f32x4*>(p.table)[e];
+            for (int e = tid; e < p.n_table * 2; e += 64 * HR_WAVES) {
+                f32x4 v = reinterpret_cast<const f32x4*>(p.table)[e];
+                if (e & 1) {               // the offset quad: normalise once here, not per 32-pixel tile (4 fp32 divisions each)
+                    v[0] = (v[0] * 2.f) / (float)(p.w - 1); v[1] = (v[1] * 2.f) / (float)(p.h - 1);
+                    v[2] = (v[2] * 2.f) / (float)(p.w - 1); v[3] = (v[3] * 2.f) / (float)(p.h - 1);
+                }
+                reinterpret_cast<f32x4*>(cst + 2 * 2 * 2 * 64 * 4 + 64)[e] = v;
+            }
     }
     const float* tab = (p.n_table <= HR_TABLE_LDS) ? cst + 2 * 2 * 2 * 64 * 4 + 64 : nullptr;
     float* rowc = cst + 2 * 2 * 2 * 64 * 4 + 64 + HR_TABLE_LDS * SAVSR_SATU_TABLE;     // [ty] table row index (as int bits) | [ty] gyn
@@ -550,7 +566,11 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
         const long long ent = ((long long)__float_as_int(rowc[trow]) * p.n_uw + iw) * SAVSR_SATU_TABLE;
         const float* te = tab ? tab + ent : p.table + ent;
         const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
-        const f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
+        f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
+        if (!tab) {                                                   // (wave-uniform) global table: raw offsets
+            oo[0] = (oo[0] * 2.f) / (float)(p.w - 1); oo[1] = (oo[1] * 2.f) / (float)(p.h - 1);
+            oo[2] = (oo[2] * 2.f) / (float)(p.w - 1); oo[3] = (oo[3] * 2.f) / (float)(p.h - 1);
+        }
         const float gxn = col0 ? gxn0 : p.gxn[Xc], gyn = rowc[HR_MAX_ROWS + trow];
         if (stamps_on) { asm volatile("" :: "v"(rr[0]), "v"(oo[0])); }
         HR_MARK(0);                                                  // table lookup
@@ -565,9 +585,10 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
             inside = inside && (unsigned)(to.ty[k] - ly0) < (unsigned)p.lrh && (unsigned)(to.tx[k] - lx0) < (unsigned)p.lrw;
             inside = inside && (unsigned)(ts.ty[k] - ly0) < (unsigned)p.lrh && (unsigned)(ts.tx[k] - lx0) < (unsigned)p.lrw;
         }
-        float* o = p.out + (long long)Y * p.W + X;
-        if (__all(inside)) hr_tile<true>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o, cst);
-        else hr_tile<false>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o, cst);
+        // byte offset of this lane's pixel inside channel plane acc_row(r, 0); the half's +4 channels are folded in
+        const unsigned o_off = 4u * (unsigned)(Y * p.W + X) + (half ? 16u * (unsigned)p.out_plane : 0u);
+        if (__all(inside)) hr_tile<true>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
+        else hr_tile<false>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
         HR_MARK(2);                                                  // gathers + MFMA + store issue
     }
     if (stamps_on) {
@@ -650,6 +671,7 @@ extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float*
                                       const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream) {
     if (!satu_weights_ok(wt) || !lrcat || !table || !idx_h || !idx_w || !gyn || !gxn || !out) return fail_arg("satu_hr_upsample: null pointer");
     if (h < 2 || w < 2 || H < 1 || W < 1 || n_uw < 1 || out_plane < (int64_t)H * W) return fail_arg("satu_hr_upsample: shape (h, w >= 2, out_plane >= H*W required)");
+    if (out_plane * 64 * 4 >= ((int64_t)1 << 32)) return fail_arg("satu_hr_upsample: output of 4 GiB or more is not supported (32-bit store offsets)");
     if ((reinterpret_cast<uintptr_t>(lrcat) | reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(wt->fusion_b) |
          reinterpret_cast<uintptr_t>(wt->wbe_w)) & 15) {
         set_error("satu_hr_upsample: lrcat / table / fusion_b / wbe_w must be 16-byte aligned");
