@@ -15,19 +15,24 @@
 // Weights: pre-split, pre-packed bf16 image in exactly the LDS order the lanes read it:
 //   [cob][chunk][tap][kstep][t][part(hi,lo)][lane 64][8]  (1-KiB pieces).
 //
-// Workgroup = 8 waves, tile = 8 rows x 32 cols of pixels x (32 NT) output channels; wave w owns
-// row w.  The kernel is PERSISTENT: a workgroup walks tiles t = blockIdx.x, + gridDim.x, ... of
-// up to 6 independent convs of identical geometry (savsr_conv2d_batch).  Per tile the K loop
-// runs over phases of KC input channels x all taps; the next phase's weight slab and input tile
-// (split to hi/lo on the fly) are staged global -> registers -> LDS under the current phase's
-// MFMAs (double buffer, one barrier per phase) -- and the phase after a tile's last one is the
-// NEXT tile's first, so a tile's prologue latency hides under its predecessor's MFMAs and its
-// epilogue stores drain under its successor's (measured per tile before: prologue 4.6 k cycles,
-// epilogue + store drain 9 k, out of 37 k).  Operand fragments run two (tap, kstep) steps ahead
-// of their MFMAs with the issue order pinned by sched_barriers (hipcc otherwise sinks every
-// ds_read to just before its MFMA).  Epilogue: each wave transposes its 32 px x COT tile through
-// a private LDS slice (half the channels at a time) and stores whole pixel records, with fused
-// bias / activation / per-pixel mask / two residuals / global-average-pool partial sums.
+// Workgroup = 8 waves; tile = 8 rows x 32 cols of pixels x (32 NT) output channels, wave w owns row w (PXT = 1), or
+// 16 rows with wave w owning rows w and w + 8 (PXT = 2: one weight-fragment read feeds two pixel rows; used when a
+// launch has >= 200 such tiles).  The kernel is PERSISTENT: <= 256 workgroups walk tiles t = blockIdx.x, + gridDim.x,
+// ... of up to 6 independent convs of identical geometry (savsr_conv2d_batch).
+//
+// Pipeline (DESIGN.md section 4a has the measurements behind each choice).  The phases (KC input channels x all taps)
+// of a workgroup's tiles form one linear sequence walked by a staging cursor.  While phase c computes from LDS buffer
+// c % 2: the weight slab of phase c+1 arrives in the other buffer by LDS-DMA (the packed image IS the LDS image); the
+// activations of phase c+1, loaded into registers during phase c-1, are split to (hi, lo) bf16 and stored to LDS; the
+// activations of phase c+2 are loaded into the freed registers.  All of that is issued in small pieces BETWEEN the
+// three MFMA groups of every (tap, kstep) step, because the two waves of a SIMD run in lockstep and share the issue
+// port.  ONE barrier per phase, placed where every fragment read of the phase has been issued, so that the last steps
+// already read the next phase's -- or the next TILE's -- first fragments: the MFMA stream does not stop at phase or
+// tile boundaries, and a tile's epilogue stores drain under its successor's MFMAs.  Fragment reads run one or two
+// steps ahead of their MFMAs with the issue order pinned by sched_barriers (hipcc otherwise sinks every ds_read to
+// just before its MFMA).  Epilogue: each wave transposes its tile through an LDS slice, 32 channels at a time, and
+// stores whole pixel records, with fused bias / activation / per-pixel mask / two residuals / global-average-pool
+// partial sums; descriptor fields are pinned in scalars once per tile and every access names the global address space.
 //
 // Replaces: every nn.Conv2d / F.conv2d of savsr_arch.py (see include/savsr_hip.h).
 #include "common.hpp"
@@ -413,11 +418,13 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         const float* e_r1 = p.res1;
         const float* e_r2 = p.res2;
         float* e_out = p.out;
+        float* e_pool = p.pool;
         int e_act = p.act, e_opix = p.out_pix, e_r1pix = p.res1_pix, e_r2pix = p.res2_pix;
         float e_slope = p.slope, e_r2s = p.res2_scale;
-        asm volatile("" : "+s"(e_bias), "+s"(e_mul), "+s"(e_r1), "+s"(e_r2), "+s"(e_out));
+        asm volatile("" : "+s"(e_bias), "+s"(e_mul), "+s"(e_r1), "+s"(e_r2), "+s"(e_out), "+s"(e_pool));
         asm volatile("" : "+s"(e_act), "+s"(e_opix), "+s"(e_r1pix), "+s"(e_r2pix), "+s"(e_slope), "+s"(e_r2s));
         const int COUT = mp.cout;
+        const bool lrelu_as_max = e_slope >= 0.f && e_slope <= 1.f;
         float* ep_base = reinterpret_cast<float*>(EP_ALIAS ? smem + (buf ^ 1) * B_UNITS : smem + 2 * B_UNITS + 2 * W_UNITS);
         float* ep = ep_base + wave * (32 * EPS);
         const int c4 = lane & 7;                                // lane l always handles channel quad l % 8
@@ -484,10 +491,17 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) v[i][q] = fmaxf(v[i][q], 0.f);
                         } else if (e_act == SAVSR_ACT_LRELU) {
+                            if (lrelu_as_max) {       // slope in [0, 1]: max(v, slope v) is the same value for every v, in half the VALU
+#pragma unroll                                        // instructions (the epilogue is VALU-issue-bound: both waves of a SIMD share the port)
+                                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int i = 0; i < 2; ++i)
+                                    for (int q = 0; q < 4; ++q) v[i][q] = fmaxf(v[i][q], v[i][q] * e_slope);
+                            } else {
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) v[i][q] = v[i][q] > 0.f ? v[i][q] : v[i][q] * e_slope;
+                                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) v[i][q] = v[i][q] > 0.f ? v[i][q] : v[i][q] * e_slope;
+                            }
                         } else if (e_act == SAVSR_ACT_SIGMOID) {
 #pragma unroll
                             for (int i = 0; i < 2; ++i)
@@ -515,7 +529,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                         for (int i = 0; i < 2; ++i) {
                             if (i == 0 ? ok0 : ok1) {
                                 stg4(e_out, 4u * (unsigned)((p0 + 8 * i) * e_opix + co), v[i]);
-                                ps[0] += v[i][0]; ps[1] += v[i][1]; ps[2] += v[i][2]; ps[3] += v[i][3];
+                                if (e_pool) { ps[0] += v[i][0]; ps[1] += v[i][1]; ps[2] += v[i][2]; ps[3] += v[i][3]; }
                             }
                         }
                     }
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         }
         }
         CV_MARK(4);
-        if (p.pool) {
+        if (e_pool) {
             // AdaptiveAvgPool2d(1) of the tensor just produced (savsr_arch.py:146,515), fused: lanes with equal
             // l % 8 hold the same channel quad -> butterfly over the 8 pixel groups, then the waves are summed in
             // wave order through LDS (deterministic) and one row per 8-row band of the tile is written (the row
@@ -622,7 +636,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 for (int wv = 0; wv < CONV_TH; ++wv) sacc += pl_[(r * CONV_TH + wv) * COT + ch];
                 const int band = cur.ty * PXT + r;                       // 8-row band of the image
                 if (cob * COT + ch < COUT && band * CONV_TH < H)
-                    p.pool[(long long)(band * mp.ntx + cur.tx) * p.pool_stride + cob * COT + ch] = sacc;
+                    e_pool[(long long)(band * mp.ntx + cur.tx) * p.pool_stride + cob * COT + ch] = sacc;
             }
             __syncthreads();                         // the slices are reused by the next tile's epilogue
         } else if (EP_ALIAS) {
