@@ -413,7 +413,10 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
     // ---- the 32 compressed channels G(C x, off); t_j = sum_m r_m (C_m f0)_j -------------------------
     // Both lanes of a pixel need all 8 t_j: each computes 4 of them (j = 4 half .. 4 half + 3: half the LDS reads
     // and FMAs of this part) and the halves are exchanged with v_permlane32_swap.
-    float tjh[4] = {0.f, 0.f, 0.f, 0.f};
+    // explicit 2-vectors: one v_pk_fma_f32 per pair (left to the SLP vectoriser this loop became pk_mul + v_mov shuffles +
+    // scalar adds, ~20 instructions per 8 MACs, and the kernel is VALU-issue-bound)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 t01 = {0.f, 0.f}, t23 = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float wk = to.wgt[k];
@@ -421,9 +424,12 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
         for (int m = 0; m < 4; ++m) {
             const f32x4 v = ro[k][32 + 2 * m + half];
             const float wr = wk * rr[m];
-            tjh[0] += wr * v[0]; tjh[1] += wr * v[1]; tjh[2] += wr * v[2]; tjh[3] += wr * v[3];
+            const f32x2 w2 = {wr, wr}, v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+            t01 = __builtin_elementwise_fma(w2, v01, t01);
+            t23 = __builtin_elementwise_fma(w2, v23, t23);
         }
     }
+    const float tjh[4] = {t01[0], t01[1], t23[0], t23[1]};
     float tj[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -486,11 +492,14 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
 }
 
 constexpr int HR_WAVES = 4;       // waves per workgroup (the kernel needs ~250 VGPRs: 2 waves per SIMD; at 128 it spills 516 B and runs 3.6x slower)
+// DIAG = the instrumented build (section stamps, no-store experiment); the product launch uses DIAG = false: kept as a
+// run-time switch the stamp accumulators cost ~30 vector instructions per tile in a VALU-issue-bound kernel.
+template <bool DIAG>
 __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int X0 = blockIdx.x * 32 * p.txw, Y0 = blockIdx.y * p.ty;
-    const long long t_entry = SATU_T();
+    const long long t_entry = DIAG ? SATU_T() : 0;
 
     // ---- stage the LRcat window of this tile, the expert-MFMA A operands, the bias and the phase table -------
     float* cst = lds + p.lrh * p.lrw * HR_LDS_REC;
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the window DMA (not counted by the compiler)
     __syncthreads();
 
-    const int dbg_all = __builtin_amdgcn_readfirstlane(g_satu_stamps_on);
+    const int dbg_all = DIAG ? __builtin_amdgcn_readfirstlane(g_satu_stamps_on) : 0;
     const int stamps_on = dbg_all & 1;
     const bool dbg_nostore = dbg_all & 2;                            // timing experiment only: skip the output stores
     long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
     const int iw0 = p.idx_w[Xc0];
     const float gxn0 = p.gxn[Xc0];
     for (int T = wave; T < ntile; T += HR_WAVES) {
-        const int trow = T / p.txw;
+        const int trow = p.txw == 1 ? T : T / p.txw;                // (a run-time integer division is ~14 vector instructions)
         const int Y = Y0 + trow;
         const int Xb = X0 + (T - trow * p.txw) * 32;
         if (Y >= p.H || Xb >= p.W) continue;                      // wave-uniform
@@ -608,7 +617,10 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
 
 using namespace savsr;
 
+static int g_satu_diag_host = 0;      // != 0: launch the instrumented HR kernel
+
 extern "C" int savsr_debug_satu_stamps(int enable) {
+    g_satu_diag_host = enable;
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_satu_stamps_on), &enable, sizeof(int));
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -616,7 +628,7 @@ extern "C" int savsr_debug_satu_stamps(int enable) {
 // Diagnostics: resident workgroups per CU the runtime predicts for the HR / LR kernels with `lds_bytes` of dynamic LDS.
 extern "C" int savsr_debug_satu_occupancy(int which, int lds_bytes) {
     int n = -1;
-    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel, 64 * HR_WAVES, (size_t)lds_bytes)
+    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel<false>, 64 * HR_WAVES, (size_t)lds_bytes)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_kernel, 512, (size_t)lds_bytes);
     return e == hipSuccess ? n : -(int)e;
 }
@@ -693,11 +705,13 @@ extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float*
     if (lds > 160 * 1024) return fail_arg("satu_hr_upsample: staged window exceeds 160 KiB of LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_hr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_hr_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_hr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_error("satu_hr_upsample: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
     dim3 grid((W + 32 * p.txw - 1) / (32 * p.txw), (H + p.ty - 1) / p.ty);
-    hipLaunchKernelGGL(satu_hr_kernel, grid, dim3(64 * HR_WAVES), lds, static_cast<hipStream_t>(stream), p);
+    if (g_satu_diag_host) hipLaunchKernelGGL(satu_hr_kernel<true>, grid, dim3(64 * HR_WAVES), lds, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(satu_hr_kernel<false>, grid, dim3(64 * HR_WAVES), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_hr_kernel");
 }
