@@ -222,6 +222,8 @@ int savsr_tail_residual(const float* feat, int64_t feat_plane, const float* tail
                         const float* center, int h, int w, int H, int W, float* out, void* stream);
 
 /* ---- diagnostics (synchronous, never called by the product path) ----------------------------
+ * While a stamps mode is on, the conv / SATU launches run INSTRUMENTED builds of their kernels (template parameter
+ * DIAG); with the mode off (the default) the product kernels carry no diagnostic code at all.
  * Conv kernel, savsr_debug_conv_stamps(mode): 0 off; 1 per-workgroup s_memtime stamps [blk][6] = entry, after
  * the prologue, after the first K phase, after the first tile's K loop, after the stores drained,
  * s_memrealtime at entry; 3 + w: accumulated section times of wave w ([blk][0..4] = steps after the barrier,

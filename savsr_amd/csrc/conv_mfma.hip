@@ -99,7 +99,9 @@ __device__ __forceinline__ void stg1(float* base, unsigned idx, float v) {
     *((SAVSR_GLOBAL float*)base + idx) = v;
 }
 
-template <int KS, int NT, int PXT>
+// DIAG: the instrumented build (section stamps, timing experiments), launched only while savsr_debug_conv_stamps is on;
+// as run-time switches the diagnostics cost scalar registers (and spills) in every step of the product kernel.
+template <int KS, int NT, int PXT, bool DIAG>
 __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams mp) {
     constexpr int TH = CONV_TH * PXT, NTHR = 64 * CONV_TH;   // wave w owns tile rows w, w + 8, .. (PXT of them)
     constexpr int TAPS = KS * KS, HALO = KS / 2;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int tiles_per_cob = mp.ntx * mp.nty;
     const int total = mp.nconv * mp.ncob * tiles_per_cob;
-    const int dbg_all = __builtin_amdgcn_readfirstlane(g_conv_stamps_on);
+    const int dbg_all = DIAG ? __builtin_amdgcn_readfirstlane(g_conv_stamps_on) : 0;
     const int stamps_on = dbg_all & 15;
     const bool dbg_nostage = dbg_all & 16, dbg_nofrag = dbg_all & 32;   // timing experiments only (results are wrong)
 
@@ -651,15 +653,17 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         for (int i = 0; i < 5; ++i) g_conv_stamps[blockIdx.x * STAMP_N + i] = sec[i];
 }
 
-template <int KS, int NT, int PXT>
-static int launch_conv(const MultiConvParams& mp, hipStream_t st) {
+static int g_conv_diag_host = 0;      // != 0: launch the instrumented kernels
+
+template <int KS, int NT, int PXT, bool DIAG>
+static int launch_conv_impl(const MultiConvParams& mp, hipStream_t st) {
     constexpr int TAPS = KS * KS, HALO = KS / 2, KC = conv_kc(KS), KSTEPS = KC / 16;
     constexpr int NPX = (CONV_TH * PXT + 2 * HALO) * (CONV_TW + 2 * HALO);
     constexpr size_t lds = 16ull * 2 * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64) + (PXT > 1 ? 0ull : 4ull * CONV_TH * 32 * 36);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;      // benign race: idempotent attribute set
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT, DIAG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("conv: hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds, hipGetErrorString(e));
@@ -669,8 +673,13 @@ static int launch_conv(const MultiConvParams& mp, hipStream_t st) {
     }
     const int total = mp.nconv * mp.ncob * mp.ntx * mp.nty;
     const int grid = total < CONV_PERSISTENT_BLOCKS ? total : CONV_PERSISTENT_BLOCKS;   // one resident workgroup per CU
-    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, PXT>), dim3(grid), dim3(64 * CONV_TH), lds, st, mp);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, PXT, DIAG>), dim3(grid), dim3(64 * CONV_TH), lds, st, mp);
     return check_launch("conv_bf16x3_kernel");
+}
+
+template <int KS, int NT, int PXT>
+static int launch_conv(const MultiConvParams& mp, hipStream_t st) {
+    return g_conv_diag_host ? launch_conv_impl<KS, NT, PXT, true>(mp, st) : launch_conv_impl<KS, NT, PXT, false>(mp, st);
 }
 
 }  // namespace savsr
@@ -678,6 +687,7 @@ static int launch_conv(const MultiConvParams& mp, hipStream_t st) {
 using namespace savsr;
 
 extern "C" int savsr_debug_conv_stamps(int enable) {
+    g_conv_diag_host = enable;
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps_on), &enable, sizeof(int));
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -111,6 +111,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, const void* lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+template <bool DIAG>      // DIAG: instrumented build (section stamps), launched only while savsr_debug_satu_stamps is on
 __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xt = smem;                                                   // [432][36]: replicate-padded x tile of one channel group
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
     const int cy = gy < p.h ? gy : p.h - 1, cx = gx < p.w ? gx : p.w - 1;
     const long long cpix = ((long long)cy * p.row_px + cx) * p.pix + 8 * half;
 
-    const int stamps_on = __builtin_amdgcn_readfirstlane(g_satu_stamps_on) & 1;
+    const int stamps_on = DIAG ? __builtin_amdgcn_readfirstlane(g_satu_stamps_on) & 1 : 0;
     long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t_prev = stamps_on ? SATU_T() : 0;
     const long long t_begin = t_prev;
@@ -629,7 +630,7 @@ extern "C" int savsr_debug_satu_stamps(int enable) {
 extern "C" int savsr_debug_satu_occupancy(int which, int lds_bytes) {
     int n = -1;
     hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel<false>, 64 * HR_WAVES, (size_t)lds_bytes)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_kernel, 512, (size_t)lds_bytes);
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_kernel<false>, 512, (size_t)lds_bytes);
     return e == hipSuccess ? n : -(int)e;
 }
 
@@ -669,12 +670,14 @@ extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x,
     static_assert(lds <= 160 * 1024, "LR stage LDS budget");
     static bool attr_done = false;      // benign race: idempotent attribute set
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_lr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_lr_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_lr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("satu_lr_stage: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
     dim3 grid((w + LR_TW - 1) / LR_TW, (h + LR_TH - 1) / LR_TH);
-    hipLaunchKernelGGL(satu_lr_kernel, grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
+    if (g_satu_diag_host) hipLaunchKernelGGL(satu_lr_kernel<true>, grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(satu_lr_kernel<false>, grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_lr_kernel");
 }
 
