@@ -26,8 +26,8 @@ import torch  # noqa: E402
 LR_H, LR_W, SCALE = 180, 320, (4, 4)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes of one SATU stage from rocprofv3 PMC passes (FETCH_SIZE x 2 for 16-B/lane streaming reads on gfx950,
-# WRITE_SIZE as read; separate passes): profiles/r01_satu_pmc_traffic.csv.  Config 2 only.
-SATU_PMC_TRAFFIC_BYTES = 391458368
+# WRITE_SIZE as read; separate passes): profiles/r01b_satu_pmc_traffic.csv (LR + HR kernels).  Config 2 only.
+SATU_PMC_TRAFFIC_BYTES = 383112499
 
 
 def effective_cpus():
