@@ -63,20 +63,44 @@ struct OscBatch { savsr_osconv_attn_desc d[OSC_MAX_BATCH]; };
 constexpr int OSC_PARTS = 32;      // interleaved row slices of the pooled-sum reduction
 
 // scale routing layer 1 (savsr_arch.py:123-125,143-146): v1 = ReLU(L1 [1/sh, 1/sw, mean] + c1)
+// A workgroup computes OSC_L1_ROWS rows of the layer; every workgroup first rebuilds the pooled mean from the producer's
+// per-tile partial sums (177 KB at cin = 192), so few, fat workgroups and 16-B loads: with 8 rows per workgroup and
+// scalar loads that redundant reduction was most of this kernel's 22 us (now 16).  Tried: the whole routing + attention
+// chain in ONE workgroup per OSConv -- 41-97 us: one HBM/L2 latency per dependent stage with a single CU's worth of
+// loads in flight; the multi-workgroup split below is faster.
+constexpr int OSC_L1_ROWS = 32;
 __global__ __launch_bounds__(512) void osconv_l1_kernel(const OscBatch bt) {
     const savsr_osconv_attn_desc& d = bt.d[blockIdx.y];
-    extern __shared__ float v0[];           // [cin + 2] then scratch [OSC_PARTS][cin]
-    float* scr = v0 + d.cin + 2;
+    extern __shared__ __attribute__((aligned(16))) float v0s[];     // [4 pad + cin] (v0 = [1/sh, 1/sw, mean] starts at +2) then scratch [OSC_PARTS][cin]
+    float* v0 = v0s + 2;
+    float* scr = v0s + 4 + d.cin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { v0[0] = d.inv_sh; v0[1] = d.inv_sw; }
-    // pooled mean from the block-ordered partial sums: OSC_PARTS interleaved row slices per channel (short, fully
-    // unrolled chains of independent loads), then a fixed-order add over the slices (deterministic)
-    for (int i = tid; i < d.cin * OSC_PARTS; i += 512) {
-        const int c = i % d.cin, part = i / d.cin;
-        float s = 0.f;
+    // this wave's weight rows do not depend on the pooled mean: their loads go out first and land under the reduction
+    // (cin <= 320, checked by the launcher: a row has <= 322 = 6 x 64 columns)
+    constexpr int RPW = OSC_L1_ROWS / 8, MAXJ = 6;
+    const int r0 = blockIdx.x * OSC_L1_ROWS + wave * RPW;
+    float wv[RPW][MAXJ];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+        for (int q = 0; q < MAXJ; ++q) {
+            const int c = lane + 64 * q;
+            wv[j][q] = (r0 + j < 2 * d.cin && c < d.cin + 2) ? d.l1_w[(long long)(r0 + j) * (d.cin + 2) + c] : 0.f;
+        }
+    // pooled mean from the block-ordered partial sums: OSC_PARTS interleaved row slices per channel quad (short, fully
+    // unrolled chains of independent 16-B loads), then a fixed-order add over the slices (deterministic)
+    const int c4n = d.cin / 4;
+    const f32x4* part4 = reinterpret_cast<const f32x4*>(d.partial);
+    for (int i = tid; i < c4n * OSC_PARTS; i += 512) {
+        const int c4 = i % c4n, part = i / c4n;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-        for (int b = part; b < d.nblk; b += OSC_PARTS) s += d.partial[(long long)b * d.cin + c];
-        scr[part * d.cin + c] = s;
+        for (int b = part; b < d.nblk; b += OSC_PARTS) {
+            const f32x4 v = part4[(long long)b * c4n + c4];
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+        *reinterpret_cast<f32x4*>(scr + part * d.cin + 4 * c4) = s;
     }
     __syncthreads();
     for (int c = tid; c < d.cin; c += 512) {
@@ -86,10 +110,18 @@ __global__ __launch_bounds__(512) void osconv_l1_kernel(const OscBatch bt) {
         v0[2 + c] = s * d.inv_n;
     }
     __syncthreads();
-    const int r = blockIdx.x * 8 + wave;
-    if (r >= 2 * d.cin) return;
-    const float acc = wave_dot(d.l1_w + (long long)r * (d.cin + 2), v0, d.cin + 2, lane);
-    if (lane == 0) d.v1[r] = fmaxf(acc + d.l1_b[r], 0.f);
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int r = r0 + j;
+        float acc = 0.f;                              // per lane in column order, then across the wave: the order of wave_dot
+#pragma unroll
+        for (int q = 0; q < MAXJ; ++q) {
+            const int c = lane + 64 * q;
+            if (c < d.cin + 2) acc += wv[j][q] * v0[c];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0 && r < 2 * d.cin) d.v1[r] = fmaxf(acc + d.l1_b[r], 0.f);
+    }
 }
 
 // scale routing layer 2 (savsr_arch.py:126-127): v2 = ReLU(L2 v1 + c2)
@@ -116,26 +148,80 @@ __global__ __launch_bounds__(512) void osconv_aggregate_kernel(const OscBatch bt
     float* a = v2 + d.cin;                 // [hidden]
     float* gates = a + d.hidden;           // [cin + cout + 9 + knum]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this thread's slice of the 8 banks does not depend on the gates: its loads go out first and land under the
+    // attention heads below (knum <= OSC_MAX_KNUM banks are preloaded; more fall back to loading in the loop)
+    constexpr int OSC_MAX_KNUM = 8;
+    const long long unit = (long long)blockIdx.x * 512 + tid;
+    const bool live = unit < d.nunits;
+    f32x4 bw[OSC_MAX_KNUM][2];
+#pragma unroll
+    for (int k = 0; k < OSC_MAX_KNUM; ++k) {
+        bw[k][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bw[k][1] = bw[k][0];
+        if (live && k < d.knum) {
+            const f32x4* b = reinterpret_cast<const f32x4*>(d.bank + ((long long)k * d.nunits + unit) * 8);
+            bw[k][0] = b[0];
+            bw[k][1] = b[1];
+        }
+    }
+    // ... and so do the head weights of this wave / thread (hidden <= 32 and cin <= 320, checked by the launcher):
+    //   fc rows wave, wave + 8, .. (<= 4 rows x 5 column slices) and ONE gate row per thread (ngate <= 512 covers
+    //   cin + cout + 9 + knum of every OSConv of the network; larger ones loop below)
+    constexpr int FC_ROWS = 4, FC_J = 5, GH = 32;
+    float fw[FC_ROWS][FC_J];
+#pragma unroll
+    for (int j = 0; j < FC_ROWS; ++j)
+#pragma unroll
+        for (int q = 0; q < FC_J; ++q) {
+            const int r = wave + 8 * j, c = lane + 64 * q;
+            fw[j][q] = (r < d.hidden && c < d.cin) ? d.fc_w[(long long)r * d.cin + c] : 0.f;
+        }
+    const int ngate = d.cin + d.cout + 9 + d.knum;
+    auto gate_row = [&](int i, float& bias) -> const float* {
+        int j = i;
+        if (j < d.cin) { bias = d.ch_b[j]; return d.ch_w + (long long)j * d.hidden; }
+        if ((j -= d.cin) < d.cout) { bias = d.fl_b[j]; return d.fl_w + (long long)j * d.hidden; }
+        if ((j -= d.cout) < 9) { bias = d.sp_b[j]; return d.sp_w + (long long)j * d.hidden; }
+        j -= 9;
+        bias = d.kn_b[j];
+        return d.kn_w + (long long)j * d.hidden;
+    };
+    float gw[GH], gbias = 0.f;
+    {
+        const float* wr = tid < ngate ? gate_row(tid, gbias) : nullptr;
+#pragma unroll
+        for (int k = 0; k < GH; ++k) gw[k] = (wr && k < d.hidden) ? wr[k] : 0.f;
+    }
     for (int i = tid; i < d.cin; i += 512) v2[i] = d.v2[i];
     __syncthreads();
-    for (int r = wave; r < d.hidden; r += 8) {
-        const float acc = wave_dot(d.fc_w + (long long)r * d.cin, v2, d.cin, lane);
-        if (lane == 0) a[r] = fmaxf(acc * d.bn_scale[r] + d.bn_shift[r], 0.f);
+#pragma unroll
+    for (int j = 0; j < FC_ROWS; ++j) {
+        const int r = wave + 8 * j;
+        float acc = 0.f;                              // per lane in column order, then across the wave: the order of wave_dot
+#pragma unroll
+        for (int q = 0; q < FC_J; ++q) {
+            const int c = lane + 64 * q;
+            if (c < d.cin) acc += fw[j][q] * v2[c];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0 && r < d.hidden) a[r] = fmaxf(acc * d.bn_scale[r] + d.bn_shift[r], 0.f);
     }
     __syncthreads();
-    const int ngate = d.cin + d.cout + 9 + d.knum;
-    for (int i = tid; i < ngate; i += 512) {
-        const float* wr;
+    if (tid < ngate) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < GH; ++k)
+            if (k < d.hidden) acc += gw[k] * a[k];
+        acc += gbias;
+        gates[tid] = (tid < d.cin + d.cout + 9) ? sigmoidf_(acc) : acc;   // kernel logits stay raw here
+    }
+    for (int i = tid + 512; i < ngate; i += 512) {
         float bias;
-        int j = i;
-        if (j < d.cin) { wr = d.ch_w + (long long)j * d.hidden; bias = d.ch_b[j]; }
-        else if ((j -= d.cin) < d.cout) { wr = d.fl_w + (long long)j * d.hidden; bias = d.fl_b[j]; }
-        else if ((j -= d.cout) < 9) { wr = d.sp_w + (long long)j * d.hidden; bias = d.sp_b[j]; }
-        else { j -= 9; wr = d.kn_w + (long long)j * d.hidden; bias = d.kn_b[j]; }
+        const float* wr = gate_row(i, bias);
         float acc = 0.f;
         for (int k = 0; k < d.hidden; ++k) acc += wr[k] * a[k];
         acc += bias;
-        gates[i] = (i < d.cin + d.cout + 9) ? sigmoidf_(acc) : acc;   // kernel logits stay raw here
+        gates[i] = (i < d.cin + d.cout + 9) ? sigmoidf_(acc) : acc;
     }
     __syncthreads();
     float* ka = gates + d.cin + d.cout + 9;
@@ -151,8 +237,7 @@ __global__ __launch_bounds__(512) void osconv_aggregate_kernel(const OscBatch bt
         for (int i = tid; i < ngate; i += 512) d.att[i] = gates[i];
 
     // ---- this workgroup's slice of the weight image: one 8-element lane unit per thread ----
-    const long long unit = (long long)blockIdx.x * 512 + tid;
-    if (unit >= d.nunits) return;
+    if (!live) return;
     const int cot = conv_cot(d.cout), nt = cot / 32, nchunk = d.cin / 16;
     const long long group = unit >> 6;            // (cob, chunk, tap, t); KSTEPS == 1 for 3x3
     const int ln = (int)(unit & 63), row = ln & 31, kh = ln >> 5;
@@ -164,7 +249,15 @@ __global__ __launch_bounds__(512) void osconv_aggregate_kernel(const OscBatch bt
     const int co = cob * cot + 32 * t + row;
     const int ci0 = chunk * 16 + kh * 8;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-    for (int k = 0; k < d.knum; ++k) {
+#pragma unroll
+    for (int k = 0; k < OSC_MAX_KNUM; ++k)
+        if (k < d.knum) {
+            const f32x4 w0 = bw[k][0], w1 = bw[k][1];
+            const float kk = ka[k];
+            s0[0] += kk * w0[0]; s0[1] += kk * w0[1]; s0[2] += kk * w0[2]; s0[3] += kk * w0[3];
+            s1[0] += kk * w1[0]; s1[1] += kk * w1[1]; s1[2] += kk * w1[2]; s1[3] += kk * w1[3];
+        }
+    for (int k = OSC_MAX_KNUM; k < d.knum; ++k) {
         const f32x4* b = reinterpret_cast<const f32x4*>(d.bank + ((long long)k * d.nunits + unit) * 8);
         const f32x4 w0 = b[0], w1 = b[1];
         const float kk = ka[k];
@@ -259,14 +352,14 @@ extern "C" int savsr_channel_sums(const float* const* src, const int32_t* src_pi
 }
 
 static int check_osconv_desc(const savsr_osconv_attn_desc* d) {
-    if (d->cin < 16 || (d->cin % 16) || d->cout < 1 || d->hidden < 1 || d->knum < 1 || d->knum > 64 || d->nblk < 1)
-        return fail_arg("osconv_weights: shape (cin multiple of 16)");
+    if (d->cin < 16 || (d->cin % 16) || d->cin > 320 || d->cout < 1 || d->hidden < 1 || d->hidden > 32 || d->knum < 1 || d->knum > 64 || d->nblk < 1)
+        return fail_arg("osconv_weights: shape (cin multiple of 16, <= 320; hidden <= 32)");
     if (!d->partial || !d->l1_w || !d->l1_b || !d->l2_w || !d->l2_b || !d->fc_w || !d->bn_scale || !d->bn_shift || !d->ch_w ||
         !d->ch_b || !d->fl_w || !d->fl_b || !d->sp_w || !d->sp_b || !d->kn_w || !d->kn_b || !d->v1 || !d->v2 || !d->bank || !d->wimg_out)
         return fail_arg("osconv_weights: null pointer");
     if (d->nunits * 8 != savsr_conv_packed_elems(d->cout, d->cin, 3)) return fail_arg("osconv_weights: nunits != packed_elems/8");
-    if ((reinterpret_cast<uintptr_t>(d->bank) | reinterpret_cast<uintptr_t>(d->wimg_out)) & 15) {
-        set_error("osconv_weights: bank / wimg_out must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(d->bank) | reinterpret_cast<uintptr_t>(d->wimg_out) | reinterpret_cast<uintptr_t>(d->partial)) & 15) {
+        set_error("osconv_weights: bank / wimg_out / partial must be 16-byte aligned");
         return SAVSR_E_ALIGN;
     }
     return 0;
@@ -287,7 +380,7 @@ extern "C" int savsr_osconv_weights_batch(const savsr_osconv_attn_desc* descs, i
     for (int i = n; i < OSC_MAX_BATCH; ++i) bt.d[i] = descs[0];
     const savsr_osconv_attn_desc* d = descs;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(osconv_l1_kernel, dim3((2 * d->cin + 7) / 8, n), dim3(512), sizeof(float) * ((OSC_PARTS + 1) * d->cin + 2), st, bt);
+    hipLaunchKernelGGL(osconv_l1_kernel, dim3((2 * d->cin + OSC_L1_ROWS - 1) / OSC_L1_ROWS, n), dim3(512), sizeof(float) * ((OSC_PARTS + 1) * d->cin + 4), st, bt);
     int rc = check_launch("osconv_l1_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(osconv_l2_kernel, dim3((d->cin + 7) / 8, n), dim3(512), sizeof(float) * 2 * d->cin, st, bt);
