@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 9
+#define SAVSR_ABI_VERSION 10
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -220,6 +220,17 @@ int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int
  * out: [3][H][W] contiguous. */
 int savsr_tail_residual(const float* feat, int64_t feat_plane, const float* tail_w /* [3][64][3][3] */, const float* tail_b,
                         const float* center, int h, int w, int H, int W, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PSNR-Y / SSIM-Y of one output frame with the reference's numerics (SURVEY section 8, row f3 -- the step after the
+ * hot path): tensor2img quantisation (lbasicsr/utils/img_util.py:66-90), BT.601 luma (metrics/metric_util.py:32-45,
+ * utils/color_util.py:59-65), calculate_psnr / calculate_ssim (metrics/psnr_ssim.py:42-48, 172-200).
+ * sr, gt: RGB planar fp32 [3] planes of [H][W] (*_plane floats apart), values in [0,1] before clamping.
+ * partial: scratch of savsr_metrics_blocks(H, W, crop_border) * 2 doubles; out: 2 doubles = PSNR-Y (inf for
+ * identical images), SSIM-Y.  Both stay on the device; the calls only enqueue. */
+int savsr_metrics_blocks(int H, int W, int crop_border);       /* < 0: the cropped image is smaller than 11 x 11 */
+int savsr_metrics_psnr_ssim_y(const float* sr, int64_t sr_plane, const float* gt, int64_t gt_plane, int H, int W,
+                              int crop_border, double* partial, double* out, void* stream);
 
 /* ---- diagnostics (synchronous, never called by the product path) ----------------------------
  * While a stamps mode is on, the conv / SATU launches run INSTRUMENTED builds of their kernels (template parameter

@@ -81,14 +81,21 @@ def validate_folder(net: Callable, lq_frames: torch.Tensor, gt_frames: Sequence[
     mine = frame_indices(n, rank, world)
     rows = torch.zeros(len(mine), 2, dtype=torch.float64)
     net.set_scale(scale)
+    on_gpu = device is not None and device.type == "cuda"
+    if on_gpu:                                        # metrics stay on the device until the per-dataset gather
+        from .metrics_gpu import psnr_ssim_y
+        rows = rows.to(device)
     for k, idx in enumerate(mine):
         win = lq_frames[window_indices(idx, n, num_frame, padding)].unsqueeze(0)
         if device is not None:
             win = win.to(device)
         out = net(win)
-        sr, gt = tensor2img(out[0]), tensor2img(gt_frames[idx])
-        rows[k, 0] = calculate_psnr(sr, gt, 0, test_y_channel=True)
-        rows[k, 1] = calculate_ssim(sr, gt, 0, test_y_channel=True)
-    if device is not None and world > 1 and device.type == "cuda":
-        return gather_rows(rows.to(device), n, rank, world).cpu()
+        if on_gpu:
+            psnr_ssim_y(out[0], gt_frames[idx].to(device), 0, out=rows[k])
+        else:
+            sr, gt = tensor2img(out[0]), tensor2img(gt_frames[idx])
+            rows[k, 0] = calculate_psnr(sr, gt, 0, test_y_channel=True)
+            rows[k, 1] = calculate_ssim(sr, gt, 0, test_y_channel=True)
+    if on_gpu:
+        return gather_rows(rows, n, rank, world).cpu()
     return gather_rows(rows, n, rank, world)
