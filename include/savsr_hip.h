@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 10
+#define SAVSR_ABI_VERSION 11
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -231,6 +231,15 @@ int savsr_tail_residual(const float* feat, int64_t feat_plane, const float* tail
 int savsr_metrics_blocks(int H, int W, int crop_border);       /* < 0: the cropped image is smaller than 11 x 11 */
 int savsr_metrics_psnr_ssim_y(const float* sr, int64_t sr_plane, const float* gt, int64_t gt_plane, int H, int W,
                               int crop_border, double* partial, double* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One axis of the anti-aliased bicubic resize behind the reference's LR synthesis (SURVEY section 8, row f2 -- the step
+ * before the hot path): lbasicsr/data/data_util.py:371-420 -> torchvision T.Resize(BICUBIC, antialias=True) -> ATen
+ * _upsample_bicubic2d_aa.  in: [planes][h][w] fp32; axis 0 resizes the width (out [planes][h][out_size]), axis 1 the
+ * height (out [planes][out_size][w]).  xmin / xsize / weights[out_size][max_taps]: the per-output-index windows and
+ * normalised weights as ATen computes them (savsr_amd/resize_gpu.py::aa_tables).  Width first, then height. */
+int savsr_resize_aa_axis(const float* in, int planes, int h, int w, int axis, int out_size, const int32_t* xmin,
+                         const int32_t* xsize, const float* weights, int max_taps, float* out, void* stream);
 
 /* ---- diagnostics (synchronous, never called by the product path) ----------------------------
  * While a stamps mode is on, the conv / SATU launches run INSTRUMENTED builds of their kernels (template parameter

@@ -15,7 +15,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 fptr = C.c_void_p   # raw device pointers travel as integers
 
@@ -94,6 +94,7 @@ SIGNATURES = {
     "savsr_debug_satu_stamps": (C.c_int, [C.c_int]),
     "savsr_debug_read_satu_stamps": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
     "savsr_debug_satu_occupancy": (C.c_int, [C.c_int, C.c_int]),
+    "savsr_resize_aa_axis": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int, fptr, C.c_void_p]),
     "savsr_metrics_blocks": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "savsr_metrics_psnr_ssim_y": (C.c_int, [fptr, C.c_int64, fptr, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "savsr_debug_read_conv_stamps": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),

@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
 OBJS=()
-for f in conv_mfma.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip; do
+for f in conv_mfma.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip; do
   o="${f%.hip}.o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.hpp -nt "$o" ] || [ ../../include/savsr_hip.h -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &

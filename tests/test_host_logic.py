@@ -115,3 +115,50 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f
+
+
+def test_resize_tables_match_torch_cpu():
+    """savsr_amd.resize_gpu.aa_tables (ATen's _compute_indices_weights_aa restated in fp32) applied on the CPU with numpy
+    reproduces torch's F.interpolate(bicubic, antialias=True) -- the op behind the reference's T.Resize
+    (lbasicsr/data/data_util.py:409-410)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from savsr_amd.resize_gpu import aa_tables
+
+    def axis(a, xmin, xsize, wt, ax):
+        a = np.moveaxis(a, ax, -1)
+        out = np.zeros(a.shape[:-1] + (len(xmin),), np.float32)
+        for i in range(len(xmin)):
+            acc = np.zeros(a.shape[:-1], np.float32)
+            for j in range(xsize[i]):
+                acc = acc + a[..., xmin[i] + j] * wt[i, j]
+            out[..., i] = acc
+        return np.moveaxis(out, -1, ax)
+
+    for h, w, oh, ow in [(64, 80, 16, 20), (37, 53, 10, 35), (30, 30, 40, 45)]:
+        x = torch.rand(1, 3, h, w, generator=torch.Generator().manual_seed(h))
+        ref = F.interpolate(x, size=(oh, ow), mode="bicubic", align_corners=False, antialias=True).numpy()
+        got = axis(axis(x.numpy(), *aa_tables(w, ow), 3), *aa_tables(h, oh), 2)
+        assert float(np.abs(got - ref).max()) < 1e-6
+
+
+def test_cal_step_and_as_mod_crop():
+    """lbasicsr/data/transforms.py:31-69: known answers for the YAML scale list."""
+    from savsr_amd.resize_gpu import as_mod_crop_hw, cal_step
+    assert [cal_step(s) for s in (4, 3.5, 1.2, 1.1, 2.95, 3.75, 1.62)] == [1, 2, 5, 10, 20, 20, 50]
+    assert as_mod_crop_hw(720, 1280, (4, 4)) == (720, 1280)
+    assert as_mod_crop_hw(720, 1272, (1.5, 4)) == (720, 1272)              # UDM10, SURVEY 8(d) config 4
+    assert as_mod_crop_hw(720, 1272, (3.5, 2)) == (714, 1272)
+    assert as_mod_crop_hw(576, 720, (3.7, 3.7)) == (555, 703)              # floor(576/10/3.7)*10*3.7, floor(720/10/3.7)*10*3.7
+    import pytest
+    with pytest.raises(ValueError):
+        cal_step(1.333)
+    # golden vectors from the reference function itself (tools/gen_golden_modcrop.py): every YAML scale x 5 GT sizes
+    import json
+    import os
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "as_mod_crop.json")))
+    assert len(rows) >= 200
+    for sc, h, w, oh, ow, st_h, st_w in rows:
+        assert as_mod_crop_hw(h, w, tuple(sc)) == (oh, ow), (sc, h, w)
+        assert (cal_step(sc[0]), cal_step(sc[1])) == (st_h, st_w)
+
