@@ -1,0 +1,71 @@
+"""Checkpoint / image formats: savsr_amd/io.py against the reference's conventions
+(base_model.py:285-319, data_util.py:29-60, img_util.py:114-153, video_base_model.py:79-92)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import savsr_amd
+from savsr_amd import io
+from savsr_amd.metrics import tensor2img
+from savsr_amd.utils import synth
+
+
+def test_png_roundtrip_and_read_img_seq(tmp_path):
+    frames = [synth.synth_gt(3, 37, 50, seed=i) for i in range(3)]
+    for i, f in enumerate(frames):
+        io.imwrite(tensor2img(f), str(tmp_path / "clip" / f"{i:08d}.png"))          # BGR uint8, parent dir created
+    (tmp_path / "clip" / ".hidden").write_text("x")                                # scandir skips hidden files
+    back = io.imread(str(tmp_path / "clip" / "00000001.png"))
+    assert back.dtype == np.uint8 and np.array_equal(back, tensor2img(frames[1]))  # lossless, BGR in = BGR out
+    seq, names = io.read_img_seq(str(tmp_path / "clip"), return_imgname=True)
+    assert names == ["00000000", "00000001", "00000002"] and tuple(seq.shape) == (3, 3, 37, 50) and seq.dtype == torch.float32
+    for i, f in enumerate(frames):                                                 # RGB, [0, 1], quantised to 8 bits
+        q = (f.clamp(0, 1) * 255.0).round() / 255.0
+        assert float((seq[i] - q).abs().max()) < 1e-7
+    crop = io.read_img_seq(str(tmp_path / "clip"), require_as_mod_crop=True, scale=(3.5, 2))
+    assert tuple(crop.shape[-2:]) == (35, 50) and torch.equal(crop, seq[..., :35, :50])
+    with pytest.raises(IOError):
+        io.imwrite(np.zeros((4, 4, 3), np.float32), str(tmp_path / "x.png"))
+
+
+def test_load_network_variants(tmp_path, synth_sd):
+    net = savsr_amd.build_network(dict(type="SAVSR")).eval()
+    net.load_state_dict(synth_sd, strict=True)
+    p = str(tmp_path / "models" / "net_g.pth")
+    io.save_network(net, p)
+    assert set(torch.load(p).keys()) == {"params"}
+    fresh = savsr_amd.build_network(dict(type="SAVSR")).eval()
+    io.load_network(fresh, p, strict=True, param_key="params_ema")                 # falls back to 'params'
+    for (k, a), (_, b) in zip(fresh.state_dict().items(), net.state_dict().items()):
+        assert torch.equal(a, b), k
+    # DataParallel-style 'module.' prefixes and a wrapped target
+    sd = {"params": {"module." + k: v for k, v in net.state_dict().items()}}
+    p2 = str(tmp_path / "wrapped.pth")
+    torch.save(sd, p2)
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+    fresh2 = savsr_amd.build_network(dict(type="SAVSR")).eval()
+    io.load_network(Wrap(fresh2), p2)
+    assert torch.equal(fresh2.state_dict()["tail.weight"], net.state_dict()["tail.weight"])
+    # non-strict: a tensor of a different size is ignored instead of raising; strict raises
+    bad = dict(net.state_dict())
+    bad["tail.bias"] = torch.zeros(5)
+    p3 = str(tmp_path / "bad.pth")
+    torch.save({"params": bad}, p3)
+    fresh3 = savsr_amd.build_network(dict(type="SAVSR")).eval()
+    before = fresh3.state_dict()["tail.bias"].clone()
+    io.load_network(fresh3, p3, strict=False)
+    assert torch.equal(fresh3.state_dict()["tail.bias"], before)
+    with pytest.raises(RuntimeError):
+        io.load_network(fresh3, p3, strict=True)
+
+
+def test_result_img_path():
+    assert io.result_img_path("results/x/visualization", "Vid4", "calendar", "datasets/Vid4/BIx4/calendar/00000003.png", "SAVSR_x4") == \
+        os.path.join("results/x/visualization", "Vid4", "calendar", "00000003_SAVSR_x4.png")
+    assert io.result_img_path("v", "Vimeo90K", "f", "a/00001/0266/im4.png", "n", suffix="s") == os.path.join("v", "Vimeo90K", "f", "00001_0266_im4_s.png")
