@@ -99,3 +99,23 @@ def validate_folder(net: Callable, lq_frames: torch.Tensor, gt_frames: Sequence[
     if on_gpu:
         return gather_rows(rows, n, rank, world).cpu()
     return gather_rows(rows, n, rank, world)
+
+
+def validate_folder_from_gt(net: Callable, gt_frames: torch.Tensor, scale: Tuple[float, float], rank: int = 0, world: int = 1,
+                            num_frame: int = 7, padding: str = "reflection", device: Optional[torch.device] = None) -> torch.Tensor:
+    """The reference's test flow with `use_arbitrary_scale_downsampling` (asvideo_test_dataset: GT -> as_mod_crop ->
+    arbitrary_scale_downsample -> windows -> net -> metrics), with every step on the GPU when `device` is one:
+    gt_frames [N, 3, H, W] RGB in [0, 1] (any size: the arbitrary-scale mod crop is applied here, transforms.py:48-69),
+    LR synthesis by savsr_amd.resize_gpu (data_util.py:371-420), PSNR-Y / SSIM-Y by savsr_amd.metrics_gpu.
+    Returns the gathered [N, 2] rows."""
+    from .resize_gpu import arbitrary_scale_downsample, as_mod_crop_hw
+    H, W = as_mod_crop_hw(gt_frames.shape[-2], gt_frames.shape[-1], tuple(scale))
+    gt = gt_frames[..., :H, :W].contiguous()
+    if device is not None and device.type == "cuda":
+        gt = gt.to(device)
+        lq = arbitrary_scale_downsample(gt, tuple(scale))
+    else:
+        import torch.nn.functional as F
+        lq = F.interpolate(gt, size=(round(H / scale[0]), round(W / scale[1])), mode="bicubic", align_corners=False, antialias=True)
+    return validate_folder(net, lq, list(gt), scale, rank, world, num_frame, padding, device)
+
