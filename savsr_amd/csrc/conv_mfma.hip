@@ -37,6 +37,10 @@
 // Replaces: every nn.Conv2d / F.conv2d of savsr_arch.py (see include/savsr_hip.h).
 #include "common.hpp"
 
+#ifndef CONV_INTERLEAVE
+#define CONV_INTERLEAVE 1
+#endif
+
 namespace savsr {
 
 struct ConvParams {
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     static_assert(!EP_ALIAS || B_UNITS * 16 >= CONV_TH * 32 * EPS * 4, "aliased epilogue slices must fit one input buffer");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
+    const int prio_group = __builtin_amdgcn_readfirstlane(wave >> 2);      // wave-uniform by construction: a scalar for the s_setprio branch
     const int tiles_per_cob = mp.ntx * mp.nty;
     const int total = mp.nconv * mp.ncob * tiles_per_cob;
     const int dbg_all = DIAG ? __builtin_amdgcn_readfirstlane(g_conv_stamps_on) : 0;
@@ -373,11 +378,41 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 if (dbg_nofrag) {
                 } else if (s + LEAD < STEPS) load_frag(buf, s + LEAD, f[(s + LEAD) % RING]);
                 else if (pend) load_frag(buf ^ 1, s + LEAD - STEPS, f[(s + LEAD) % RING]);
+#if CONV_INTERLEAVE < 2
                 __builtin_amdgcn_sched_barrier(0);
+#else
+                if (!(FINE && !DIAG)) __builtin_amdgcn_sched_barrier(0);
+#endif
                 // The two waves of a SIMD alternate issue priority step by step.  Left to the oldest-first arbiter, waves
                 // 0-3 run every step ahead, then idle ~2 k cycles per phase at the barrier while waves 4-7 finish alone
                 // (a lone wave cannot cover its own staging work with MFMAs): stamps, 80 k vs 99 k cycles of steps.
-                if (((s ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                if (((s ^ prio_group) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#if CONV_INTERLEAVE
+                // Straight-line step (FINE, product build): the staging pieces are issued unconditionally -- without a next
+                // phase they re-stage the cursor's last phase into a buffer nobody reads -- so that the step is ONE basic
+                // block and the scheduler can be told to put a few vector instructions behind every MFMA instead of
+                // clumps between the MFMA groups (both waves of a SIMD clump at the same time and the matrix pipe drains).
+                if (FINE && !DIAG) {
+                    mma_part(f[s % RING], 0);
+                    if (s < B_IT) stage_store_item(s, buf ^ 1);
+                    mma_part(f[s % RING], 1);
+                    if (s < SB) { if (LEAD + s < W_IT) issue_w(LEAD + s, buf ^ 1); }
+                    else if (s - SB < W_IT) issue_w(s - SB, buf);
+                    if (s >= LB0) issue_b(s - LB0);
+                    mma_part(f[s % RING], 2);
+#pragma unroll
+                    for (int i = 0; i < 3 * PXT * NT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+#if CONV_INTERLEAVE >= 2
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // up to one DS read (next step's fragments)
+#endif
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // up to three VALU
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // up to one DS write
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
+#endif
                 mma_part(f[s % RING], 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (FINE && s < B_IT && pend && !dbg_nostage) stage_store_item(s, buf ^ 1);
