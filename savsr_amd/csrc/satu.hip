@@ -19,6 +19,10 @@
 //   the lane that consumes it (HR stage): no cross-lane movement on either side.
 #include "common.hpp"
 
+#ifndef LR_INTERLEAVE
+#define LR_INTERLEAVE 1
+#endif
+
 namespace savsr {
 
 constexpr int REC = SAVSR_SATU_LRCAT;      // 160
@@ -236,7 +240,9 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
                 const int kx = G / 4, ks = G % 4;
                 __builtin_amdgcn_sched_barrier(0);
                 acc[kx & 1] = mma3(fr.ah[ks], fr.al[ks], sth[ks], stl[ks], acc[kx & 1]);
+#if !LR_INTERLEAVE
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 if (kx + 1 < 5) { fr.ah[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 0) * 64]; fr.al[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 1) * 64]; }
                 if (kx > 0) lrelu_x(ks, acc[(kx - 1) & 1], x_pf);
                 if (kx + 1 < 5) {
@@ -248,6 +254,15 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
                     if (kx1 > 0) x_pf = x_read(kx1 - 1, ks1);
                     if (kx1 + 1 < 5) b_pf = bias_read(kx1 + 1, ks1);
                 }
+#if LR_INTERLEAVE
+                // the group is one basic block: ~5 vector instructions and one LDS read behind each of its 3 MFMAs
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                }
+#endif
             }
             {
                 f32x4 xq[4];
