@@ -680,6 +680,9 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             __syncthreads();                         // the aliased slices become a staging buffer again
         }
     }
+    // The last phases re-stage unconditionally (straight-line steps): no LDS-DMA of this wave may still be in flight when
+    // its LDS is released.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (stamps_on == 1) {
         __builtin_amdgcn_s_waitcnt(0);              // diagnostics: include the store drain in the last stamp
         stamp(stamps_on, 4);
