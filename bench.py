@@ -120,7 +120,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SAVSR_BENCH_FORCE_DIST"):     # (the env switch exercises the RCCL path with one rank)
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)    # RCCL over xGMI
 
