@@ -289,7 +289,22 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* partial, int
     __shared__ float scr[SE_PARTS * 128];
     __shared__ float m[128];
     __shared__ float z[64];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // the MLP weights do not depend on the pooled mean: their loads go out first and land under the reduction
+    // (c <= 128, cmid <= 64 checked by the launcher; wave w < cmid owns hidden unit w, thread o < c owns output o)
+    float w1v[2] = {0.f, 0.f}, b1v = 0.f;
+    if (wave < cmid) {
+        if (lane < c) w1v[0] = w1[wave * c + lane];
+        if (lane + 64 < c) w1v[1] = w1[wave * c + lane + 64];
+        b1v = b1[wave];
+    }
+    float w2v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b2v = 0.f;
+    if (t < c) {
+        b2v = b2[t];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < cmid) w2v[k] = w2[t * cmid + k];
+    }
     for (int i = t; i < c * SE_PARTS; i += 1024) {
         const int ch = i % c, part = i / c;
         float s = 0.f;
@@ -305,16 +320,24 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* partial, int
         m[ch] = s * inv_n;
     }
     __syncthreads();
-    if (t < cmid) {
-        float acc = b1[t];
-        for (int i = 0; i < c; ++i) acc += w1[t * c + i] * m[i];
-        z[t] = fmaxf(acc, 0.f);
+    for (int r = wave; r < cmid; r += 16) {
+        float acc;
+        if (r == wave) acc = (lane < c ? w1v[0] * m[lane] : 0.f) + (lane + 64 < c ? w1v[1] * m[lane + 64] : 0.f);
+        else {                                            // cmid > 16 waves: later rows are loaded here
+            acc = 0.f;
+            for (int i = lane; i < c; i += 64) acc += w1[r * c + i] * m[i];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) z[r] = fmaxf(acc + (r == wave ? b1v : b1[r]), 0.f);
     }
     __syncthreads();
-    for (int o = t; o < c; o += 1024) {
-        float acc = b2[o];
-        for (int k = 0; k < cmid; ++k) acc += w2[o * cmid + k] * z[k];
-        gate[o] = sigmoidf_(acc);
+    if (t < c) {
+        float acc = b2v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < cmid) acc += w2v[k] * z[k];
+        for (int k = 8; k < cmid; ++k) acc += w2[t * cmid + k] * z[k];
+        gate[t] = sigmoidf_(acc);
     }
 }
 
