@@ -129,11 +129,24 @@ __global__ __launch_bounds__(512) void osconv_l2_kernel(const OscBatch bt) {
     const savsr_osconv_attn_desc& d = bt.d[blockIdx.y];
     extern __shared__ float v1[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this wave's weight row first (it does not depend on v1; 2 cin <= 640 = 10 x 64 columns, checked by the launcher)
+    const int r = blockIdx.x * 8 + wave;
+    float wv[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        const int c = lane + 64 * q;
+        wv[q] = (r < d.cin && c < 2 * d.cin) ? d.l2_w[(long long)r * (2 * d.cin) + c] : 0.f;
+    }
     for (int i = tid; i < 2 * d.cin; i += 512) v1[i] = d.v1[i];
     __syncthreads();
-    const int r = blockIdx.x * 8 + wave;
     if (r >= d.cin) return;
-    const float acc = wave_dot(d.l2_w + (long long)r * (2 * d.cin), v1, 2 * d.cin, lane);
+    float acc = 0.f;                                  // per lane in column order, then across the wave: the order of wave_dot
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        const int c = lane + 64 * q;
+        if (c < 2 * d.cin) acc += wv[q] * v1[c];
+    }
+    acc = wave_sum(acc);
     if (lane == 0) d.v2[r] = fmaxf(acc + d.l2_b[r], 0.f);
 }
 
