@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ fea
     const int X0 = blockIdx.x * TL_TW, Y0 = blockIdx.y * TL_TH;
     const long long HW = (long long)H * W;
     const bool vec = (W & 3) == 0 && (FP & 3) == 0 && X0 + TL_TW <= W;     // interior columns 16-B aligned and inside the image
-    float a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // per output channel: {pixel row 2 ty, row 2 ty + 1}
 
     for (int c0 = 0; c0 < 64; c0 += TL_CH) {
         __syncthreads();
@@ -86,25 +87,27 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ fea
         __syncthreads();
 #pragma unroll 2
         for (int ch = 0; ch < TL_CH; ++ch) {
+            // explicit 2-vectors {row r, row r + 1} of one column: the thread's two output pixels share every weight, so one
+            // v_pk_fma_f32 per (tap, output channel) with the pair read by one ds_read2_b32 (left to the SLP vectoriser the
+            // loop paired COLUMNS and spent 14 v_mov + 20 s_mov per channel on shuffles beside its 27 packed FMAs)
             const float* tp = tile + (ch * TL_R + 2 * ty) * TL_S + 3 + tx;
-            float v[4][3];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) v[r][c] = tp[r * TL_S + c];
             const float* wc = wgt + (c0 + ch) * 9;           // wave-uniform -> scalar loads
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                const float* wo = wc + o * 64 * 9;
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float wk = wo[k];
-                    a[0][o] += wk * v[k / 3][k % 3];
-                    a[1][o] += wk * v[k / 3 + 1][k % 3];
+                for (int c = 0; c < 3; ++c) {
+                    const f32x2 v = {tp[r * TL_S + c], tp[(r + 1) * TL_S + c]};
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        const float wk = wc[o * 64 * 9 + r * 3 + c];
+                        acc2[o] = __builtin_elementwise_fma(f32x2{wk, wk}, v, acc2[o]);
+                    }
                 }
-            }
         }
     }
+    float a[2][3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) { a[0][o] = acc2[o][0]; a[1][o] = acc2[o][1]; }
     const int X = X0 + tx;
     if (X >= W) return;
     // F.interpolate(x_center, size=(H, W), mode='bilinear', align_corners=False), :739
