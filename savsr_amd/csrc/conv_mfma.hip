@@ -99,6 +99,13 @@ __device__ __forceinline__ float ldg1(const float* base, unsigned idx) {
 __device__ __forceinline__ void stg4(float* base, unsigned byte_off, const f32x4& v) {
     *(SAVSR_GLOBAL f32x4*)((SAVSR_GLOBAL char*)base + byte_off) = v;
 }
+// max without the NaN canonicalisation hipcc puts in front of fmaxf (one extra v_max_f32 per call); operands here are
+// results of fp32 arithmetic, never signalling NaNs
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void stg1(float* base, unsigned idx, float v) {
     *((SAVSR_GLOBAL float*)base + idx) = v;
 }
@@ -136,6 +143,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     const int dbg_all = DIAG ? __builtin_amdgcn_readfirstlane(g_conv_stamps_on) : 0;
     const int stamps_on = dbg_all & 15;
     const bool dbg_nostage = dbg_all & 16, dbg_nofrag = dbg_all & 32;   // timing experiments only (results are wrong)
+    const bool dbg_nost = dbg_all & 64, dbg_nolds = dbg_all & 128;      // epilogue without its global stores / without the LDS transpose
 
     f32x4 b_reg[B_IT];
 
@@ -255,10 +263,6 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     stamp(stamps_on, 0);
     stamp(stamps_on, 5);
 
-    if (dbg_all & 64) {                                      // experiment: stagger the workgroups so their epilogue bursts do not coincide
-        const long long t_end = (long long)__builtin_amdgcn_s_memtime() + 3000ll * ((blockIdx.x >> 3) & 3);
-        while ((long long)__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(4);
-    }
     // ---- software pipeline over the block's phases (tiles x chunks, walked linearly by the staging cursor) ----
     //   LDS buffer c%2 holds phase c.  While phase c computes: phase c+1 sits in (or is arriving into) the staging
     //   registers; at step SB it is split + stored to the other buffer, ONE barrier publishes it, the cursor moves to
@@ -461,7 +465,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         asm volatile("" : "+s"(e_bias), "+s"(e_mul), "+s"(e_r1), "+s"(e_r2), "+s"(e_out), "+s"(e_pool));
         asm volatile("" : "+s"(e_act), "+s"(e_opix), "+s"(e_r1pix), "+s"(e_r2pix), "+s"(e_slope), "+s"(e_r2s));
         const int COUT = mp.cout;
-        const bool lrelu_as_max = e_slope >= 0.f && e_slope <= 1.f;
+        const bool act_as_max = e_act == SAVSR_ACT_NONE || e_act == SAVSR_ACT_RELU || (e_act == SAVSR_ACT_LRELU && e_slope >= 0.f && e_slope <= 1.f);
+        const float slope_eff = e_act == SAVSR_ACT_NONE ? 1.f : (e_act == SAVSR_ACT_RELU ? 0.f : e_slope);
         float* ep_base = reinterpret_cast<float*>(EP_ALIAS ? smem + (buf ^ 1) * B_UNITS : smem + 2 * B_UNITS + 2 * W_UNITS);
         float* ep = ep_base + wave * (32 * EPS);
         const int c4 = lane & 7;                                // lane l always handles channel quad l % 8
@@ -472,6 +477,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         const bool chan_full = (cob + 1) * COT <= COUT;       // the 16-row variant is only launched with cout % 64 == 0
         const bool x_inside = x0 + CONV_TW <= W;
         if (PXT > 1 || chan_full) {
+            // (a branch-free variant of this path for interior tiles, chosen once per tile, measured the same: A/B/A on one box)
             // loads that do not depend on the accumulators go out first: the bias quads of both channel groups, and the
             // residual quads one (row, channel-group) step ahead of their use (issued next to their use they exposed one
             // global-load latency per step)
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 v = {acc[r][t][4 * g], acc[r][t][4 * g + 1], acc[r][t][4 * g + 2], acc[r][t][4 * g + 3]};
-                        *reinterpret_cast<f32x4*>(ep + px * EPS + 8 * g + 4 * half) = v;
+                        if (!(DIAG && dbg_nolds)) *reinterpret_cast<f32x4*>(ep + px * EPS + 8 * g + 4 * half) = v;
                     }
                     const int co = cob * COT + 32 * t + 4 * c4;
                     const f32x4 b4 = bias4[t];
@@ -519,26 +525,21 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                         f32x4 v[2];
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ep + ((lane >> 3) + 16 * ih + 8 * i) * EPS + 4 * c4);
+                            f32x4 a4;
+                            if (DIAG && dbg_nolds) a4 = f32x4{acc[r][t][8 * ih + 4 * i], acc[r][t][8 * ih + 4 * i + 1], acc[r][t][8 * ih + 4 * i + 2], acc[r][t][8 * ih + 4 * i + 3]};
+                            else a4 = *reinterpret_cast<const f32x4*>(ep + ((lane >> 3) + 16 * ih + 8 * i) * EPS + 4 * c4);
                             v[i] = f32x4{a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
                         }
-                        if (e_act == SAVSR_ACT_RELU) {
+                        if (act_as_max) {             // none / ReLU / LeakyReLU(0..1) as ONE v_max_f32(v, v * s), s = 1 / 0 / slope: no branch
+#pragma unroll                                        // chain (its phi copies were 300 v_mov per tile) and no NaN-canonicalising second
+                            for (int i = 0; i < 2; ++i)   // v_max (fmaxf costs two); ReLU of a negative value gives -0 instead of +0
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[i][q] = vmax_raw(v[i][q], v[i][q] * slope_eff);
+                        } else if (e_act == SAVSR_ACT_LRELU) {
 #pragma unroll
                             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) v[i][q] = fmaxf(v[i][q], 0.f);
-                        } else if (e_act == SAVSR_ACT_LRELU) {
-                            if (lrelu_as_max) {       // slope in [0, 1]: max(v, slope v) is the same value for every v, in half the VALU
-#pragma unroll                                        // instructions (the epilogue is VALU-issue-bound: both waves of a SIMD share the port)
-                                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) v[i][q] = fmaxf(v[i][q], v[i][q] * e_slope);
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) v[i][q] = v[i][q] > 0.f ? v[i][q] : v[i][q] * e_slope;
-                            }
+                                for (int q = 0; q < 4; ++q) v[i][q] = v[i][q] > 0.f ? v[i][q] : v[i][q] * e_slope;
                         } else if (e_act == SAVSR_ACT_SIGMOID) {
 #pragma unroll
                             for (int i = 0; i < 2; ++i)
@@ -565,7 +566,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             if (i == 0 ? ok0 : ok1) {
-                                stg4(e_out, 4u * (unsigned)((p0 + 8 * i) * e_opix + co), v[i]);
+                                if (!(DIAG && dbg_nost)) stg4(e_out, 4u * (unsigned)((p0 + 8 * i) * e_opix + co), v[i]);
+                                else asm volatile("" :: "v"(v[i][0]), "v"(v[i][1]), "v"(v[i][2]), "v"(v[i][3]));
                                 if (e_pool) { ps[0] += v[i][0]; ps[1] += v[i][1]; ps[2] += v[i][2]; ps[3] += v[i][3]; }
                             }
                         }
