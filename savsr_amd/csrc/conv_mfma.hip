@@ -476,7 +476,13 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         // (the epilogue's ~10 scalar branches per unit were a third of its time).
         const bool chan_full = (cob + 1) * COT <= COUT;       // the 16-row variant is only launched with cout % 64 == 0
         const bool x_inside = x0 + CONV_TW <= W;
-        if (PXT > 1 || chan_full) {
+        if (DIAG && (dbg_all & 256)) {
+            // timing experiment: no epilogue body at all (results invalid)
+#pragma unroll
+            for (int r = 0; r < PXT; ++r)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { psum[r][t] = f32x4{0.f, 0.f, 0.f, 0.f}; asm volatile("" :: "v"(acc[r][t][0])); }
+        } else if (PXT > 1 || chan_full) {
             // (a branch-free variant of this path for interior tiles, chosen once per tile, measured the same: A/B/A on one box)
             // loads that do not depend on the accumulators go out first: the bias quads of both channel groups, and the
             // residual quads one (row, channel-group) step ahead of their use (issued next to their use they exposed one
@@ -491,11 +497,12 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             auto load_r1 = [&](int r, int t, f32x4 (&dst)[4]) {
                 const int y = y0 + wave + CONV_TH * r;
                 const int co = cob * COT + 32 * t + 4 * c4;
+                // one integer multiply per group, then uniform strides (v_mul_lo_u32 is a quarter-rate instruction)
+                const unsigned off0 = 4u * (unsigned)((y * W + x0 + (lane >> 3)) * e_r1pix + co), ustride = 32u * (unsigned)e_r1pix;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (y < H && (x_inside || x0 + (lane >> 3) + 8 * i < W))
-                        dst[i] = ldg4(e_r1, 4u * (unsigned)((y * W + x0 + (lane >> 3) + 8 * i) * e_r1pix + co));
+                    if (y < H && (x_inside || x0 + (lane >> 3) + 8 * i < W)) dst[i] = ldg4(e_r1, off0 + (unsigned)i * ustride);
                 }
             };
             if (e_r1) load_r1(0, 0, rr[0]);
@@ -517,6 +524,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                     }
                     const int co = cob * COT + 32 * t + 4 * c4;
                     const f32x4 b4 = bias4[t];
+                    const unsigned ooff0 = 4u * (unsigned)(pbase * e_opix + co), ostride = 32u * (unsigned)e_opix;   // unit u = pixel pbase + 8 u
                     f32x4 ps = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ih = 0; ih < 2; ++ih) {                  // two units (pixels pbase + 16 ih, + 8) at a time: register budget
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             if (i == 0 ? ok0 : ok1) {
-                                if (!(DIAG && dbg_nost)) stg4(e_out, 4u * (unsigned)((p0 + 8 * i) * e_opix + co), v[i]);
+                                if (!(DIAG && dbg_nost)) stg4(e_out, ooff0 + (unsigned)(2 * ih + i) * ostride, v[i]);
                                 else asm volatile("" :: "v"(v[i][0]), "v"(v[i][1]), "v"(v[i][2]), "v"(v[i][3]));
                                 if (e_pool) { ps[0] += v[i][0]; ps[1] += v[i][1]; ps[2] += v[i][2]; ps[3] += v[i][3]; }
                             }
