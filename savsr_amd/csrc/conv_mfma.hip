@@ -491,7 +491,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 bias4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (e_bias) bias4[t] = ldg4(e_bias, 4u * (unsigned)(cob * COT + 32 * t + 4 * c4));
+                if (e_bias && !(DIAG && (dbg_all & 512))) bias4[t] = ldg4(e_bias, 4u * (unsigned)(cob * COT + 32 * t + 4 * c4));   // (512: timing experiment without the bias load)
             }
             f32x4 rr[2][4];
             auto load_r1 = [&](int r, int t, f32x4 (&dst)[4]) {

@@ -93,7 +93,7 @@ def main():
             s3 = np.array(buf[:], dtype=np.int64).reshape(nb, 6)[:, :5]
             print("wave-%d section cycles summed over the phases (median): steps after the barrier (+ staging issue) %d | steps before the barrier %d | wait %d | barrier %d | epilogue %d"
                   % tuple([wv] + np.median(s3, axis=0).tolist()))
-        for flag, name in ((16, "no staging"), (32, "no fragment reads"), (48, "MFMAs only"), (64, "epilogue without stores"), (128, "epilogue without LDS transpose"), (192, "epilogue without either"), (256, "no epilogue body")):
+        for flag, name in ((16, "no staging"), (32, "no fragment reads"), (48, "MFMAs only"), (64, "epilogue without stores"), (128, "epilogue without LDS transpose"), (192, "epilogue without either"), (256, "no epilogue body"), (512, "epilogue without the bias load")):
             eng.lib.savsr_debug_conv_stamps(7 + flag)
             run()
             torch.cuda.synchronize()
