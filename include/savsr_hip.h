@@ -247,8 +247,9 @@ int savsr_resize_aa_axis(const float* in, int planes, int h, int w, int axis, in
  * Conv kernel, savsr_debug_conv_stamps(mode): 0 off; 1 per-workgroup s_memtime stamps [blk][6] = entry, after
  * the prologue, after the first K phase, after the first tile's K loop, after the stores drained,
  * s_memrealtime at entry; 3 + w: accumulated section times of wave w ([blk][0..4] = steps after the barrier,
- * steps before it, wait, barrier, epilogue); + 16 / + 32: timing experiments that skip the staging / the
- * fragment reads (results invalid). */
+ * steps before it, wait, barrier, epilogue); + 16 / + 32 / + 64 / + 128 / + 256 / + 512: timing experiments that skip
+ * the staging / the fragment reads / the epilogue's stores / its LDS transpose / its whole body / its bias load
+ * (results invalid). */
 int savsr_debug_conv_stamps(int enable);
 int savsr_debug_read_conv_stamps(long long* host, int nblocks);
 /* SATU LR / HR kernels: [blk][8] accumulated section times of wave 0 (see satu.hip), last = total. */
