@@ -40,6 +40,9 @@
 #ifndef CONV_INTERLEAVE
 #define CONV_INTERLEAVE 1
 #endif
+#ifndef CONV_IL_VALU
+#define CONV_IL_VALU 3
+#endif
 
 namespace savsr {
 
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #if CONV_INTERLEAVE >= 2
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // up to one DS read (next step's fragments)
 #endif
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // up to three VALU
+                        __builtin_amdgcn_sched_group_barrier(0x002, CONV_IL_VALU, 0);      // up to CONV_IL_VALU (3) VALU
                         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // up to one DS write
                     }
                     __builtin_amdgcn_sched_barrier(0);
