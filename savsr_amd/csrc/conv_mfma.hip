@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                          : "=&s"(keep) : "v"(st_w + e), "s"(dst) : "memory");
         }
     };
-    auto issue_b = [&](int i) {
+    auto issue_b_to = [&](int i, f32x4 (&dstreg)[B_IT]) {
         const int e = tid + i * NTHR;
         const int c8 = e % PER;                                         // float4 of the chunk
         const int po = st_pixoff[i];
@@ -225,14 +225,15 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         // load, which counts on lgkmcnt and ties the fragment-read waits to these loads)
         const SAVSR_GLOBAL float* src = po < 0 ? (const SAVSR_GLOBAL float*)g_conv_zero16
                                                : (const SAVSR_GLOBAL float*)st_base + (po * st_pix + st_cb + c8 * 4);
-        b_reg[i] = *(const SAVSR_GLOBAL f32x4*)src;
+        dstreg[i] = *(const SAVSR_GLOBAL f32x4*)src;
     };
+    auto issue_b = [&](int i) { issue_b_to(i, b_reg); };
     auto stage_issue = [&](int j, int wbuf) {
         if (j < W_IT) issue_w(j, wbuf);
         else if (j < W_IT + B_IT) issue_b(j - W_IT);
     };
     // registers -> LDS buffer `buf`, splitting the activations to (hi, lo) bf16
-    auto stage_store_item = [&](int i, int buf) {
+    auto stage_store_item_from = [&](const f32x4 (&srcreg)[B_IT], int i, int buf) {
         bf16x8* bl = smem + buf * B_UNITS;
         {
             const int e = tid + i * NTHR;
@@ -241,9 +242,9 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 bf16x4 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const __bf16 hh = (__bf16)b_reg[i][j];
+                    const __bf16 hh = (__bf16)srcreg[i][j];
                     hi[j] = hh;
-                    lo[j] = (__bf16)(b_reg[i][j] - (float)hh);
+                    lo[j] = (__bf16)(srcreg[i][j] - (float)hh);
                 }
                 bf16x4* dst = reinterpret_cast<bf16x4*>(bl + q * NPX + pl) + sub;
                 dst[0] = hi;
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             }
         }
     };
+    auto stage_store_item = [&](int i, int buf) { stage_store_item_from(b_reg, i, buf); };
     auto stage_store = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) stage_store_item(i, buf);
@@ -318,20 +320,27 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     bool pend = false;                                       // phase c+1 exists (staging registers hold / are receiving it)
     Frag f[RING];
     if (tile < total) {
+        // Prologue: the loads of phase 1 are issued BEFORE phase 0's are waited for (a second register set, live only
+        // here), unconditionally (without a phase 1 they re-load phase 0 into registers / a buffer nobody uses), so the
+        // block start pays one global latency, not two.  VMEM returns in order: once the activation loads of phase 0
+        // have landed (the compiler's wait in front of the split), the older weight DMA of phase 0 has landed too.
         stage_begin_tile(decode(tile));
+        f32x4 b0[B_IT];
 #pragma unroll
-        for (int j = 0; j < N_LD; ++j) stage_issue(j, 0);
-        stage_store(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight DMA has landed
+        for (int j = 0; j < W_IT; ++j) issue_w(j, 0);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) issue_b_to(i, b0);
+        pend = stage_next();
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j)
+            if (!FINE || j < LEAD) issue_w(j, 1);            // FINE: the rest of phase 1's weight DMA follows in phase 0's steps
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) issue_b(i);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) stage_store_item_from(b0, i, 0);
     }
     __syncthreads();
     if (tile < total) {
-        pend = stage_next();
-        if (pend) {
-#pragma unroll
-            for (int j = 0; j < N_LD; ++j)
-                if (!FINE || j >= W_IT || j < LEAD) stage_issue(j, 1);   // FINE: the rest of the weight DMA follows in phase 0's steps
-        }
         load_frag(0, 0, f[0]);
         if (LEAD > 1 && STEPS > 1) load_frag(0, 1, f[1]);
     }
