@@ -421,7 +421,8 @@ template <bool FROM_LDS>
 __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int ly0, int lx0, const Taps& to, const Taps& ts,
                                         const f32x4 rr, int half, int lane, bool valid, unsigned o_off, const float* cst) {
     auto rec_of = [&](int ty, int tx) -> const f32x4* {
-        if (FROM_LDS) return reinterpret_cast<const f32x4*>(lds + ((ty - ly0) * p.lrw + (tx - lx0)) * HR_LDS_REC);
+        // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): window coordinates are tiny
+        if (FROM_LDS) return reinterpret_cast<const f32x4*>(lds + __mul24(__mul24(ty - ly0, p.lrw) + (tx - lx0), HR_LDS_REC));
         return reinterpret_cast<const f32x4*>(p.lrcat + ((long long)ty * p.w + tx) * REC);
     };
     const f32x4* ro[4] = {rec_of(to.ty[0], to.tx[0]), rec_of(to.ty[1], to.tx[1]), rec_of(to.ty[2], to.tx[2]), rec_of(to.ty[3], to.tx[3])};
