@@ -279,13 +279,18 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     constexpr int SB = STEPS >= LEAD ? STEPS - LEAD : 0;     // the step whose fragment prefetch is the first of the next phase
     // FINE schedule (3x3): the staging traffic is spread over the steps, at most one store and two loads per wave and
     // step -- issued in one burst after the barrier, the 8 waves queue 80 KiB on the CU's 64 B/clk address path and
-    // every wave stalls ~1.3 k cycles in front of its next MFMAs.  In phase c: steps 0 .. B_IT-1 split + store the
-    // activations of phase c+1 (loaded during phase c-1); steps LB0 .. load those of phase c+2; the weight DMA of phase
-    // c+2 starts right after barrier(c) (its LDS buffer is free from there) and continues in the first steps of c+1.
+    // every wave stalls ~1.3 k cycles in front of its next MFMAs.  In phase c: the weight DMA of phase c+1 starts right
+    // after barrier(c-1) (its LDS buffer is free from there) and continues in steps 0 .. W_IT-LEAD-1; steps SD .. SB-1
+    // split + store the activations of phase c+1 (loaded during phase c-1), the LAST steps in front of the barrier;
+    // step LB0 + i = SD + 1 + i re-loads register set i with the activations of phase c+2.  The stores sit late because
+    // hipcc's wait in front of store i is "all but the loads issued after load i", and the DMAs it does not see are in
+    // that queue too: stored in steps 0 .. B_IT-1 the last store waited for a DMA issued one step (~0.7 us) earlier.
+    // Now everything a store or the barrier waits for was issued >= 4 steps before.
     constexpr bool FINE = KS == 3;
-    constexpr int LB0 = STEPS - B_IT;                        // first activation-load step (the cursor advances there)
-    constexpr int NB = B_IT - LEAD;                          // activation loads younger than the last weight DMA at the barrier
-    static_assert(!FINE || (LB0 < SB && W_IT - LEAD <= LB0 && B_IT <= LB0 + 1), "FINE staging schedule");
+    constexpr int SD = SB - B_IT;                            // first activation-store step
+    constexpr int LB0 = SD + 1;                              // first activation-load step (the cursor advances there)
+    constexpr int NB = B_IT - 1;                             // activation loads younger than the last weight DMA at the barrier
+    static_assert(!FINE || (SD >= 0 && LB0 < SB && W_IT - LEAD <= LB0 && LB0 + B_IT <= STEPS), "FINE staging schedule");
     constexpr int N_LD = B_IT + W_IT;
     constexpr int LD_PER = (N_LD + (STEPS - SB) - 1) / (STEPS - SB);
     int st_tile = blockIdx.x, st_chunk = 0;
@@ -410,11 +415,11 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 // clumps between the MFMA groups (both waves of a SIMD clump at the same time and the matrix pipe drains).
                 if (FINE && !DIAG) {
                     mma_part(f[s % RING], 0);
-                    if (s < B_IT) stage_store_item(s, buf ^ 1);
+                    if (s >= SD && s < SD + B_IT) stage_store_item(s - SD, buf ^ 1);
                     mma_part(f[s % RING], 1);
                     if (s < SB) { if (LEAD + s < W_IT) issue_w(LEAD + s, buf ^ 1); }
                     else if (s - SB < W_IT) issue_w(s - SB, buf);
-                    if (s >= LB0) issue_b(s - LB0);
+                    if (s >= LB0 && s - LB0 < B_IT) issue_b(s - LB0);
                     mma_part(f[s % RING], 2);
 #pragma unroll
                     for (int i = 0; i < 3 * PXT * NT; ++i) {
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #endif
                 mma_part(f[s % RING], 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (FINE && s < B_IT && pend && !dbg_nostage) stage_store_item(s, buf ^ 1);
+                if (FINE && s >= SD && s < SD + B_IT && pend && !dbg_nostage) stage_store_item(s - SD, buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_part(f[s % RING], 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                     } else {
                         if (s - SB < W_IT && pend2) issue_w(s - SB, buf);
                     }
-                    if (s >= LB0 && pend2) issue_b(s - LB0);
+                    if (s >= LB0 && s - LB0 < B_IT && pend2) issue_b(s - LB0);
                 } else if (s >= SB && pend2) {
 #pragma unroll
                     for (int j = (s - SB) * LD_PER; j < (s - SB + 1) * LD_PER && j < N_LD; ++j) stage_issue(j, buf);
@@ -499,36 +504,47 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             // loads that do not depend on the accumulators go out first: the bias quads of both channel groups, and the
             // residual quads one (row, channel-group) step ahead of their use (issued next to their use they exposed one
             // global-load latency per step)
+            // Every one of these loads is issued UNCONDITIONALLY and used on every path (absent operands read a 16-B block
+            // of zeros, out-of-image lanes the tensor's first quad, whose sum is never stored): a load under a branch, or
+            // one whose use a path skips, makes hipcc's wait insertion lose count -- it then drained all of the wave's
+            // loads (s_waitcnt vmcnt(0)) at the top of EVERY K phase, at the start of every epilogue and right behind
+            // each residual prefetch, and copied the prefetched quads around between the branches.
+            const int wave_s = __builtin_amdgcn_readfirstlane(wave);          // row tests as scalar branches
+            const float* zero16 = (const float*)g_conv_zero16;
+            const float* b_base = e_bias ? e_bias : zero16;
+            const unsigned b_off = e_bias ? 4u * (unsigned)(cob * COT + 4 * c4) : 0u, b_step = e_bias ? 128u : 0u;
             f32x4 bias4[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                bias4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (e_bias && !(DIAG && (dbg_all & 512))) bias4[t] = ldg4(e_bias, 4u * (unsigned)(cob * COT + 32 * t + 4 * c4));   // (512: timing experiment without the bias load)
-            }
+            for (int t = 0; t < NT; ++t) bias4[t] = (DIAG && (dbg_all & 512)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ldg4(b_base, b_off + (unsigned)t * b_step);   // (512: timing experiment without the bias load)
+            const float* r1_base = e_r1 ? e_r1 : zero16;
             f32x4 rr[2][4];
             auto load_r1 = [&](int r, int t, f32x4 (&dst)[4]) {
-                const int y = y0 + wave + CONV_TH * r;
+                const int y = y0 + wave_s + CONV_TH * r;
                 const int co = cob * COT + 32 * t + 4 * c4;
                 // one integer multiply per group, then uniform strides (v_mul_lo_u32 is a quarter-rate instruction)
                 const unsigned off0 = 4u * (unsigned)((y * W + x0 + (lane >> 3)) * e_r1pix + co), ustride = 32u * (unsigned)e_r1pix;
+                const bool row_ok = e_r1 && y < H;                              // scalar
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (y < H && (x_inside || x0 + (lane >> 3) + 8 * i < W)) dst[i] = ldg4(e_r1, off0 + (unsigned)i * ustride);
+                    const bool ok = row_ok && (x_inside || x0 + (lane >> 3) + 8 * i < W);
+                    dst[i] = ldg4(r1_base, ok ? off0 + (unsigned)i * ustride : 0u);
                 }
             };
-            if (e_r1) load_r1(0, 0, rr[0]);
+            load_r1(0, 0, rr[0]);
 #pragma unroll
             for (int r = 0; r < PXT; ++r) {
-                const int y = y0 + wave + CONV_TH * r;
+                const int y = y0 + wave_s + CONV_TH * r;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) psum[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int pbase = y * W + x0 + (lane >> 3);                              // unit i is pixel pbase + 8 i
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int gi = r * NT + t;
-                    if (e_r1 && gi + 1 < PXT * NT) load_r1((gi + 1) / NT, (gi + 1) % NT, rr[(gi + 1) & 1]);
-                    if (y >= H) continue;                                                // wave-uniform
+                    if (gi + 1 < PXT * NT) load_r1((gi + 1) / NT, (gi + 1) % NT, rr[(gi + 1) & 1]);
+                    if (y >= H) {                                                        // scalar: rows below the image
+                        asm volatile("" :: "v"(bias4[t]), "v"(rr[gi & 1][0]), "v"(rr[gi & 1][1]), "v"(rr[gi & 1][2]), "v"(rr[gi & 1][3]));   // (used on every path, see above)
+                        continue;
+                    }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 v = {acc[r][t][4 * g], acc[r][t][4 * g + 1], acc[r][t][4 * g + 2], acc[r][t][4 * g + 3]};
@@ -571,8 +587,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { v[0][q] *= m0; v[1][q] *= m1; }
                         }
-                        if (e_r1) {
-                            const f32x4 ra = rr[gi & 1][2 * ih], rb = rr[gi & 1][2 * ih + 1];
+                        {
+                            const f32x4 ra = rr[gi & 1][2 * ih], rb = rr[gi & 1][2 * ih + 1];                  // zeros without a residual
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { v[0][q] += ra[q]; v[1][q] += rb[q]; }
                         }
