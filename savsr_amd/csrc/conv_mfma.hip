@@ -43,6 +43,13 @@
 #ifndef CONV_IL_VALU
 #define CONV_IL_VALU 3
 #endif
+// Timing experiments on the PRODUCT kernel (results invalid; never set in a shipped build): 1 = no staging in the steps,
+// 2 = no fragment reads in the steps, 4 = no epilogue body; 8 = every workgroup records its entry / exit s_memtime in
+// stamp slots 0 / 4 (clock-independent totals: the experiments change the power draw and with it the shader clock).  The run-time switches of the instrumented build cost it
+// its straight-line steps and read s_memtime (an lgkmcnt(0) wait) in every section, so small effects drown there.
+#ifndef CONV_EXP
+#define CONV_EXP 0
+#endif
 
 namespace savsr {
 
@@ -266,6 +273,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #define CV_MARK(i) do { if (stamps_on >= 3) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); sec[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     stamp(stamps_on, 0);
+    if ((CONV_EXP & 8) && !DIAG && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && blockIdx.x < STAMP_BLOCKS)   // (scalar branch: all of wave 0 stores)
+        g_conv_stamps[blockIdx.x * STAMP_N + 0] = (long long)__builtin_amdgcn_s_memtime();
     stamp(stamps_on, 5);
 
     // ---- software pipeline over the block's phases (tiles x chunks, walked linearly by the staging cursor) ----
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                     CV_MARK(3);
                     if (!FINE) pend2 = pend && stage_next();
                 }
-                if (dbg_nofrag) {
+                if (dbg_nofrag || (CONV_EXP & 2)) {
                 } else if (s + LEAD < STEPS) load_frag(buf, s + LEAD, f[(s + LEAD) % RING]);
                 else if (pend) load_frag(buf ^ 1, s + LEAD - STEPS, f[(s + LEAD) % RING]);
 #if CONV_INTERLEAVE < 2
@@ -415,11 +424,13 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 // clumps between the MFMA groups (both waves of a SIMD clump at the same time and the matrix pipe drains).
                 if (FINE && !DIAG) {
                     mma_part(f[s % RING], 0);
-                    if (s >= SD && s < SD + B_IT) stage_store_item(s - SD, buf ^ 1);
+                    if (!(CONV_EXP & 1) && s >= SD && s < SD + B_IT) stage_store_item(s - SD, buf ^ 1);
                     mma_part(f[s % RING], 1);
-                    if (s < SB) { if (LEAD + s < W_IT) issue_w(LEAD + s, buf ^ 1); }
-                    else if (s - SB < W_IT) issue_w(s - SB, buf);
-                    if (s >= LB0 && s - LB0 < B_IT) issue_b(s - LB0);
+                    if (!(CONV_EXP & 1)) {
+                        if (s < SB) { if (LEAD + s < W_IT) issue_w(LEAD + s, buf ^ 1); }
+                        else if (s - SB < W_IT) issue_w(s - SB, buf);
+                        if (s >= LB0 && s - LB0 < B_IT) issue_b(s - LB0);
+                    }
                     mma_part(f[s % RING], 2);
 #pragma unroll
                     for (int i = 0; i < 3 * PXT * NT; ++i) {
@@ -493,14 +504,15 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         // (the epilogue's ~10 scalar branches per unit were a third of its time).
         const bool chan_full = (cob + 1) * COT <= COUT;       // the 16-row variant is only launched with cout % 64 == 0
         const bool x_inside = x0 + CONV_TW <= W;
-        if (DIAG && (dbg_all & 256)) {
+        if ((DIAG && (dbg_all & 256)) || (CONV_EXP & 4)) {
             // timing experiment: no epilogue body at all (results invalid)
 #pragma unroll
             for (int r = 0; r < PXT; ++r)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { psum[r][t] = f32x4{0.f, 0.f, 0.f, 0.f}; asm volatile("" :: "v"(acc[r][t][0])); }
         } else if (PXT > 1 || chan_full) {
-            // (a branch-free variant of this path for interior tiles, chosen once per tile, measured the same: A/B/A on one box)
+            // (a second instance of this path without per-lane bounds tests for tiles inside the image, chosen once per tile,
+            // measured the same twice: A/B/A/B on one box, before and after the wait-count repairs below)
             // loads that do not depend on the accumulators go out first: the bias quads of both channel groups, and the
             // residual quads one (row, channel-group) step ahead of their use (issued next to their use they exposed one
             // global-load latency per step)
@@ -711,7 +723,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 for (int wv = 0; wv < CONV_TH; ++wv) sacc += pl_[(r * CONV_TH + wv) * COT + ch];
                 const int band = cur.ty * PXT + r;                       // 8-row band of the image
                 if (cob * COT + ch < COUT && band * CONV_TH < H)
-                    e_pool[(long long)(band * mp.ntx + cur.tx) * p.pool_stride + cob * COT + ch] = sacc;
+                    stg1(e_pool, (unsigned)((band * mp.ntx + cur.tx) * p.pool_stride + cob * COT + ch), sacc);   // (a FLAT store here makes hipcc force the next VMEM wait of the following tile to vmcnt(0))
             }
             __syncthreads();                         // the slices are reused by the next tile's epilogue
         } else if (EP_ALIAS) {
@@ -721,6 +733,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     // The last phases re-stage unconditionally (straight-line steps): no LDS-DMA of this wave may still be in flight when
     // its LDS is released.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((CONV_EXP & 8) && !DIAG && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && blockIdx.x < STAMP_BLOCKS)
+        g_conv_stamps[blockIdx.x * STAMP_N + 4] = (long long)__builtin_amdgcn_s_memtime();
     if (stamps_on == 1) {
         __builtin_amdgcn_s_waitcnt(0);              // diagnostics: include the store drain in the last stamp
         stamp(stamps_on, 4);

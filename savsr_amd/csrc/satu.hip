@@ -517,6 +517,11 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int X0 = blockIdx.x * 32 * p.txw, Y0 = blockIdx.y * p.ty;
     const long long t_entry = DIAG ? SATU_T() : 0;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);      // tile walk and row / column tests as scalar code
+    // per-lane column constants of the first column tile (the only one when txw == 1); issued first, under the staging
+    const int Xc0 = (X0 + px < p.W) ? X0 + px : p.W - 1;
+    int iw0 = p.idx_w[Xc0];
+    float gxn0 = p.gxn[Xc0];
 
     // ---- stage the LRcat window of this tile, the expert-MFMA A operands, the bias and the phase table -------
     float* cst = lds + p.lrh * p.lrw * HR_LDS_REC;
@@ -575,11 +580,13 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
     tacc[4] = t_prev - t_entry;                                      // staging of the LDS window + constants
 #define HR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
     const int ntile = p.ty * p.txw;
-    // per-lane column constants of the first column tile (the only one when txw == 1)
-    const int Xc0 = (X0 + px < p.W) ? X0 + px : p.W - 1;
-    const int iw0 = p.idx_w[Xc0];
-    const float gxn0 = p.gxn[Xc0];
-    for (int T = wave; T < ntile; T += HR_WAVES) {
+    // No load may be pending, as far as hipcc can tell, when the tile loop is entered or continued: its waits count only
+    // what it can see on every path, so one conditional load in the loop (or one issued in front of it) turns into
+    // s_waitcnt vmcnt(0..1) at the top of EVERY tile -- behind the previous tile's 64 output stores, i.e. a full write
+    // round trip per tile.  The column constants are therefore consumed here (they landed under the staging), and the
+    // loads of the other column tiles are waited for inside their branch.
+    asm volatile("" : "+v"(iw0), "+v"(gxn0));
+    for (int T = wave_s; T < ntile; T += HR_WAVES) {
         const int trow = p.txw == 1 ? T : T / p.txw;                // (a run-time integer division is ~14 vector instructions)
         const int Y = Y0 + trow;
         const int Xb = X0 + (T - trow * p.txw) * 32;
@@ -587,17 +594,31 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
         const int X = Xb + px;
         const bool valid = X < p.W && !dbg_nostore;
         const int Xc = X < p.W ? X : p.W - 1;
-        const bool col0 = Xb == X0;                                   // wave-uniform
-        const int iw = col0 ? iw0 : p.idx_w[Xc];
-        const long long ent = ((long long)__float_as_int(rowc[trow]) * p.n_uw + iw) * SAVSR_SATU_TABLE;
-        const float* te = tab ? tab + ent : p.table + ent;
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
-        f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
-        if (!tab) {                                                   // (wave-uniform) global table: raw offsets
+        const bool col0 = Xb == X0;                                   // scalar
+        int iw = iw0;
+        float gxn = gxn0;
+        if (!col0) {
+            iw = p.idx_w[Xc];
+            gxn = p.gxn[Xc];
+            asm volatile("" : "+v"(iw), "+v"(gxn));                   // (waited for here, see above)
+        }
+        // Two explicit address spaces: a pointer select between the LDS copy and the global table compiles to FLAT loads,
+        // which count on vmcnt AND lgkmcnt and after which hipcc forces every wait of the tile to zero.
+        f32x4 rr, oo;
+        if (tab) {                                                    // (wave-uniform) LDS copy: offsets already normalised
+            const float* te = tab + (__float_as_int(rowc[trow]) * p.n_uw + iw) * SAVSR_SATU_TABLE;
+            rr = *reinterpret_cast<const f32x4*>(te);
+            oo = *reinterpret_cast<const f32x4*>(te + 4);
+        } else {                                                      // global table: raw offsets
+            typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+            const long long ent = ((long long)__float_as_int(rowc[trow]) * p.n_uw + iw) * SAVSR_SATU_TABLE;
+            rr = *(gf32x4*)(p.table + ent);
+            oo = *(gf32x4*)(p.table + ent + 4);
+            asm volatile("" : "+v"(rr), "+v"(oo));                    // both waited for inside the branch (see above the loop)
             oo[0] = (oo[0] * 2.f) / (float)(p.w - 1); oo[1] = (oo[1] * 2.f) / (float)(p.h - 1);
             oo[2] = (oo[2] * 2.f) / (float)(p.w - 1); oo[3] = (oo[3] * 2.f) / (float)(p.h - 1);
         }
-        const float gxn = col0 ? gxn0 : p.gxn[Xc], gyn = rowc[HR_MAX_ROWS + trow];
+        const float gyn = rowc[HR_MAX_ROWS + trow];
         if (stamps_on) { asm volatile("" :: "v"(rr[0]), "v"(oo[0])); }
         HR_MARK(0);                                                  // table lookup
         const Taps to = make_taps(gxn, gyn, oo[0], oo[1], p.h, p.w);
@@ -614,7 +635,10 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
         // byte offset of this lane's pixel inside channel plane acc_row(r, 0); the half's +4 channels are folded in
         const unsigned o_off = 4u * (unsigned)(Y * p.W + X) + (half ? 16u * (unsigned)p.out_plane : 0u);
         if (__all(inside)) hr_tile<true>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
-        else hr_tile<false>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
+        else {
+            hr_tile<false>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
+            __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the fallback's gathers are not left pending either (see above the loop)
+        }
         HR_MARK(2);                                                  // gathers + MFMA + store issue
     }
     if (stamps_on) {

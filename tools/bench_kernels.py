@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--h", type=int, default=180)
     ap.add_argument("--w", type=int, default=320)
     ap.add_argument("--batch", type=int, default=1, help="conv: convs per launch (savsr_conv2d_batch)")
+    ap.add_argument("--cycles", action="store_true", help="conv, library built with -DCONV_EXP=8 (+ experiments): per-workgroup s_memtime totals")
     ap.add_argument("--stamps", action="store_true", help="conv / satu: print per-workgroup section timings (s_memtime)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -70,6 +71,15 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     us = 1e3 * ev0.elapsed_time(ev1) / a.iters
+    if a.cycles and a.what == "conv":
+        import ctypes as C
+        import numpy as np
+        nb = min(256, a.batch * ((w + 31) // 32) * ((h + 7) // 8))
+        buf = (C.c_longlong * (6 * nb))()
+        eng.lib.savsr_debug_read_conv_stamps(buf, nb)
+        st = np.array(buf[:], dtype=np.int64).reshape(nb, 6)
+        tot = st[:, 4] - st[:, 0]
+        print("workgroup s_memtime totals: median %d  max %d  -> %.2f GHz against the event time" % (np.median(tot), tot.max(), tot.max() / us / 1e3))
     if a.stamps and a.what == "conv":
         import ctypes as C
         import numpy as np
