@@ -417,6 +417,15 @@ __device__ __forceinline__ Taps make_taps(float gxn, float gyn, float onx, float
     return t;
 }
 
+// acc[4g .. 4g+3] += w * v as two v_pk_fma_f32 (explicit 2-vectors: the SLP vectoriser packs only about half of these)
+__device__ __forceinline__ void fma_quad(f32x16& acc, int g, float w, const f32x4& v) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 w2 = {w, w};
+    const f32x2 a01 = __builtin_elementwise_fma(w2, f32x2{v[0], v[1]}, f32x2{acc[4 * g], acc[4 * g + 1]});
+    const f32x2 a23 = __builtin_elementwise_fma(w2, f32x2{v[2], v[3]}, f32x2{acc[4 * g + 2], acc[4 * g + 3]});
+    acc[4 * g] = a01[0]; acc[4 * g + 1] = a01[1]; acc[4 * g + 2] = a23[0]; acc[4 * g + 3] = a23[1];
+}
+
 template <bool FROM_LDS>
 __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int ly0, int lx0, const Taps& to, const Taps& ts,
                                         const f32x4 rr, int half, int lane, bool valid, unsigned o_off, const float* cst) {
@@ -468,6 +477,11 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
     const bf16x8* wimg = reinterpret_cast<const bf16x8*>(cst) + lane;               // LDS copy of [t][ks][part][lane]
     const f32x4* fb4 = reinterpret_cast<const f32x4*>(cst + 2 * 2 * 2 * 64 * 4 + half * 32);   // LDS copy of fusion_b, packed [half][q]
     const long long HW = p.out_plane;
+    // The 32 plane bases of a tile's stores are rebuilt from this pointer with scalar adds for every tile.  Left
+    // loop-invariant, hipcc keeps all of them (64 SGPRs) across the tile loop, spills them to VGPR lanes and pays two
+    // v_readlane + one 64-bit VALU add per store in a VALU-issue-bound kernel.
+    float* outp = p.out;
+    asm volatile("" : "+s"(outp));
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         f32x16 acc;
@@ -483,7 +497,7 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = ro[k][16 * half + 8 + 4 * t + g];
-                acc[4 * g] += wk * v[0]; acc[4 * g + 1] += wk * v[1]; acc[4 * g + 2] += wk * v[2]; acc[4 * g + 3] += wk * v[3];
+                fma_quad(acc, g, wk, v);
             }
         }
         // + (Wb E) v on the bf16 matrix cores (split operands)
@@ -497,13 +511,18 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = rs[k][16 * half + 4 * t + g];
-                acc[4 * g] += wk * v[0]; acc[4 * g + 1] += wk * v[1]; acc[4 * g + 2] += wk * v[2]; acc[4 * g + 3] += wk * v[3];
+                fma_quad(acc, g, wk, v);
             }
         }
         if (valid) {
+            unsigned oo = o_off;
+            asm volatile("" : "+v"(oo));       // the 32 -> 64-bit extension must sit in THIS block for the (scalar base, 32-bit lane offset) store form to be selected
 #pragma unroll
-            for (int r = 0; r < 16; ++r)       // uniform plane base (scalar arithmetic) + one per-lane 32-bit byte offset: no 64-bit VALU add per store
-                *(__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)(p.out + (long long)(32 * t + acc_row(r, 0)) * HW) + o_off) = acc[r];
+            for (int r = 0; r < 16; ++r) {     // uniform plane base (scalar arithmetic) + one per-lane 32-bit byte offset: no 64-bit VALU add per store
+                float* pl = outp + (long long)(32 * t + acc_row(r, 0)) * HW;
+                asm volatile("" : "+s"(pl));     // (opaque, or hipcc re-associates to (outp + lane offset) + plane: a 64-bit VALU add per store)
+                *(__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)pl + oo) = acc[r];
+            }
         }
     }
 }
