@@ -215,12 +215,22 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
                 return *reinterpret_cast<const f32x4*>(xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half + 8 * g);
             };
             auto lrelu_x = [&](int g, const f32x16& acc, const f32x4 xq) {   // sta += LeakyReLU_0.1(K) * x_pad   (:228, :297-313)
+                // 2 vector instructions per element: v_pk_mul (0.1 k), v_max (one: fmaxf costs two, NaN canonicalisation), v_pk_fma.
+                // The max and the accumulation are VOLATILE asm: pure arithmetic has no ordering against the sched_barriers
+                // between the MFMA groups, and hipcc's DAG scheduler collected all of a phase's LeakyReLU * x work (260
+                // instructions) into one clump behind the barrier, serial to the phase's 60 MFMAs (ISA listing).
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float k = acc[4 * g + i];
-                    // max(k, 0.1 k) as one v_med3_f32 against +inf: fmaxf costs two v_max_f32 (NaN canonicalisation) and this
-                    // loop is VALU-issue-bound beside the MFMAs (6 VALU per MFMA)
-                    sacc[4 * g + i] += __builtin_amdgcn_fmed3f(k, 0.1f * k, __builtin_inff()) * xq[i];
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x2 k = {acc[4 * g + 2 * h2], acc[4 * g + 2 * h2 + 1]};
+                    const f32x2 t = k * f32x2{0.1f, 0.1f};
+                    float m0, m1;
+                    asm volatile("v_max_f32 %0, %2, %3\n\tv_max_f32 %1, %4, %5" : "=&v"(m0), "=&v"(m1) : "v"(k[0]), "v"(t[0]), "v"(k[1]), "v"(t[1]));
+                    f32x2 sv = {sacc[4 * g + 2 * h2], sacc[4 * g + 2 * h2 + 1]};
+                    const f32x2 m = {m0, m1}, x2 = {xq[2 * h2], xq[2 * h2 + 1]};
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(sv) : "v"(m), "v"(x2));
+                    sacc[4 * g + 2 * h2] = sv[0];
+                    sacc[4 * g + 2 * h2 + 1] = sv[1];
                 }
             };
             AFrag fr;                                 // ONE fragment set: a k-step's pair is reloaded for the next tap as soon as its
