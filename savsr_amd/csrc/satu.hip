@@ -19,6 +19,11 @@
 //   the lane that consumes it (HR stage): no cross-lane movement on either side.
 #include "common.hpp"
 
+// Timing experiments on the product LR kernel (results invalid; never set in a shipped build): 1 = weight fragments not
+// re-read per tap, 2 = x / bias quads not re-read per group.
+#ifndef LR_EXP
+#define LR_EXP 0
+#endif
 #ifndef LR_INTERLEAVE
 #define LR_INTERLEAVE 1
 #endif
@@ -253,14 +258,14 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
 #if !LR_INTERLEAVE
                 __builtin_amdgcn_sched_barrier(0);
 #endif
-                if (kx + 1 < 5) { fr.ah[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 0) * 64]; fr.al[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 1) * 64]; }
+                if (!(LR_EXP & 1) && kx + 1 < 5) { fr.ah[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 0) * 64]; fr.al[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 1) * 64]; }
                 if (kx > 0) lrelu_x(ks, acc[(kx - 1) & 1], x_pf);
                 if (kx + 1 < 5) {
                     f32x16& an = acc[(kx + 1) & 1];
                     an[4 * ks] = b_pf[0]; an[4 * ks + 1] = b_pf[1]; an[4 * ks + 2] = b_pf[2]; an[4 * ks + 3] = b_pf[3];
                 }
                 const int G1 = G + 1, kx1 = G1 / 4, ks1 = G1 % 4;
-                if (G1 < 20) {
+                if (G1 < 20 && !(LR_EXP & 2)) {
                     if (kx1 > 0) x_pf = x_read(kx1 - 1, ks1);
                     if (kx1 + 1 < 5) b_pf = bias_read(kx1 + 1, ks1);
                 }
