@@ -20,7 +20,8 @@
 #include "common.hpp"
 
 // Timing experiments on the product LR kernel (results invalid; never set in a shipped build): 1 = weight fragments not
-// re-read per tap, 2 = x / bias quads not re-read per group.
+// re-read per tap, 2 = x / bias quads not re-read per group; 8 = every workgroup records its s_memtime total in stamp
+// slot 7 (cycles are the comparable figure: the variants change the power draw and with it the shader clock).
 #ifndef LR_EXP
 #define LR_EXP 0
 #endif
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
     long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t_prev = stamps_on ? SATU_T() : 0;
     const long long t_begin = t_prev;
+    const long long t_lr0 = (LR_EXP & 8) ? SATU_T() : 0;
 #define LR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     const bf16x8* kw = reinterpret_cast<const bf16x8*>(p.wt.kconv_w);
@@ -339,6 +341,10 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
         accC = mma3(pc[(ks * 2 + 0) * 64], pc[(ks * 2 + 1) * 64], xh, xl, accC);
     }
     LR_MARK(4);                                        // projections
+    if ((LR_EXP & 8) && !DIAG && __builtin_amdgcn_readfirstlane(tid) == 0) {      // (scalar branch: all of wave 0 stores)
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        if (b < SSTAMP_BLOCKS) g_satu_stamps[b * SSTAMP_N + 7] = SATU_T() - t_lr0;
+    }
     if (stamps_on && tid == 0) {
         const int b = blockIdx.x + gridDim.x * blockIdx.y;
         if (b < SSTAMP_BLOCKS) {

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--h", type=int, default=180)
     ap.add_argument("--w", type=int, default=320)
     ap.add_argument("--batch", type=int, default=1, help="conv: convs per launch (savsr_conv2d_batch)")
-    ap.add_argument("--cycles", action="store_true", help="conv, library built with -DCONV_EXP=8 (+ experiments): per-workgroup s_memtime totals")
+    ap.add_argument("--cycles", action="store_true", help="conv / satu, library built with -DCONV_EXP=8 / -DLR_EXP=8 (+ experiments): per-workgroup s_memtime totals")
     ap.add_argument("--stamps", action="store_true", help="conv / satu: print per-workgroup section timings (s_memtime)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -118,6 +118,14 @@ def main():
             print("experiment (%s; results invalid): %.2f us/iter; wave-4 sections %s" % (name, 1e3 * ev0.elapsed_time(ev1) / 5, np.median(s3, axis=0).astype(int).tolist()))
         rt = st[:, 5]
         print("workgroup start spread (100 MHz ticks): min %d max %d -> %.2f us" % (rt.min(), rt.max(), (rt.max() - rt.min()) / 100.0))
+    if a.cycles and a.what == "satu":
+        import ctypes as C
+        import numpy as np
+        nb = ((w + 31) // 32) * ((h + 7) // 8)
+        buf = (C.c_longlong * (8 * nb))()
+        eng.lib.savsr_debug_read_satu_stamps(buf, nb)
+        tot = np.array(buf[:], dtype=np.int64).reshape(nb, 8)[:, 7]
+        print("LR workgroup s_memtime totals (library built with -DLR_EXP=8 + experiments): median %d  max %d" % (np.median(tot), tot.max()))
     if a.stamps and a.what == "satu":
         import ctypes as C
         import numpy as np

@@ -7,7 +7,7 @@
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 
-template <int BARRIER, int PRIO, int FRAG, int LAYOUT>
+template <int BARRIER, int PRIO, int FRAG, int LAYOUT, int NVALU>
 __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int phases) {
     extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
     bf16x8* lds = reinterpret_cast<bf16x8*>(raw);
@@ -19,6 +19,7 @@ __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int phases)
     for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     bf16x8 f[2][8];
     for (int i = 0; i < 8; ++i) { f[0][i] = lds[i * 64 + lane]; f[1][i] = lds[512 + i * 64 + lane]; }
+    float vx[4] = {1.f + lane, 2.f, 3.f, 4.f}; const float vy = 1.0001f;
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int ph = 0; ph < phases; ++ph) {
 #pragma unroll
@@ -41,28 +42,32 @@ __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int phases)
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
 #pragma unroll
-                for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(a & 1) * 2 + (part & 1)], fr[4 + (a >> 1) * 2 + (part >> 1)], acc[a], 0, 0, 0);
+                for (int a = 0; a < 4; ++a) {
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(a & 1) * 2 + (part & 1)], fr[4 + (a >> 1) * 2 + (part >> 1)], acc[a], 0, 0, 0);
+#pragma unroll
+                    for (int v = 0; v < NVALU; ++v) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(vx[v & 3]) : "v"(vy));   // independent vector work behind every MFMA
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
-    float sum = 0.f;
+    float sum = vx[0] + vx[1] + vx[2] + vx[3];
     for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) sum += acc[a][r];
     out[blockIdx.x * 512 + threadIdx.x] = sum;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int BARRIER, int PRIO, int FRAG, int LAYOUT>
+template <int BARRIER, int PRIO, int FRAG, int LAYOUT, int NVALU = 0>
 void run(const char* name) {
     float* out; long long* cyc;
     hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8);
     const int phases = 200;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k<BARRIER, PRIO, FRAG, LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 153600);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k<BARRIER, PRIO, FRAG, LAYOUT, NVALU>), hipFuncAttributeMaxDynamicSharedMemorySize, 153600);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<BARRIER, PRIO, FRAG, LAYOUT>), dim3(256), dim3(512), LAYOUT ? 153600 : 131072, 0, out, cyc, phases);
+    hipLaunchKernelGGL((k<BARRIER, PRIO, FRAG, LAYOUT, NVALU>), dim3(256), dim3(512), LAYOUT ? 153600 : 131072, 0, out, cyc, phases);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<BARRIER, PRIO, FRAG, LAYOUT>), dim3(256), dim3(512), LAYOUT ? 153600 : 131072, 0, out, cyc, phases);
+    hipLaunchKernelGGL((k<BARRIER, PRIO, FRAG, LAYOUT, NVALU>), dim3(256), dim3(512), LAYOUT ? 153600 : 131072, 0, out, cyc, phases);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
@@ -81,5 +86,12 @@ int main() {
     run<1, 1, 1, 0>("+ barrier + setprio + fragment reads");
     run<1, 0, 1, 1>("+ barrier + fragment reads, conv layout");
     run<1, 1, 1, 1>("+ barrier + setprio + reads, conv layout");
+    run<1, 1, 1, 1, 1>("... + 1 VALU per MFMA");
+    run<1, 1, 1, 1, 2>("... + 2 VALU per MFMA");
+    run<1, 1, 1, 1, 3>("... + 3 VALU per MFMA");
+    run<1, 1, 1, 1, 4>("... + 4 VALU per MFMA");
+    run<1, 1, 1, 1, 6>("... + 6 VALU per MFMA");
+    run<1, 0, 0, 0, 3>("MFMAs + barrier + 3 VALU per MFMA");
+    run<1, 0, 0, 0, 6>("MFMAs + barrier + 6 VALU per MFMA");
     return 0;
 }
