@@ -44,7 +44,8 @@
 #define CONV_IL_VALU 3
 #endif
 // Timing experiments on the PRODUCT kernel (results invalid; never set in a shipped build): 1 = no staging in the steps,
-// 2 = no fragment reads in the steps, 4 = no epilogue body; 8 = every workgroup records its entry / exit s_memtime in
+// 2 = no fragment reads in the steps, 4 = no epilogue body, 16 = epilogue without its global stores, 32 = without its
+// residual loads, 64 = without the LDS transpose (values straight from the accumulators); 8 = every workgroup records its entry / exit s_memtime in
 // stamp slots 0 / 4 (clock-independent totals: the experiments change the power draw and with it the shader clock).  The run-time switches of the instrumented build cost it
 // its straight-line steps and read s_memtime (an lgkmcnt(0) wait) in every section, so small effects drown there.
 #ifndef CONV_EXP
@@ -492,8 +493,15 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         float e_slope = p.slope, e_r2s = p.res2_scale;
         asm volatile("" : "+s"(e_bias), "+s"(e_mul), "+s"(e_r1), "+s"(e_r2), "+s"(e_out), "+s"(e_pool));
         asm volatile("" : "+s"(e_act), "+s"(e_opix), "+s"(e_r1pix), "+s"(e_r2pix), "+s"(e_slope), "+s"(e_r2s));
+#ifdef CONV_EPI_SIMPLE          // experiment: the common epilogue only (no per-pixel mask, no second residual, max-form activation)
+        e_mul = nullptr; e_r2 = nullptr;
+#endif
         const int COUT = mp.cout;
+#ifdef CONV_EPI_SIMPLE
+        const bool act_as_max = true;
+#else
         const bool act_as_max = e_act == SAVSR_ACT_NONE || e_act == SAVSR_ACT_RELU || (e_act == SAVSR_ACT_LRELU && e_slope >= 0.f && e_slope <= 1.f);
+#endif
         const float slope_eff = e_act == SAVSR_ACT_NONE ? 1.f : (e_act == SAVSR_ACT_RELU ? 0.f : e_slope);
         float* ep_base = reinterpret_cast<float*>(EP_ALIAS ? smem + (buf ^ 1) * B_UNITS : smem + 2 * B_UNITS + 2 * W_UNITS);
         float* ep = ep_base + wave * (32 * EPS);
@@ -528,14 +536,14 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             f32x4 bias4[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) bias4[t] = (DIAG && (dbg_all & 512)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ldg4(b_base, b_off + (unsigned)t * b_step);   // (512: timing experiment without the bias load)
-            const float* r1_base = e_r1 ? e_r1 : zero16;
+            const float* r1_base = (e_r1 && !(CONV_EXP & 32)) ? e_r1 : zero16;
             f32x4 rr[2][4];
             auto load_r1 = [&](int r, int t, f32x4 (&dst)[4]) {
                 const int y = y0 + wave_s + CONV_TH * r;
                 const int co = cob * COT + 32 * t + 4 * c4;
                 // one integer multiply per group, then uniform strides (v_mul_lo_u32 is a quarter-rate instruction)
                 const unsigned off0 = 4u * (unsigned)((y * W + x0 + (lane >> 3)) * e_r1pix + co), ustride = 32u * (unsigned)e_r1pix;
-                const bool row_ok = e_r1 && y < H;                              // scalar
+                const bool row_ok = e_r1 && !(CONV_EXP & 32) && y < H;          // scalar
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const bool ok = row_ok && (x_inside || x0 + (lane >> 3) + 8 * i < W);
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 v = {acc[r][t][4 * g], acc[r][t][4 * g + 1], acc[r][t][4 * g + 2], acc[r][t][4 * g + 3]};
-                        if (!(DIAG && dbg_nolds)) *reinterpret_cast<f32x4*>(ep + px * EPS + 8 * g + 4 * half) = v;
+                        if (!(DIAG && dbg_nolds) && !(CONV_EXP & 64)) *reinterpret_cast<f32x4*>(ep + px * EPS + 8 * g + 4 * half) = v;
                     }
                     const int co = cob * COT + 32 * t + 4 * c4;
                     const f32x4 b4 = bias4[t];
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             f32x4 a4;
-                            if (DIAG && dbg_nolds) a4 = f32x4{acc[r][t][8 * ih + 4 * i], acc[r][t][8 * ih + 4 * i + 1], acc[r][t][8 * ih + 4 * i + 2], acc[r][t][8 * ih + 4 * i + 3]};
+                            if ((DIAG && dbg_nolds) || (CONV_EXP & 64)) a4 = f32x4{acc[r][t][8 * ih + 4 * i], acc[r][t][8 * ih + 4 * i + 1], acc[r][t][8 * ih + 4 * i + 2], acc[r][t][8 * ih + 4 * i + 3]};
                             else a4 = *reinterpret_cast<const f32x4*>(ep + ((lane >> 3) + 16 * ih + 8 * i) * EPS + 4 * c4);
                             v[i] = f32x4{a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
                         }
@@ -614,7 +622,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             if (i == 0 ? ok0 : ok1) {
-                                if (!(DIAG && dbg_nost)) stg4(e_out, ooff0 + (unsigned)(2 * ih + i) * ostride, v[i]);
+                                if (!(DIAG && dbg_nost) && !(CONV_EXP & 16)) stg4(e_out, ooff0 + (unsigned)(2 * ih + i) * ostride, v[i]);
                                 else asm volatile("" :: "v"(v[i][0]), "v"(v[i][1]), "v"(v[i][2]), "v"(v[i][3]));
                                 if (e_pool) { ps[0] += v[i][0]; ps[1] += v[i][1]; ps[2] += v[i][2]; ps[3] += v[i][3]; }
                             }
