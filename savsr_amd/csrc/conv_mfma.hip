@@ -584,13 +584,17 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                             f32x4 a4;
                             if ((DIAG && dbg_nolds) || (CONV_EXP & 64)) a4 = f32x4{acc[r][t][8 * ih + 4 * i], acc[r][t][8 * ih + 4 * i + 1], acc[r][t][8 * ih + 4 * i + 2], acc[r][t][8 * ih + 4 * i + 3]};
                             else a4 = *reinterpret_cast<const f32x4*>(ep + ((lane >> 3) + 16 * ih + 8 * i) * EPS + 4 * c4);
-                            v[i] = f32x4{a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
-                        }
-                        if (act_as_max) {             // none / ReLU / LeakyReLU(0..1) as ONE v_max_f32(v, v * s), s = 1 / 0 / slope: no branch
-#pragma unroll                                        // chain (its phi copies were 300 v_mov per tile) and no NaN-canonicalising second
-                            for (int i = 0; i < 2; ++i)   // v_max (fmaxf costs two); ReLU of a negative value gives -0 instead of +0
+                            v[i] = a4 + b4;           // (whole-vector forms: two v_pk_add_f32 / v_pk_mul_f32 per quad; written per element
+                        }                             //  hipcc issued 4 scalar instructions each, and the epilogue is vector-issue-bound)
+                        if (e_act == SAVSR_ACT_NONE) {
+                            // nothing to compute (half of the launches: second convs of the residual blocks, merges)
+                        } else if (act_as_max) {      // ReLU / LeakyReLU(0..1) as ONE v_max_f32(v, v * s), s = 0 / slope: no branch chain (its
+#pragma unroll                                        // phi copies were 300 v_mov per tile) and no NaN-canonicalising second v_max (fmaxf
+                            for (int i = 0; i < 2; ++i) {   // costs two); ReLU of a negative value gives -0 instead of +0
+                                const f32x4 sv = v[i] * slope_eff;
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) v[i][q] = vmax_raw(v[i][q], v[i][q] * slope_eff);
+                                for (int q = 0; q < 4; ++q) v[i][q] = vmax_raw(v[i][q], sv[q]);
+                            }
                         } else if (e_act == SAVSR_ACT_LRELU) {
 #pragma unroll
                             for (int i = 0; i < 2; ++i)
@@ -607,11 +611,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { v[0][q] *= m0; v[1][q] *= m1; }
                         }
-                        {
-                            const f32x4 ra = rr[gi & 1][2 * ih], rb = rr[gi & 1][2 * ih + 1];                  // zeros without a residual
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { v[0][q] += ra[q]; v[1][q] += rb[q]; }
-                        }
+                        v[0] += rr[gi & 1][2 * ih];                                                   // zeros without a residual
+                        v[1] += rr[gi & 1][2 * ih + 1];
                         if (e_r2) {
                             f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
                             if (ok0) ra = ldg4(e_r2, 4u * (unsigned)(p0 * e_r2pix + co));
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                             if (i == 0 ? ok0 : ok1) {
                                 if (!(DIAG && dbg_nost) && !(CONV_EXP & 16)) stg4(e_out, ooff0 + (unsigned)(2 * ih + i) * ostride, v[i]);
                                 else asm volatile("" :: "v"(v[i][0]), "v"(v[i][1]), "v"(v[i][2]), "v"(v[i][3]));
-                                if (e_pool) { ps[0] += v[i][0]; ps[1] += v[i][1]; ps[2] += v[i][2]; ps[3] += v[i][3]; }
+                                if (e_pool) ps += v[i];
                             }
                         }
                     }
