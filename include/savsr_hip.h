@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 11
+#define SAVSR_ABI_VERSION 12
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -174,6 +174,8 @@ int savsr_pack_windows(const float* lq, float* out, int T, int h, int w, int hp,
 #define SAVSR_SATU_C      64
 #define SAVSR_SATU_LRCAT  160
 #define SAVSR_SATU_TABLE  8    /* r0 r1 r2 r3 off_x off_y soff_x soff_y */
+#define SAVSR_SATU_LRCAT_TAIL 96 /* LRcat record of the tail-projected form (savsr_satu_*_tail) */
+#define SAVSR_TAIL_PLANES 27     /* 9 taps x 3 colours */
 
 typedef struct savsr_satu_weights {      /* all device pointers; packed by the caller */
     const float* body0_w; const float* body0_b;   /* [64][4], [64]   savsr_arch.py:245 */
@@ -199,12 +201,19 @@ int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const floa
 /* Optional LDS staging plan of the HR stage (a pure performance hint; results never depend on it):
  * each workgroup owns tile_rows x (32 * tile_cols32) HR pixels and stages an lr_rows x lr_cols window
  * of LRcat records whose origin is the tile's base sampling coordinate + (off_min_x, off_min_y).
- * Waves whose taps leave the window gather from global memory instead.  NULL = no staging. */
+ * Waves whose taps leave the window gather from global memory instead.  NULL = no window staging.
+ * The workgroup also stages its own tile_rows x (32 tile_cols32) slice of the phase table, so the
+ * LDS need is savsr_satu_hr_lds_bytes(form, tile_rows, tile_cols32, lr_rows, lr_cols) <= 160 KiB
+ * (two workgroups per CU need <= ~80 KiB each). */
 typedef struct savsr_satu_tiling {
     int32_t tile_rows, tile_cols32, lr_rows, lr_cols;
     float   off_min_x, off_min_y;
-    int32_t table_entries;   /* n_uh * n_uw (tables of <= 256 entries are cached in LDS); 0 = unknown */
+    int32_t table_entries;   /* n_uh * n_uw; informational (every table size takes the same path) */
+    float   step_x, step_y;  /* LR pixels per HR pixel (1 / scale_w, 1 / scale_h) for the window origin; <= 0: w / W, h / H */
 } savsr_satu_tiling;
+int64_t savsr_satu_hr_lds_bytes(int tail_form, int tile_rows, int tile_cols32, int lr_rows, int lr_cols);
+/* resident workgroups per CU the HR kernel of a form is compiled for (plan tiles so that this many fit 160 KiB of LDS) */
+int savsr_satu_hr_occupancy_target(int tail_form);
 
 /* gxn[W], gyn[H]: normalised base grid coordinates (savsr_arch.py:270-280) computed by the caller
  * in fp32; idx_h[H], idx_w[W]: index of each row/column's (coor_h, coor_w) value in the table.
@@ -214,6 +223,26 @@ int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int
                            const float* table, int n_uw, const int32_t* idx_h, const int32_t* idx_w,
                            const float* gyn, const float* gxn, int H, int W,
                            const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tail-projected form of SATU + tail = savsr_arch.py:315-376 followed by :738-739, the form SAVSR.forward runs.
+ * The tail conv is linear and a bilinear gather commutes with a channel contraction, so the tail's weights, regrouped as
+ * Wt27[p = 3 (3 ky + kx) + o][c] (27 rows, padded to 32), are multiplied into every matrix of the stage by the caller:
+ *   wt->proj_w   = LR projections (Wt27 Wa | Wt27 Wb | C-stack), wt->wbe_w = (Wt27 Wb E_n), wt->fusion_b = Wt27 b
+ *   P[p] = G(Wt27 Wa sta, soff) + G(Wt27 Wb x, off) + sum_n r_n (Wt27 Wb E_n)(sum_m r_m C_m G(x, off)) + Wt27 b
+ * savsr_satu_lr_stage_tail -> LRcat [h][w][96]; savsr_satu_hr_tail -> P: [27] planes of [H][W]; savsr_tail_gather adds
+ * the nine shifted taps per colour, the tail bias and the bilinear residual of the unpadded centre frame.
+ * The [64][H][W] SATU output never exists (236 MB written + re-read per 720x1280 frame in the two-kernel form).
+ * Same argument meaning as the standalone entry points above. */
+int savsr_satu_lr_stage_tail(const savsr_satu_weights* wt, const float* x, const float* st,
+                             int32_t pix, int32_t row_px, int h, int w, float* lrcat, void* stream);
+int savsr_satu_hr_tail(const savsr_satu_weights* wt, const float* lrcat, int h, int w,
+                       const float* table, int n_uw, const int32_t* idx_h, const int32_t* idx_w,
+                       const float* gyn, const float* gxn, int H, int W,
+                       const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream);
+/* p27: [27] planes of [H][W], p_plane floats apart; center: [3][h][w]; out: [3][H][W] contiguous. */
+int savsr_tail_gather(const float* p27, int64_t p_plane, const float* tail_b, const float* center,
+                      int h, int w, int H, int W, float* out, void* stream);
 
 /* tail conv 3x3 64->3 + bias at HR plus the bilinear residual of the (unpadded) centre frame
  * (savsr_arch.py:738-739).  feat: [64] planes of [H][W], feat_plane floats apart; center: [3][h][w];

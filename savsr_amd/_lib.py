@@ -9,13 +9,17 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsavsr_hip.so")
+# SAVSR_LIB_PATH: diagnostics only (tools/conv_experiments.sh loads an experiment build under its own name so that the
+# product library is never overwritten); unset, the in-tree product library is the only one ever loaded.
+LIB_PATH = os.environ.get("SAVSR_LIB_PATH") or os.path.join(_HERE, "csrc", "libsavsr_hip.so")
 
 MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 11
+ABI_VERSION = 12
+SATU_LRCAT_TAIL = 96
+TAIL_PLANES = 27
 
 fptr = C.c_void_p   # raw device pointers travel as integers
 
@@ -63,7 +67,8 @@ class SatuWeights(C.Structure):
 
 class SatuTiling(C.Structure):
     _fields_ = [("tile_rows", C.c_int32), ("tile_cols32", C.c_int32), ("lr_rows", C.c_int32), ("lr_cols", C.c_int32),
-                ("off_min_x", C.c_float), ("off_min_y", C.c_float), ("table_entries", C.c_int32)]
+                ("off_min_x", C.c_float), ("off_min_y", C.c_float), ("table_entries", C.c_int32),
+                ("step_x", C.c_float), ("step_y", C.c_float)]
 
 
 # name -> (restype, argtypes); must list every symbol include/savsr_hip.h declares
@@ -90,6 +95,13 @@ SIGNATURES = {
                                       fptr, C.c_void_p]),
     "savsr_satu_hr_upsample": (C.c_int, [C.POINTER(SatuWeights), fptr, C.c_int, C.c_int, fptr, C.c_int, fptr, fptr,
                                          fptr, fptr, C.c_int, C.c_int, C.POINTER(SatuTiling), fptr, C.c_int64, C.c_void_p]),
+    "savsr_satu_lr_stage_tail": (C.c_int, [C.POINTER(SatuWeights), fptr, fptr, C.c_int32, C.c_int32, C.c_int, C.c_int,
+                                           fptr, C.c_void_p]),
+    "savsr_satu_hr_tail": (C.c_int, [C.POINTER(SatuWeights), fptr, C.c_int, C.c_int, fptr, C.c_int, fptr, fptr,
+                                     fptr, fptr, C.c_int, C.c_int, C.POINTER(SatuTiling), fptr, C.c_int64, C.c_void_p]),
+    "savsr_satu_hr_occupancy_target": (C.c_int, [C.c_int]),
+    "savsr_satu_hr_lds_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "savsr_tail_gather": (C.c_int, [fptr, C.c_int64, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
     "savsr_debug_conv_stamps": (C.c_int, [C.c_int]),
     "savsr_debug_satu_stamps": (C.c_int, [C.c_int]),
     "savsr_debug_read_satu_stamps": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),

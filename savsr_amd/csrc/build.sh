@@ -1,20 +1,62 @@
 #!/bin/bash
 # Builds libsavsr_hip.so for gfx950 in-tree (the .so is git-ignored but travels with gpurun).
+#
+# An object is rebuilt when its source, a shared header or the compile flags changed: the flags (incl. EXTRA_FLAGS,
+# which the experiment scripts use for -D switches) are hashed into <obj>.flags next to each object, so an object
+# left behind by an experiment build is never linked into the product library.  A failed compile removes its object
+# and fails the script (every background job is waited for by PID).
+#   OUT=<name>.so    library to link (default libsavsr_hip.so; experiment builds use their own name)
+#   OBJDIR=<dir>     where objects go (default: this directory)
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function ${EXTRA_FLAGS:-}"
+OUT=${OUT:-libsavsr_hip.so}
+OBJDIR=${OBJDIR:-.}
+mkdir -p "$OBJDIR"
+SIG=$(printf '%s' "$HIPCC $FLAGS" | sha1sum | cut -d' ' -f1)
+
+stale() {   # stale <src> <obj>
+  local src=$1 obj=$2
+  [ ! -f "$obj" ] || [ ! -f "$obj.flags" ] || [ "$(cat "$obj.flags")" != "$SIG" ] ||
+    [ "$src" -nt "$obj" ] || [ common.hpp -nt "$obj" ] || [ ../../include/savsr_hip.h -nt "$obj" ]
+}
+
+compile() { # compile <src> <obj> [extra hipcc args]
+  local src=$1 obj=$2
+  shift 2
+  rm -f "$obj" "$obj.flags"
+  if $HIPCC $FLAGS "$@" -c "$src" -o "$obj.tmp"; then
+    mv "$obj.tmp" "$obj"
+    printf '%s' "$SIG" > "$obj.flags"
+  else
+    rm -f "$obj.tmp"
+    return 1
+  fi
+}
+
 OBJS=()
+PIDS=()
 for f in conv_mfma.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip; do
-  o="${f%.hip}.o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.hpp -nt "$o" ] || [ ../../include/savsr_hip.h -nt "$o" ]; then
-    $HIPCC $FLAGS -c "$f" -o "$o" &
+  o="$OBJDIR/${f%.hip}.o"
+  if stale "$f" "$o"; then
+    compile "$f" "$o" &
+    PIDS+=($!)
   fi
   OBJS+=("$o")
 done
-if [ ! -f api.o ] || [ api.cpp -nt api.o ] || [ common.hpp -nt api.o ] || [ ../../include/savsr_hip.h -nt api.o ]; then
-  $HIPCC $FLAGS -x hip -c api.cpp -o api.o &
+if stale api.cpp "$OBJDIR/api.o"; then
+  compile api.cpp "$OBJDIR/api.o" -x hip &
+  PIDS+=($!)
 fi
-wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libsavsr_hip.so "${OBJS[@]}" api.o
-echo "built $(pwd)/libsavsr_hip.so"
+rc=0
+for p in "${PIDS[@]:-}"; do
+  [ -z "$p" ] && continue
+  wait "$p" || rc=1
+done
+if [ $rc -ne 0 ]; then
+  echo "build.sh: a compile failed; $OUT not linked" >&2
+  exit 1
+fi
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${OBJS[@]}" "$OBJDIR/api.o"
+echo "built $(pwd)/$OUT"

@@ -16,6 +16,11 @@ inline int fail_arg(const char* what) {
     return SAVSR_E_ARG;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for kernels that use more than 64 KiB of dynamic LDS.  The attribute is
+// per (function, DEVICE): the guard is keyed by the current device so that a process driving several GPUs (one engine
+// per device, or the reference's non-distributed DataParallel flow) sets it on each of them.  Benign race: idempotent.
+int ensure_dynamic_lds(const void* fn, int bytes, const char* what);
+
 inline int check_launch(const char* kernel) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

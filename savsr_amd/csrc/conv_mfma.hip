@@ -760,16 +760,7 @@ static int launch_conv_impl(const MultiConvParams& mp, hipStream_t st) {
     constexpr int NPX = (CONV_TH * PXT + 2 * HALO) * (CONV_TW + 2 * HALO);
     constexpr size_t lds = 16ull * 2 * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64) + (PXT > 1 ? 0ull : 4ull * CONV_TH * 32 * 36);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;      // benign race: idempotent attribute set
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT, DIAG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("conv: hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds, hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_done = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT, DIAG>), (int)lds, "conv")) return rc;
     const int total = mp.nconv * mp.ncob * mp.ntx * mp.nty;
     const int grid = total < CONV_PERSISTENT_BLOCKS ? total : CONV_PERSISTENT_BLOCKS;   // one resident workgroup per CU
     hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, PXT, DIAG>), dim3(grid), dim3(64 * CONV_TH), lds, st, mp);
@@ -829,7 +820,10 @@ static int fill_params(const savsr_conv_desc* d, ConvParams& p) {
     if (d->cin != d->nsrc * d->src_ch) return fail_arg("conv: cin != nsrc*src_ch");
     if (d->h < 1 || d->w < 1 || d->cout < 1) return fail_arg("conv: shape");
     if (!d->wpacked || !d->out) return fail_arg("conv: null weights/out");
-    uintptr_t al = reinterpret_cast<uintptr_t>(d->wpacked) | reinterpret_cast<uintptr_t>(d->out) | (uintptr_t)(d->out_pix * 4);
+    // sources, weights and bias are read with 16-B LDS-DMA / vector loads whatever the output width; only the OUTPUT-side
+    // tensors (out, residuals: addressed per output channel) fall back to scalar accesses when cout < 4 (the 1-channel mask conv)
+    uintptr_t al = reinterpret_cast<uintptr_t>(d->wpacked);
+    uintptr_t al_out = reinterpret_cast<uintptr_t>(d->out) | (uintptr_t)(d->out_pix * 4);
     for (int i = 0; i < SAVSR_MAX_SRC; ++i) {
         const bool on = i < d->nsrc;
         if (on && !d->src[i]) return fail_arg("conv: null source");
@@ -837,10 +831,10 @@ static int fill_params(const savsr_conv_desc* d, ConvParams& p) {
         p.src_pix[i] = on ? d->src_pix[i] : 0;
         if (on) al |= reinterpret_cast<uintptr_t>(d->src[i]) | (uintptr_t)(d->src_pix[i] * 4);
     }
-    if (d->res1) al |= reinterpret_cast<uintptr_t>(d->res1) | (uintptr_t)(d->res1_pix * 4);
-    if (d->res2) al |= reinterpret_cast<uintptr_t>(d->res2) | (uintptr_t)(d->res2_pix * 4);
+    if (d->res1) al_out |= reinterpret_cast<uintptr_t>(d->res1) | (uintptr_t)(d->res1_pix * 4);
+    if (d->res2) al_out |= reinterpret_cast<uintptr_t>(d->res2) | (uintptr_t)(d->res2_pix * 4);
     if (d->bias) al |= reinterpret_cast<uintptr_t>(d->bias);
-    if ((al & 15) && d->cout >= 4) {
+    if ((al & 15) || ((al_out & 15) && d->cout >= 4)) {
         set_error("conv: sources / residuals / bias / out / weights must be 16-byte aligned with pixel strides multiple of 4 floats");
         return SAVSR_E_ALIGN;
     }

@@ -31,7 +31,11 @@
 
 namespace savsr {
 
-constexpr int REC = SAVSR_SATU_LRCAT;      // 160
+// Floats per LRcat record for NB 32-row output blocks per projection: (A | B) per lane half, then the 32 compressed channels.
+// NB = 2: the standalone SATU (64 fused channels, SAVSR_SATU_LRCAT = 160); NB = 1: the tail-projected form (27 of 32 rows
+// used, SAVSR_SATU_LRCAT_TAIL = 96), see the header comment of the HR stage.
+__host__ __device__ constexpr int rec_floats(int nb) { return 64 * nb + 32; }
+static_assert(rec_floats(2) == SAVSR_SATU_LRCAT && rec_floats(1) == SAVSR_SATU_LRCAT_TAIL, "record sizes");
 
 // Diagnostics (never used by the product path): accumulated s_memtime deltas of kernel sections, written by
 // wave 0 of each workgroup when enabled with savsr_debug_satu_stamps(1).
@@ -121,8 +125,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, const void* lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
-template <bool DIAG>      // DIAG: instrumented build (section stamps), launched only while savsr_debug_satu_stamps is on
+template <bool DIAG, int NB>      // DIAG: instrumented build (section stamps), launched only while savsr_debug_satu_stamps is on
 __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
+    constexpr int REC = rec_floats(NB);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xt = smem;                                                   // [432][36]: replicate-padded x tile of one channel group
     bf16x8* wbuf = reinterpret_cast<bf16x8*>(smem + LR_NPX * LR_XS);    // [2][LR_PHASE]: weight slabs of a kernel row, double buffered
@@ -202,9 +207,9 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
             // staged under this phase: the next kernel row's slabs; at the end of a channel group also the next x tile;
             // under the very last phase the projection weights (same 40 KB) and the centre pixel's x
             if (ph + 1 < 10) dma_phase(ph + 1, buf ^ 1);
-            else {
+            else {                                    // projection image: (2 NB + 1) x 8 KB
 #pragma unroll
-                for (int i = 0; i < 5; ++i)
+                for (int i = 0; i < 2 * NB + 1; ++i)
                     glds16(reinterpret_cast<const bf16x8*>(p.wt.proj_w) + (i * 8 + wave) * 64 + lane, wbuf + (buf ^ 1) * LR_PHASE + (i * 8 + wave) * 64);
             }
 
@@ -302,11 +307,11 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
         sta[cg] = sacc;
     }
 
-    // ---- LR-side projections (bf16x3): proj image = A [t][kidx 4][part][lane] | B [t][ks 4][part][lane] | C [ks 4][part][lane],
+    // ---- LR-side projections (bf16x3): proj image = A [t < NB][kidx 4][part][lane] | B [t < NB][ks 4][part][lane] | C [ks 4][part][lane],
     // now in LDS buffer 0 (phase 9 ran from buffer 1)
     const bf16x8* pa = wbuf + lane;
-    const bf16x8* pb = pa + 2 * 4 * 2 * 64;
-    const bf16x8* pc = pb + 2 * 4 * 2 * 64;
+    const bf16x8* pb = pa + NB * 4 * 2 * 64;
+    const bf16x8* pc = pb + NB * 4 * 2 * 64;
     f32x4 xc[8];                                      // the centre pixel's x: B operand of the Wb / C projections
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -314,9 +319,13 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
         xc[2 * ks] = g[0];
         xc[2 * ks + 1] = g[1];
     }
-    f32x16 accA[2], accB[2], accC;
+    f32x16 accA[NB], accB[NB], accC;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { accA[0][r] = 0.f; accA[1][r] = 0.f; accB[0][r] = 0.f; accB[1][r] = 0.f; accC[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int t = 0; t < NB; ++t) { accA[t][r] = 0.f; accB[t][r] = 0.f; }
+        accC[r] = 0.f;
+    }
 #pragma unroll
     for (int cg = 0; cg < 2; ++cg)
 #pragma unroll
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
             split8v(lo4, hi4, bh, bl);
             const int kidx = cg * 2 + s;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NB; ++t)
                 accA[t] = mma3(pa[((t * 4 + kidx) * 2 + 0) * 64], pa[((t * 4 + kidx) * 2 + 1) * 64], bh, bl, accA[t]);
         }
 #pragma unroll
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
         bf16x8 xh, xl;
         split8v(xc[2 * ks], xc[2 * ks + 1], xh, xl);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NB; ++t)
             accB[t] = mma3(pb[((t * 4 + ks) * 2 + 0) * 64], pb[((t * 4 + ks) * 2 + 1) * 64], xh, xl, accB[t]);
         accC = mma3(pc[(ks * 2 + 0) * 64], pc[(ks * 2 + 1) * 64], xh, xl, accC);
     }
@@ -354,34 +363,48 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
     }
     if (!valid) return;
     float* recf = p.lrcat + ((long long)gy * p.w + gx) * REC;
-    f32x4* rec = reinterpret_cast<f32x4*>(recf + half * 64);
+    f32x4* rec = reinterpret_cast<f32x4*>(recf + half * 32 * NB);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NB; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 a = {accA[t][4 * g], accA[t][4 * g + 1], accA[t][4 * g + 2], accA[t][4 * g + 3]};
             f32x4 b = {accB[t][4 * g], accB[t][4 * g + 1], accB[t][4 * g + 2], accB[t][4 * g + 3]};
             rec[t * 4 + g] = a;
-            rec[8 + t * 4 + g] = b;
+            rec[4 * NB + t * 4 + g] = b;
         }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 c = {accC[4 * g], accC[4 * g + 1], accC[4 * g + 2], accC[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(recf + 128 + 8 * g + 4 * half) = c;     // rows 8g + 4 half + {0..3} = C-stack channels
+        *reinterpret_cast<f32x4*>(recf + 64 * NB + 8 * g + 4 * half) = c;     // rows 8g + 4 half + {0..3} = C-stack channels
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// HR stage.  One wave = 32 consecutive HR pixels of one output row x all 64 channels; two lanes
-// (half 0 / half 1) per pixel, each owning 32 of the 64 output channels in MFMA accumulator
-// order.  grid_sample (zeros padding, align_corners=True) semantics of savsr_arch.py:262-295.
+// HR stage.  One wave = 32 consecutive HR pixels of one output row x all 32 NB output channels; two lanes
+// (half 0 / half 1) per pixel, each owning 16 NB of them in MFMA accumulator order.
+// grid_sample (zeros padding, align_corners=True) semantics of savsr_arch.py:262-295.
 //
-// A workgroup (HR_WAVES waves) owns an HR tile of TY rows x 32*TXW columns and first stages the LRcat
-// records its taps can touch (tile footprint + the offset range of the phase table) into LDS
-// with a 656-B record pitch (conflict-free b128 reads).  A wave whose 8 taps all fall inside the
-// staged window gathers from LDS (256 B/clk/CU); any other wave -- and every wave when the
-// caller passes lrh == 0 -- gathers the same records from global memory, so correctness never
-// depends on the window the caller chose.
+// NB = 2 is STAUpsample.forward itself: out = [64] planes (savsr_satu_hr_upsample).
+// NB = 1 is the form the network runs (savsr_satu_hr_tail): every matrix of the stage -- fusion (:374), the expert
+// expand (:358) and with them the LR-side projections -- is pre-multiplied by the 3x3 tail conv's weights
+// (savsr_arch.py:738) regrouped as Wt27[p = 3 tap + o][c]: the tail conv is linear and the bilinear gather commutes
+// with a channel contraction, so
+//     P[p] = Wt27 (fusion output) = G(Wt27 Wa sta, soff) + G(Wt27 Wb x, off) + sum_n r_n (Wt27 Wb E_n)(sum_m r_m C_m G(x, off)) + Wt27 b
+// needs 27 (of 32) output rows instead of 64, gathers 96-float records instead of 160-float ones, and the
+// [64][H][W] feature map (236 MB at 720x1280, written here and re-read by the tail) never exists: the stage writes
+// the 27 planes P, and tail_gather_kernel (tail.hip) adds the nine shifted taps per output channel.
+//
+// A workgroup (HR_WAVES waves) owns an HR tile of TY rows x 32*TXW columns and first stages into LDS
+//   * the LRcat records its taps can touch (tile footprint + the offset range of the phase table), with a record
+//     pitch of REC + 4 floats (conflict-free b128 reads), one LDS-DMA per record;
+//   * the phase-table entries of ITS rows x columns ([TY][32 TXW][8], offsets normalised once here), so the tile
+//     loop never looks anything up in global memory, whatever the size of the table (4 entries at x2, 24 360 at
+//     x3.9 for 180x320: the product table is indexed by (idx_h[Y], idx_w[X]) only during this staging);
+//   * gyn of its rows, gxn of its columns, the expert-MFMA A operands and the bias.
+// A wave whose 8 taps all fall inside the staged window gathers from LDS (256 B/clk/CU); any other wave -- and every
+// wave when the caller passes lrh == 0 -- gathers the same records from global memory, so correctness never depends
+// on the window the caller chose.
 // ------------------------------------------------------------------------------------------
 struct HrParams {
     savsr_satu_weights wt;
@@ -398,13 +421,14 @@ struct HrParams {
     long long out_plane;         // floats between output channel planes (>= H*W)
     int ty, txw, lrh, lrw;       // HR tile rows, 32-px column tiles per workgroup, staged LR window
     float omin_x, omin_y;        // lower bound of the sampling offsets (window origin)
-    int n_table;                 // phase-table entries (n_uh * n_uw); <= HR_TABLE_LDS entries are kept in LDS
+    float step_x, step_y;        // LR pixels per HR pixel (1 / scale), for the window origin only
 };
 
-constexpr int HR_LDS_REC = 164;  // floats per staged record (160 used)
-constexpr int HR_TABLE_LDS = 256; // phase-table entries cached in LDS (x4: 16; x3.9: 1521 stays in global/L1)
 constexpr int HR_MAX_ROWS = 64;
-constexpr int HR_CONST_FLOATS = 2 * 2 * 2 * 64 * 4 + 64 + HR_TABLE_LDS * SAVSR_SATU_TABLE + 2 * HR_MAX_ROWS;   // wbe image | fusion_b | table | row idx, gyn
+__host__ __device__ constexpr int hr_lds_rec(int nb) { return rec_floats(nb) + 4; }       // floats per staged record
+__host__ __device__ constexpr int hr_wimg_floats(int nb) { return nb * 2 * 2 * 64 * 4; }  // (Wb E) image [t][ks][part][lane][8 bf16]
+// floats of LDS behind the window: image | bias [half][16 NB] (padded to 64) | table [ty][32 txw][8] | gyn [64] | gxn [32 txw] | idx_h [64] | idx_w [32 txw]
+__host__ __device__ inline int hr_const_floats(int nb, int ty, int txw) { return hr_wimg_floats(nb) + 64 + ty * 32 * txw * 8 + 2 * (HR_MAX_ROWS + 32 * txw); }
 
 struct Taps {
     int ty[4], tx[4];  // LR coordinates of the 4 taps (nw, ne, sw, se), clamped into the image
@@ -447,12 +471,13 @@ __device__ __forceinline__ void fma_quad(f32x16& acc, int g, float w, const f32x
     acc[4 * g] = a01[0]; acc[4 * g + 1] = a01[1]; acc[4 * g + 2] = a23[0]; acc[4 * g + 3] = a23[1];
 }
 
-template <bool FROM_LDS>
+template <bool FROM_LDS, int NB>
 __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int ly0, int lx0, const Taps& to, const Taps& ts,
                                         const f32x4 rr, int half, int lane, bool valid, unsigned o_off, const float* cst) {
+    constexpr int REC = rec_floats(NB), LREC = hr_lds_rec(NB);
     auto rec_of = [&](int ty, int tx) -> const f32x4* {
         // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): window coordinates are tiny
-        if (FROM_LDS) return reinterpret_cast<const f32x4*>(lds + __mul24(__mul24(ty - ly0, p.lrw) + (tx - lx0), HR_LDS_REC));
+        if (FROM_LDS) return reinterpret_cast<const f32x4*>(lds + __mul24(__mul24(ty - ly0, p.lrw) + (tx - lx0), LREC));
         return reinterpret_cast<const f32x4*>(p.lrcat + ((long long)ty * p.w + tx) * REC);
     };
     const f32x4* ro[4] = {rec_of(to.ty[0], to.tx[0]), rec_of(to.ty[1], to.tx[1]), rec_of(to.ty[2], to.tx[2]), rec_of(to.ty[3], to.tx[3])};
@@ -469,7 +494,7 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
         const float wk = to.wgt[k];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const f32x4 v = ro[k][32 + 2 * m + half];
+            const f32x4 v = ro[k][16 * NB + 2 * m + half];
             const float wr = wk * rr[m];
             const f32x2 w2 = {wr, wr}, v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
             t01 = __builtin_elementwise_fma(w2, v01, t01);
@@ -496,15 +521,15 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
         split8v(v0, v1, bh[ks], bl[ks]);
     }
     const bf16x8* wimg = reinterpret_cast<const bf16x8*>(cst) + lane;               // LDS copy of [t][ks][part][lane]
-    const f32x4* fb4 = reinterpret_cast<const f32x4*>(cst + 2 * 2 * 2 * 64 * 4 + half * 32);   // LDS copy of fusion_b, packed [half][q]
+    const f32x4* fb4 = reinterpret_cast<const f32x4*>(cst + hr_wimg_floats(NB) + half * 16 * NB);   // LDS copy of the bias, packed [half][q]
     const long long HW = p.out_plane;
-    // The 32 plane bases of a tile's stores are rebuilt from this pointer with scalar adds for every tile.  Left
+    // The plane bases of a tile's stores are rebuilt from this pointer with scalar adds for every tile.  Left
     // loop-invariant, hipcc keeps all of them (64 SGPRs) across the tile loop, spills them to VGPR lanes and pays two
     // v_readlane + one 64-bit VALU add per store in a VALU-issue-bound kernel.
     float* outp = p.out;
     asm volatile("" : "+s"(outp));
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NB; ++t) {
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -517,7 +542,7 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
             const float wk = to.wgt[k];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = ro[k][16 * half + 8 + 4 * t + g];
+                const f32x4 v = ro[k][8 * NB * half + 4 * NB + 4 * t + g];
                 fma_quad(acc, g, wk, v);
             }
         }
@@ -531,47 +556,75 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
             const float wk = ts.wgt[k];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = rs[k][16 * half + 4 * t + g];
+                const f32x4 v = rs[k][8 * NB * half + 4 * t + g];
                 fma_quad(acc, g, wk, v);
             }
         }
+        // stores: uniform plane base (scalar arithmetic) + one per-lane 32-bit byte offset, no 64-bit VALU add per store.
+        // NB == 1: rows 27 .. 31 of the block are padding (27 = 9 taps x 3 colours): registers 0 .. 11 hold live rows in both
+        // lane halves (rows r', r' + 4), registers 12 .. 14 only in half 0 (rows 24, 25, 26), register 15 in neither.
+        constexpr int R_BOTH = NB == 1 ? 12 : 16, R_LOW = NB == 1 ? 15 : 16;
         if (valid) {
             unsigned oo = o_off;
             asm volatile("" : "+v"(oo));       // the 32 -> 64-bit extension must sit in THIS block for the (scalar base, 32-bit lane offset) store form to be selected
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {     // uniform plane base (scalar arithmetic) + one per-lane 32-bit byte offset: no 64-bit VALU add per store
+            for (int r = 0; r < R_BOTH; ++r) {
                 float* pl = outp + (long long)(32 * t + acc_row(r, 0)) * HW;
                 asm volatile("" : "+s"(pl));     // (opaque, or hipcc re-associates to (outp + lane offset) + plane: a 64-bit VALU add per store)
                 *(__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)pl + oo) = acc[r];
+            }
+            if (R_LOW > R_BOTH && half == 0) {
+#pragma unroll
+                for (int r = R_BOTH; r < R_LOW; ++r) {
+                    float* pl = outp + (long long)(32 * t + acc_row(r, 0)) * HW;
+                    asm volatile("" : "+s"(pl));
+                    *(__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)pl + oo) = acc[r];
+                }
             }
         }
     }
 }
 
-constexpr int HR_WAVES = 4;       // waves per workgroup (the kernel needs ~250 VGPRs: 2 waves per SIMD; at 128 it spills 516 B and runs 3.6x slower)
+#ifndef HR_OCC_TAIL
+#define HR_OCC_TAIL 3             // resident workgroups per CU the tail-projected kernel is compiled for (146 VGPRs: 3 waves per SIMD fit 168)
+#endif
+constexpr int HR_WAVES = 4;       // waves per workgroup (the kernel needs ~180-250 VGPRs: 2 waves per SIMD; at 128 it spills and runs 3.6x slower)
 // DIAG = the instrumented build (section stamps, no-store experiment); the product launch uses DIAG = false: kept as a
 // run-time switch the stamp accumulators cost ~30 vector instructions per tile in a VALU-issue-bound kernel.
-template <bool DIAG>
-__global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParams p) {
+template <bool DIAG, int NB>
+__global__ __launch_bounds__(64 * HR_WAVES, NB == 1 ? HR_OCC_TAIL : 2) void satu_hr_kernel(const HrParams p) {
+    constexpr int REC = rec_floats(NB), LREC = hr_lds_rec(NB);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int X0 = blockIdx.x * 32 * p.txw, Y0 = blockIdx.y * p.ty;
     const long long t_entry = DIAG ? SATU_T() : 0;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);      // tile walk and row / column tests as scalar code
-    // per-lane column constants of the first column tile (the only one when txw == 1); issued first, under the staging
-    const int Xc0 = (X0 + px < p.W) ? X0 + px : p.W - 1;
-    int iw0 = p.idx_w[Xc0];
-    float gxn0 = p.gxn[Xc0];
+    const int ncol = 32 * p.txw;
 
-    // ---- stage the LRcat window of this tile, the expert-MFMA A operands, the bias and the phase table -------
-    float* cst = lds + p.lrh * p.lrw * HR_LDS_REC;
+    // ---- stage the LRcat window of this tile, the expert-MFMA A operands, the bias and the tile's table entries -------
+    float* cst = lds + p.lrh * p.lrw * LREC;
+    float* tab = cst + hr_wimg_floats(NB) + 64;                   // [ty][ncol][8]
+    float* rowg = tab + p.ty * ncol * 8;                          // [HR_MAX_ROWS] gyn of the tile's rows
+    float* colg = rowg + HR_MAX_ROWS;                             // [ncol] gxn of the tile's columns
+    int* rowi = reinterpret_cast<int*>(colg + ncol);              // [HR_MAX_ROWS] table row of the tile's rows
+    int* coli = rowi + HR_MAX_ROWS;                               // [ncol] table column of the tile's columns
+    // (1) the per-row / per-column lookups: issued first, they land under the window's DMA issue
+    const int Yr = Y0 + tid < p.H ? Y0 + tid : p.H - 1;           // (threads >= ty load a valid address and drop the value)
+    const int Xr0 = X0 + tid < p.W ? X0 + tid : p.W - 1;
+    const int ih_v = p.idx_h[Yr];
+    const float gy_v = p.gyn[Yr];
+    const int iw_v = p.idx_w[Xr0];
+    const float gx_v = p.gxn[Xr0];
+    // (2) the window.  Its origin is the tile's base sampling coordinate + the lower bound of the offsets, evaluated from
+    // kernel arguments only (no load in front of the DMA issue); being a plan, it needs no bit-exactness (a wave whose
+    // taps fall outside gathers from global memory).
     int ly0 = 0, lx0 = 0;
     if (p.lrh > 0) {
-        const float by = ((p.gyn[Y0] + 1.f) / 2.f) * (float)(p.h - 1) + p.omin_y - 0.01f;
-        const float bx = ((p.gxn[X0 < p.W ? X0 : p.W - 1] + 1.f) / 2.f) * (float)(p.w - 1) + p.omin_x - 0.01f;
+        const float by = ((float)Y0 + 0.5f) * p.step_y - 0.5f + p.omin_y - 0.01f;
+        const float bx = ((float)X0 + 0.5f) * p.step_x - 0.5f + p.omin_x - 0.01f;
         ly0 = (int)floorf(fminf(fmaxf(by, 0.f), (float)(p.h - 1)));
         lx0 = (int)floorf(fminf(fmaxf(bx, 0.f), (float)(p.w - 1)));
-        // one LDS-DMA per record: lanes 0..39 move its 640 B straight into the 656-B-pitch slot (no registers, no
+        // one LDS-DMA per record: lanes 0 .. REC/4-1 move it straight into its padded slot (no registers, no
         // ds_write, every record of the wave in flight at once; the register-staged loop this replaces was a third
         // of the kernel).  Records outside the image are never read (taps are clamped into it) and stay unwritten.
         const int nrec = p.lrh * p.lrw;
@@ -580,33 +633,52 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
             const int gy = ly0 + ry, gx = lx0 + rx;
             if (gy < p.h && gx < p.w && lane < REC / 4) {
                 const float* src = p.lrcat + ((long long)gy * p.w + gx) * REC + 4 * lane;
-                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds + r * HR_LDS_REC));
+                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds + r * LREC));
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
             }
         }
     }
+    if (tid < p.ty) { rowi[tid] = ih_v; rowg[tid] = gy_v; }
+    if (tid < ncol) { coli[tid] = iw_v; colg[tid] = gx_v; }
+    for (int e = tid + 64 * HR_WAVES; e < ncol; e += 64 * HR_WAVES) {           // (tiles wider than 256 columns)
+        const int Xc = X0 + e < p.W ? X0 + e : p.W - 1;
+        coli[e] = p.idx_w[Xc];
+        colg[e] = p.gxn[Xc];
+    }
     {
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wt.wbe_w);
-        for (int e = tid; e < 2 * 2 * 2 * 64; e += 64 * HR_WAVES) reinterpret_cast<f32x4*>(cst)[e] = wsrc[e];
-        if (tid < 16) reinterpret_cast<f32x4*>(cst + 2 * 2 * 2 * 64 * 4)[tid] = reinterpret_cast<const f32x4*>(p.wt.fusion_b)[tid];
-        if (p.n_table <= HR_TABLE_LDS)
-            for (int e = tid; e < p.n_table * 2; e += 64 * HR_WAVES) {
-                f32x4 v = reinterpret_cast<const f32x4*>(p.table)[e];
-                if (e & 1) {               // the offset quad: normalise once here, not per 32-pixel tile (4 fp32 divisions each)
-                    v[0] = (v[0] * 2.f) / (float)(p.w - 1); v[1] = (v[1] * 2.f) / (float)(p.h - 1);
-                    v[2] = (v[2] * 2.f) / (float)(p.w - 1); v[3] = (v[3] * 2.f) / (float)(p.h - 1);
-                }
-                reinterpret_cast<f32x4*>(cst + 2 * 2 * 2 * 64 * 4 + 64)[e] = v;
-            }
+        for (int e = tid; e < hr_wimg_floats(NB) / 4; e += 64 * HR_WAVES) reinterpret_cast<f32x4*>(cst)[e] = wsrc[e];
+        if (tid < 8 * NB) reinterpret_cast<f32x4*>(cst + hr_wimg_floats(NB))[tid] = reinterpret_cast<const f32x4*>(p.wt.fusion_b)[tid];
     }
-    const float* tab = (p.n_table <= HR_TABLE_LDS) ? cst + 2 * 2 * 2 * 64 * 4 + 64 : nullptr;
-    float* rowc = cst + 2 * 2 * 2 * 64 * 4 + 64 + HR_TABLE_LDS * SAVSR_SATU_TABLE;     // [ty] table row index (as int bits) | [ty] gyn
-    if (tid < p.ty) {
-        const int Yc = Y0 + tid < p.H ? Y0 + tid : p.H - 1;
-        rowc[tid] = __int_as_float(p.idx_h[Yc]);
-        rowc[HR_MAX_ROWS + tid] = p.gyn[Yc];
+    __syncthreads();
+    {
+        // (3) the tile's own slice of the phase table: entry (row, col) = table[idx_h[Y]][idx_w[X]]; the offset quad is normalised
+        // here, once per workgroup, as the reference does per pixel ((off * 2) / (size - 1), :285-287).  Four independent
+        // 16-B loads in flight per thread and round.
+        const float fw1 = (float)(p.w - 1), fh1 = (float)(p.h - 1);
+        const int nq = p.ty * ncol * 2;
+        for (int e0 = tid; e0 < nq; e0 += 4 * 64 * HR_WAVES) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 64 * HR_WAVES;
+                const int ec = e < nq ? e : tid;                  // (clamped: loaded, not stored)
+                const int q = ec & 1, pe = ec >> 1;
+                const int trow = pe / ncol, col = pe - trow * ncol;
+                v[u] = *reinterpret_cast<const f32x4*>(p.table + ((long long)rowi[trow] * p.n_uw + coli[col]) * SAVSR_SATU_TABLE + 4 * q);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 64 * HR_WAVES;
+                if (e < nq) {
+                    f32x4 t = v[u];
+                    if (e & 1) { t[0] = (t[0] * 2.f) / fw1; t[1] = (t[1] * 2.f) / fh1; t[2] = (t[2] * 2.f) / fw1; t[3] = (t[3] * 2.f) / fh1; }
+                    *reinterpret_cast<f32x4*>(tab + (e >> 1) * 8 + 4 * (e & 1)) = t;
+                }
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the window DMA (not counted by the compiler)
     __syncthreads();
@@ -620,45 +692,23 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
     tacc[4] = t_prev - t_entry;                                      // staging of the LDS window + constants
 #define HR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
     const int ntile = p.ty * p.txw;
-    // No load may be pending, as far as hipcc can tell, when the tile loop is entered or continued: its waits count only
+    // No global load may be pending, as far as hipcc can tell, when the tile loop is entered or continued: its waits count only
     // what it can see on every path, so one conditional load in the loop (or one issued in front of it) turns into
-    // s_waitcnt vmcnt(0..1) at the top of EVERY tile -- behind the previous tile's 64 output stores, i.e. a full write
-    // round trip per tile.  The column constants are therefore consumed here (they landed under the staging), and the
-    // loads of the other column tiles are waited for inside their branch.
-    asm volatile("" : "+v"(iw0), "+v"(gxn0));
+    // s_waitcnt vmcnt(0..1) at the top of EVERY tile -- behind the previous tile's output stores, i.e. a full write
+    // round trip per tile.  Everything a tile looks up is therefore in LDS.
     for (int T = wave_s; T < ntile; T += HR_WAVES) {
         const int trow = p.txw == 1 ? T : T / p.txw;                // (a run-time integer division is ~14 vector instructions)
+        const int tcol = T - trow * p.txw;
         const int Y = Y0 + trow;
-        const int Xb = X0 + (T - trow * p.txw) * 32;
+        const int Xb = X0 + tcol * 32;
         if (Y >= p.H || Xb >= p.W) continue;                      // wave-uniform
         const int X = Xb + px;
         const bool valid = X < p.W && !dbg_nostore;
-        const int Xc = X < p.W ? X : p.W - 1;
-        const bool col0 = Xb == X0;                                   // scalar
-        int iw = iw0;
-        float gxn = gxn0;
-        if (!col0) {
-            iw = p.idx_w[Xc];
-            gxn = p.gxn[Xc];
-            asm volatile("" : "+v"(iw), "+v"(gxn));                   // (waited for here, see above)
-        }
-        // Two explicit address spaces: a pointer select between the LDS copy and the global table compiles to FLAT loads,
-        // which count on vmcnt AND lgkmcnt and after which hipcc forces every wait of the tile to zero.
-        f32x4 rr, oo;
-        if (tab) {                                                    // (wave-uniform) LDS copy: offsets already normalised
-            const float* te = tab + (__float_as_int(rowc[trow]) * p.n_uw + iw) * SAVSR_SATU_TABLE;
-            rr = *reinterpret_cast<const f32x4*>(te);
-            oo = *reinterpret_cast<const f32x4*>(te + 4);
-        } else {                                                      // global table: raw offsets
-            typedef __attribute__((address_space(1))) const f32x4 gf32x4;
-            const long long ent = ((long long)__float_as_int(rowc[trow]) * p.n_uw + iw) * SAVSR_SATU_TABLE;
-            rr = *(gf32x4*)(p.table + ent);
-            oo = *(gf32x4*)(p.table + ent + 4);
-            asm volatile("" : "+v"(rr), "+v"(oo));                    // both waited for inside the branch (see above the loop)
-            oo[0] = (oo[0] * 2.f) / (float)(p.w - 1); oo[1] = (oo[1] * 2.f) / (float)(p.h - 1);
-            oo[2] = (oo[2] * 2.f) / (float)(p.w - 1); oo[3] = (oo[3] * 2.f) / (float)(p.h - 1);
-        }
-        const float gyn = rowc[HR_MAX_ROWS + trow];
+        const float* te = tab + (trow * ncol + tcol * 32 + px) * 8;
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
+        const f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
+        const float gxn = colg[tcol * 32 + px];
+        const float gyn = rowg[trow];
         if (stamps_on) { asm volatile("" :: "v"(rr[0]), "v"(oo[0])); }
         HR_MARK(0);                                                  // table lookup
         const Taps to = make_taps(gxn, gyn, oo[0], oo[1], p.h, p.w);
@@ -674,9 +724,9 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
         }
         // byte offset of this lane's pixel inside channel plane acc_row(r, 0); the half's +4 channels are folded in
         const unsigned o_off = 4u * (unsigned)(Y * p.W + X) + (half ? 16u * (unsigned)p.out_plane : 0u);
-        if (__all(inside)) hr_tile<true>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
+        if (__all(inside)) hr_tile<true, NB>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
         else {
-            hr_tile<false>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
+            hr_tile<false, NB>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
             __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the fallback's gathers are not left pending either (see above the loop)
         }
         HR_MARK(2);                                                  // gathers + MFMA + store issue
@@ -698,7 +748,7 @@ __global__ __launch_bounds__(64 * HR_WAVES, 2) void satu_hr_kernel(const HrParam
 
 using namespace savsr;
 
-static int g_satu_diag_host = 0;      // != 0: launch the instrumented HR kernel
+static int g_satu_diag_host = 0;      // != 0: launch the instrumented kernels (tail-projected form only)
 
 extern "C" int savsr_debug_satu_stamps(int enable) {
     g_satu_diag_host = enable;
@@ -706,11 +756,13 @@ extern "C" int savsr_debug_satu_stamps(int enable) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
-// Diagnostics: resident workgroups per CU the runtime predicts for the HR / LR kernels with `lds_bytes` of dynamic LDS.
+extern "C" int savsr_satu_hr_occupancy_target(int tail_form) { return tail_form ? HR_OCC_TAIL : 2; }
+
+// Diagnostics: resident workgroups per CU the runtime predicts for the HR / LR kernels (tail-projected form) with `lds_bytes` of dynamic LDS.
 extern "C" int savsr_debug_satu_occupancy(int which, int lds_bytes) {
     int n = -1;
-    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel<false>, 64 * HR_WAVES, (size_t)lds_bytes)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_kernel<false>, 512, (size_t)lds_bytes);
+    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel<false, 1>, 64 * HR_WAVES, (size_t)lds_bytes)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_kernel<false, 1>, 512, (size_t)lds_bytes);
     return e == hipSuccess ? n : -(int)e;
 }
 
@@ -735,8 +787,9 @@ extern "C" int savsr_satu_phase_table(const savsr_satu_weights* wt, const float*
     return check_launch("satu_phase_table_kernel");
 }
 
-extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const float* st, int32_t pix, int32_t row_px, int h,
-                                   int w, float* lrcat, void* stream) {
+template <int NB>
+static int lr_stage(const savsr_satu_weights* wt, const float* x, const float* st, int32_t pix, int32_t row_px, int h, int w, float* lrcat,
+                    void* stream) {
     if (!satu_weights_ok(wt) || !x || !st || !lrcat) return fail_arg("satu_lr_stage: null pointer");
     if (h < 1 || w < 1 || row_px < w || pix < 64 || (pix & 3)) return fail_arg("satu_lr_stage: shape/strides");
     if ((reinterpret_cast<uintptr_t>(lrcat) | reinterpret_cast<uintptr_t>(wt->kconv_w) | reinterpret_cast<uintptr_t>(wt->kconv_b) |
@@ -748,53 +801,76 @@ extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x,
     p.wt = *wt; p.x = x; p.st = st; p.pix = pix; p.row_px = row_px; p.h = h; p.w = w; p.lrcat = lrcat;
     constexpr size_t lds = LR_NPX * LR_XS * sizeof(float) + 2 * LR_PHASE * 16 + 25 * 64 * sizeof(float);     // 150.5 KB
     static_assert(lds <= 160 * 1024, "LR stage LDS budget");
-    static bool attr_done = false;      // benign race: idempotent attribute set
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_lr_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_lr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("satu_lr_stage: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
-    }
+    const bool diag = NB == 1 && g_satu_diag_host;
+    const void* fn = diag ? reinterpret_cast<const void*>(&satu_lr_kernel<true, 1>) : reinterpret_cast<const void*>(&satu_lr_kernel<false, NB>);
+    if (int rc = ensure_dynamic_lds(fn, (int)lds, "satu_lr_stage")) return rc;
     dim3 grid((w + LR_TW - 1) / LR_TW, (h + LR_TH - 1) / LR_TH);
-    if (g_satu_diag_host) hipLaunchKernelGGL(satu_lr_kernel<true>, grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL(satu_lr_kernel<false>, grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
+    if (diag) hipLaunchKernelGGL((satu_lr_kernel<true, 1>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL((satu_lr_kernel<false, NB>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_lr_kernel");
 }
 
-extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uw,
-                                      const int32_t* idx_h, const int32_t* idx_w, const float* gyn, const float* gxn, int H, int W,
-                                      const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream) {
-    if (!satu_weights_ok(wt) || !lrcat || !table || !idx_h || !idx_w || !gyn || !gxn || !out) return fail_arg("satu_hr_upsample: null pointer");
-    if (h < 2 || w < 2 || H < 1 || W < 1 || n_uw < 1 || out_plane < (int64_t)H * W) return fail_arg("satu_hr_upsample: shape (h, w >= 2, out_plane >= H*W required)");
-    if (out_plane * 64 * 4 >= ((int64_t)1 << 32)) return fail_arg("satu_hr_upsample: output of 4 GiB or more is not supported (32-bit store offsets)");
+extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const float* st, int32_t pix, int32_t row_px, int h,
+                                   int w, float* lrcat, void* stream) {
+    return lr_stage<2>(wt, x, st, pix, row_px, h, w, lrcat, stream);
+}
+
+extern "C" int savsr_satu_lr_stage_tail(const savsr_satu_weights* wt, const float* x, const float* st, int32_t pix, int32_t row_px, int h,
+                                        int w, float* lrcat, void* stream) {
+    return lr_stage<1>(wt, x, st, pix, row_px, h, w, lrcat, stream);
+}
+
+extern "C" int64_t savsr_satu_hr_lds_bytes(int tail_form, int tile_rows, int tile_cols32, int lr_rows, int lr_cols) {
+    if (tile_rows < 1 || tile_rows > HR_MAX_ROWS || tile_cols32 < 1 || lr_rows < 0 || lr_cols < 0) return -1;
+    const int nb = tail_form ? 1 : 2;
+    return ((int64_t)lr_rows * lr_cols * hr_lds_rec(nb) + hr_const_floats(nb, tile_rows, tile_cols32)) * (int64_t)sizeof(float);
+}
+
+template <int NB>
+static int hr_stage(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uw, const int32_t* idx_h,
+                    const int32_t* idx_w, const float* gyn, const float* gxn, int H, int W, const savsr_satu_tiling* tiling, float* out,
+                    int64_t out_plane, void* stream) {
+    if (!satu_weights_ok(wt) || !lrcat || !table || !idx_h || !idx_w || !gyn || !gxn || !out) return fail_arg("satu_hr: null pointer");
+    if (h < 2 || w < 2 || H < 1 || W < 1 || n_uw < 1 || out_plane < (int64_t)H * W) return fail_arg("satu_hr: shape (h, w >= 2, out_plane >= H*W required)");
+    if (out_plane * 32 * NB * 4 >= ((int64_t)1 << 32)) return fail_arg("satu_hr: output of 4 GiB or more is not supported (32-bit store offsets)");
     if ((reinterpret_cast<uintptr_t>(lrcat) | reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(wt->fusion_b) |
          reinterpret_cast<uintptr_t>(wt->wbe_w)) & 15) {
-        set_error("satu_hr_upsample: lrcat / table / fusion_b / wbe_w must be 16-byte aligned");
+        set_error("satu_hr: lrcat / table / fusion_b / wbe_w must be 16-byte aligned");
         return SAVSR_E_ALIGN;
     }
     HrParams p;
     p.wt = *wt; p.lrcat = lrcat; p.h = h; p.w = w; p.table = table; p.n_uw = n_uw; p.idx_h = idx_h; p.idx_w = idx_w;
     p.gyn = gyn; p.gxn = gxn; p.H = H; p.W = W; p.out = out; p.out_plane = out_plane;
-    p.ty = 8; p.txw = 1; p.lrh = 0; p.lrw = 0; p.omin_x = 0.f; p.omin_y = 0.f; p.n_table = 1 << 30;      // default: no staging, gathers from global
+    p.ty = 8; p.txw = 1; p.lrh = 0; p.lrw = 0; p.omin_x = 0.f; p.omin_y = 0.f;      // default: no window staging, gathers from global
+    p.step_x = (float)w / (float)W; p.step_y = (float)h / (float)H;
     if (tiling) {
-        if (tiling->tile_rows < 1 || tiling->tile_rows > HR_MAX_ROWS || tiling->tile_cols32 < 1 || tiling->lr_rows < 0 || tiling->lr_cols < 0)
-            return fail_arg("satu_hr_upsample: tiling");
+        if (tiling->tile_rows < 1 || tiling->tile_rows > HR_MAX_ROWS || tiling->tile_cols32 < 1 || tiling->tile_cols32 > 8 || tiling->lr_rows < 0 ||
+            tiling->lr_cols < 0)
+            return fail_arg("satu_hr: tiling");
         p.ty = tiling->tile_rows; p.txw = tiling->tile_cols32; p.lrh = tiling->lr_rows; p.lrw = tiling->lr_cols;
         p.omin_x = tiling->off_min_x; p.omin_y = tiling->off_min_y;
-        p.n_table = tiling->table_entries > 0 ? tiling->table_entries : (1 << 30);
+        if (tiling->step_x > 0.f && tiling->step_y > 0.f) { p.step_x = tiling->step_x; p.step_y = tiling->step_y; }
         if (p.lrh == 0 || p.lrw == 0) { p.lrh = 0; p.lrw = 0; }
     }
-    const size_t lds = ((size_t)p.lrh * p.lrw * HR_LDS_REC + HR_CONST_FLOATS) * sizeof(float);
-    if (lds > 160 * 1024) return fail_arg("satu_hr_upsample: staged window exceeds 160 KiB of LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_hr_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&satu_hr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { set_error("satu_hr_upsample: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
-    }
+    const size_t lds = ((size_t)p.lrh * p.lrw * hr_lds_rec(NB) + hr_const_floats(NB, p.ty, p.txw)) * sizeof(float);
+    if (lds > 160 * 1024) return fail_arg("satu_hr: staged window + tile tables exceed 160 KiB of LDS");
+    const bool diag = NB == 1 && g_satu_diag_host;
+    const void* fn = diag ? reinterpret_cast<const void*>(&satu_hr_kernel<true, 1>) : reinterpret_cast<const void*>(&satu_hr_kernel<false, NB>);
+    if (int rc = ensure_dynamic_lds(fn, 160 * 1024, "satu_hr")) return rc;
     dim3 grid((W + 32 * p.txw - 1) / (32 * p.txw), (H + p.ty - 1) / p.ty);
-    if (g_satu_diag_host) hipLaunchKernelGGL(satu_hr_kernel<true>, grid, dim3(64 * HR_WAVES), lds, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL(satu_hr_kernel<false>, grid, dim3(64 * HR_WAVES), lds, static_cast<hipStream_t>(stream), p);
+    if (diag) hipLaunchKernelGGL((satu_hr_kernel<true, 1>), grid, dim3(64 * HR_WAVES), lds, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL((satu_hr_kernel<false, NB>), grid, dim3(64 * HR_WAVES), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_hr_kernel");
+}
+
+extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uw,
+                                      const int32_t* idx_h, const int32_t* idx_w, const float* gyn, const float* gxn, int H, int W,
+                                      const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream) {
+    return hr_stage<2>(wt, lrcat, h, w, table, n_uw, idx_h, idx_w, gyn, gxn, H, W, tiling, out, out_plane, stream);
+}
+
+extern "C" int savsr_satu_hr_tail(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uw,
+                                  const int32_t* idx_h, const int32_t* idx_w, const float* gyn, const float* gxn, int H, int W,
+                                  const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream) {
+    return hr_stage<1>(wt, lrcat, h, w, table, n_uw, idx_h, idx_w, gyn, gxn, H, W, tiling, out, out_plane, stream);
 }

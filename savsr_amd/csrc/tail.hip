@@ -131,6 +131,81 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ fea
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Tail of the tail-projected form (see satu.hip, HR stage): the SATU HR stage already applied the 3x3 tail conv's
+// CHANNEL contraction, P[3 tap + o][Y][X] = Wt[o][:][ky][kx] . F[:][Y][X] (tap = 3 ky + kx); what is left of
+// savsr_arch.py:738-739 is the spatial part and the residual:
+//     out[o][Y][X] = tail_b[o] + sum_{ky,kx} P[3 (3 ky + kx) + o][Y + ky - 1][X + kx - 1]  (zero outside)  + bilinear(center)
+// Pure HBM streaming: every element of the 27 planes is read once (99.5 MB at 720x1280 instead of the 236 MB feature map),
+// 11 MB written.  One thread = 4 consecutive pixels of a row (16-B loads; the kx = 0 / 2 planes are read at a +-4-B
+// offset, which global loads allow), rows of 27 independent loads in flight per thread.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <bool VEC>   // VEC: W % 4 == 0 and the plane pitch a multiple of 4 floats -> 16-B accesses; else one pixel per thread
+__global__ __launch_bounds__(256) void tail_gather_kernel(const float* __restrict__ P, long long PP, const float* __restrict__ bias,
+                                                          const float* __restrict__ center, int h, int w, int H, int W, float* __restrict__ out) {
+    constexpr int NPX = VEC ? 4 : 1;
+    const int xq = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int X = xq * NPX;
+    if (X >= W || Y >= H) return;
+    float acc[3][NPX];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) acc[o][i] = 0.f;
+    const bool interior = VEC && X >= 4 && X + 8 <= W;           // every shifted 4-vector of this thread lies inside the row
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = Y + ky - 1;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float* row = P + (long long)(3 * (3 * ky + kx) + o) * PP + (long long)yy * W;
+                if (VEC && (interior || kx == 1)) {
+                    const f32x4u v = *reinterpret_cast<const f32x4u*>(row + X + kx - 1);
+#pragma unroll
+                    for (int i = 0; i < NPX; ++i) acc[o][i] += v[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NPX; ++i) {
+                        const int xx = X + i + kx - 1;
+                        if (xx >= 0 && xx < W) acc[o][i] += row[xx];
+                    }
+                }
+            }
+    }
+    // F.interpolate(x_center, size=(H, W), mode='bilinear', align_corners=False), :739
+    int y0, y1;
+    float ly;
+    bil_src(Y, (float)h / (float)H, h, y0, y1, ly);
+    const long long HW = (long long)H * W;
+    float res[3][NPX];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        int x0, x1;
+        float lx;
+        bil_src(X + i, (float)w / (float)W, w, x0, x1, lx);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float* c = center + (long long)o * h * w;
+            const float top = (1.f - lx) * c[y0 * w + x0] + lx * c[y0 * w + x1];
+            const float bot = (1.f - lx) * c[y1 * w + x0] + lx * c[y1 * w + x1];
+            res[o][i] = (acc[o][i] + bias[o]) + ((1.f - ly) * top + ly * bot);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float* dst = out + (long long)o * HW + (long long)Y * W + X;
+        if (VEC) *reinterpret_cast<f32x4*>(dst) = f32x4{res[o][0], res[o][VEC ? 1 : 0], res[o][VEC ? 2 : 0], res[o][VEC ? 3 : 0]};
+        else dst[0] = res[o][0];
+    }
+}
+
 }  // namespace savsr
 
 using namespace savsr;
@@ -143,4 +218,17 @@ extern "C" int savsr_tail_residual(const float* feat, int64_t feat_plane, const 
     dim3 grid((W + TL_TW - 1) / TL_TW, (H + TL_TH - 1) / TL_TH);
     hipLaunchKernelGGL(tail_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), feat, w, b, center, h, wd, H, W, (long long)feat_plane, out);
     return check_launch("tail_kernel");
+}
+
+
+extern "C" int savsr_tail_gather(const float* p27, int64_t p_plane, const float* b, const float* center, int h, int wd, int H, int W,
+                                 float* out, void* stream) {
+    if (!p27 || !b || !center || !out) return fail_arg("tail_gather: null pointer");
+    if (h < 1 || wd < 1 || H < 1 || W < 1 || p_plane < (int64_t)H * W) return fail_arg("tail_gather: shape");
+    const bool vec = (W & 3) == 0 && (p_plane & 3) == 0 && !((reinterpret_cast<uintptr_t>(p27) | reinterpret_cast<uintptr_t>(out)) & 15);
+    const int npx = vec ? 4 : 1;
+    dim3 grid((W + 64 * npx - 1) / (64 * npx), (H + 3) / 4);
+    if (vec) hipLaunchKernelGGL(tail_gather_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p27, (long long)p_plane, b, center, h, wd, H, W, out);
+    else hipLaunchKernelGGL(tail_gather_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p27, (long long)p_plane, b, center, h, wd, H, W, out);
+    return check_launch("tail_gather_kernel");
 }

@@ -140,11 +140,9 @@ class HipEngine:
         self.osc: Dict[str, dict] = {}      # osconv key -> tensors
         self.se: Dict[str, tuple] = {}
         self._keep: List[torch.Tensor] = []
-        self._bufs: Dict[tuple, torch.Tensor] = {}
-        self._satu_axes: Dict[tuple, dict] = {}
+        self._init_caches()
         self.satu_events: Optional[list] = None     # bench.py: (start, end) HIP events around SATU
         self.use_graphs = os.environ.get("SAVSR_GRAPHS", "1") != "0"
-        self._graphs: Dict[tuple, tuple] = {}
         self.n_streams = max(1, int(os.environ.get("SAVSR_STREAMS", "3")))   # clips of a batch in flight concurrently
         self._siblings: List["HipEngine"] = []
         self._streams: List[torch.cuda.Stream] = []
@@ -273,6 +271,40 @@ class HipEngine:
         self.satu_w = sw
         self.tail_w = self._dev(sd["tail.weight"].reshape(3, 64 * 9))
         self.tail_b = self._dev(sd["tail.bias"])
+        # ---- tail-projected form (include/savsr_hip.h, savsr_satu_*_tail): the 3x3 tail conv's channel contraction
+        # Wt27[p = 3 (3 ky + kx) + o][c] (rows 27..31 zero) multiplied into fusion / expand / the LR projections in float64
+        wt27 = np.zeros((32, c), dtype=np.float64)
+        tw = sd["tail.weight"].to("cpu", torch.float64).numpy()                          # [3 o][64 c][3 ky][3 kx]
+        for ky in range(3):
+            for kx in range(3):
+                for o in range(3):
+                    wt27[3 * (3 * ky + kx) + o] = tw[o, :, ky, kx]
+        ta = (wt27 @ wa.astype(np.float64)).astype(np.float32)                           # [32][64] applies to sta
+        tb = (wt27 @ wb.astype(np.float64)).astype(np.float32)                           # [32][64] applies to x
+        pa1 = np.zeros((1, 4, 64, 8), dtype=np.float32)
+        pb1 = np.zeros((1, 4, 64, 8), dtype=np.float32)
+        for kidx in range(4):
+            cgi, s = kidx // 2, kidx % 2
+            ch = 32 * cgi + 16 * s + 8 * (jj[None, :] >> 2) + 4 * lh[:, None] + (jj[None, :] & 3)
+            pa1[0, kidx] = ta[li[:, None], ch]
+            pb1[0, kidx] = tb[li[:, None], 16 * kidx + 8 * lh[:, None] + jj[None, :]]
+        proj1 = np.concatenate([pa1.reshape(-1), pb1.reshape(-1), pc.reshape(-1)])
+        twbe = np.einsum("pc,ncj->npj", wt27 @ wb.astype(np.float64), expd.astype(np.float64)).astype(np.float32)   # (Wt27 Wb E_n)[p][j]
+        twbe_p = np.zeros((1, 2, 64, 8), dtype=np.float32)
+        for ksi in range(2):
+            twbe_p[0, ksi] = twbe[(2 * ksi + lh)[:, None], li[:, None], jj[None, :]]
+        tfb = (wt27 @ fb.astype(np.float64)).astype(np.float32)
+        tfb_p = np.zeros((2, 16), dtype=np.float32)
+        for hh in range(2):
+            for r in range(16):
+                tfb_p[hh, r] = tfb[acc_row(r, hh)]
+        self.satu_tail_t = dict(proj_w=img(proj1), wbe_w=img(twbe_p), fusion_b=t_(tfb_p))
+        swt = SatuWeights()
+        for k, v in self.satu_t.items():
+            setattr(swt, k, v.data_ptr())
+        for k, v in self.satu_tail_t.items():
+            setattr(swt, k, v.data_ptr())
+        self.satu_w_tail = swt
 
     def _pack_all(self, sd):
         cfg = self.cfg
@@ -331,6 +363,7 @@ class HipEngine:
         e.lib, e.dev, e.cfg, e.nf = self.lib, self.dev, self.cfg, self.nf
         e.pw, e.se, e._keep = self.pw, self.se, self._keep
         e.satu_t, e.satu_w, e.tail_w, e.tail_b, e.gamma, e.n_l2 = self.satu_t, self.satu_w, self.tail_w, self.tail_b, self.gamma, self.n_l2
+        e.satu_tail_t, e.satu_w_tail = self.satu_tail_t, self.satu_w_tail
         e.osc = {}
         for k, ent in self.osc.items():
             c = dict(ent)
@@ -338,19 +371,70 @@ class HipEngine:
                 c[name] = torch.empty_like(ent[name])
             e.osc[k] = c
         e.se_gate = torch.empty_like(self.se_gate)
-        e._bufs, e._satu_axes, e._graphs = {}, {}, {}
+        e._init_caches()
         e.satu_events, e.use_graphs = None, self.use_graphs
         e._siblings, e._streams = [], []
         return e
 
     # ------------------------------------------------------------------ buffers / launch helpers
-    def buf(self, name: str, *shape: int) -> torch.Tensor:
+    # Device memory is cached per LR clip shape (the ~200 named channel-last feature maps) and, inside a shape, per scale
+    # (HR-sized buffers, the captured hipGraphs with their static input / output).  Both levels are small LRU caches: an
+    # arbitrary-scale sweep over many (shape, scale) pairs (BASELINE configs 3 / 5) keeps a bounded working set instead of
+    # pinning every size it has ever seen (the reference frees everything per frame, video_base_model.py:72-74).
+    def _init_caches(self):
+        from collections import OrderedDict
+        self.max_shapes = max(1, int(os.environ.get("SAVSR_CACHE_SHAPES", "4")))
+        self.max_scales = max(1, int(os.environ.get("SAVSR_CACHE_SCALES", "48")))
+        self._ctx: "OrderedDict[tuple, dict]" = OrderedDict()
+        self._axes: "OrderedDict[tuple, dict]" = OrderedDict()
+        self._default_ctx = dict(bufs={}, scales=OrderedDict())      # direct kernel-level calls (tests, tools) outside a forward
+        self._default_sc = dict(bufs={}, graphs=None)
+        self._cur, self._cur_sc = self._default_ctx, self._default_sc
+
+    def _select(self, shape: tuple, scale) -> dict:
+        """Make (clip shape, scale) the current buffer context; evicts the least recently used ones beyond the caps."""
+        skey = tuple(int(v) for v in shape)
+        ctx = self._ctx.get(skey)
+        if ctx is None:
+            from collections import OrderedDict
+            ctx = dict(bufs={}, scales=OrderedDict())
+            self._ctx[skey] = ctx
+            while len(self._ctx) > self.max_shapes:
+                self._ctx.popitem(last=False)
+        else:
+            self._ctx.move_to_end(skey)
+        ckey = (float(scale[0]), float(scale[1]))
+        sc = ctx["scales"].get(ckey)
+        if sc is None:
+            sc = dict(bufs={}, graphs=None)
+            ctx["scales"][ckey] = sc
+            while len(ctx["scales"]) > self.max_scales:
+                ctx["scales"].popitem(last=False)
+        else:
+            ctx["scales"].move_to_end(ckey)
+        self._cur, self._cur_sc = ctx, sc
+        return sc
+
+    def cache_stats(self) -> dict:
+        n = lambda d: sum(t.numel() * t.element_size() for t in d.values())
+        return {"shapes": len(self._ctx), "scales": sum(len(c["scales"]) for c in self._ctx.values()), "axes": len(self._axes),
+                "bytes": sum(n(c["bufs"]) + sum(n(sc["bufs"]) for sc in c["scales"].values()) for c in self._ctx.values())}
+
+    def _get_buf(self, store: dict, name: str, shape: tuple) -> torch.Tensor:
         key = (name,) + tuple(shape)
-        t = self._bufs.get(key)
+        t = store.get(key)
         if t is None:
             t = torch.empty(shape, device=self.dev, dtype=torch.float32)
-            self._bufs[key] = t
+            store[key] = t
         return t
+
+    def buf(self, name: str, *shape: int) -> torch.Tensor:
+        """Named LR-sized buffer of the current clip shape."""
+        return self._get_buf(self._cur["bufs"], name, shape)
+
+    def sbuf(self, name: str, *shape: int) -> torch.Tensor:
+        """Named buffer whose size depends on the scale (HR-sized), owned by the current (shape, scale) context."""
+        return self._get_buf(self._cur_sc["bufs"], name, shape)
 
     @staticmethod
     def _stream() -> int:
@@ -540,7 +624,7 @@ class HipEngine:
     # ------------------------------------------------------------------ SATU
     def satu_axes(self, h: int, w: int, scale):
         key = (h, w, float(scale[0]), float(scale[1]))
-        ent = self._satu_axes.get(key)
+        ent = self._axes.get(key)
         if ent is None:
             H, W = get_hw(h, w, scale)
             ch, _, gyn = satu_axis_tables(H, h, scale[0])
@@ -552,14 +636,22 @@ class HipEngine:
                        ih=up(ih.reshape(-1), np.int32), iw=up(iw.reshape(-1), np.int32), gyn=up(gyn, np.float32), gxn=up(gxn, np.float32),
                        table=torch.empty(len(uh) * len(uw) * _lib.SATU_TABLE, device=self.dev))
             self._plan_hr_tiling(ent, h, w, scale)
-            self._satu_axes[key] = ent
+            self._axes[key] = ent
+            while len(self._axes) > self.max_shapes * self.max_scales:
+                self._axes.popitem(last=False)
+        else:
+            self._axes.move_to_end(key)
         return ent
+
+    # measured cost model of one HR workgroup, cycles (tools/bench_kernels.py satu --stamps): per staged record, per 32-pixel
+    # tile of a wave (4 waves), per tile row of table staging -- [standalone 64-channel form, tail-projected form]
+    HR_COST = {False: (155, 6900, 60), True: (100, 4300, 60)}
 
     def _plan_hr_tiling(self, ent: dict, h: int, w: int, scale):
         """One-time (per size/scale) choice of the HR stage's LDS window: evaluate the phase table,
-        read the range of the sampling offsets back and pick the largest HR tile whose LRcat window
-        (tile footprint + offset range + bilinear tap) fits two workgroups per CU.  Purely a
-        performance plan: waves whose taps leave the window gather from global memory."""
+        read the range of the sampling offsets back and pick the HR tile whose LRcat window
+        (tile footprint + offset range + bilinear tap) plus its slice of the table fits two workgroups per CU at the
+        lowest modelled cost.  Purely a performance plan: waves whose taps leave the window gather from global memory."""
         sw = C.byref(self.satu_w)
         _lib.check(self.lib.savsr_satu_phase_table(sw, ent["uh"].data_ptr(), ent["n_uh"], ent["uw"].data_ptr(), ent["n_uw"],
                                                    1.0 / scale[1], 1.0 / scale[0], ent["table"].data_ptr(), self._stream()),
@@ -567,40 +659,41 @@ class HipEngine:
         tab = ent["table"].view(-1, _lib.SATU_TABLE).cpu().numpy()       # synchronises once
         ox = np.concatenate([tab[:, 4], tab[:, 6]])
         oy = np.concatenate([tab[:, 5], tab[:, 7]])
-        if not (np.isfinite(ox).all() and np.isfinite(oy).all()):
-            ent["tiling"] = None
-            return
-        rx = float(ox.max() - ox.min())
-        ry = float(oy.max() - oy.min())
-        budget = (78 * 1024 - 17152) // (164 * 4)                      # records per workgroup at 2 workgroups / CU (16.6 KB of constants)
+        finite = bool(np.isfinite(ox).all() and np.isfinite(oy).all())
         H, W = ent["H"], ent["W"]
-        slots = 2 * torch.cuda.get_device_properties(self.dev).multi_processor_count     # resident workgroups (2 per CU)
-        best = None
-        for tcols in (1, 2, 4):
-            for trows in (4, 6, 8, 10, 12, 14, 15, 16, 18, 20, 22, 24, 28, 32):
-                lr_c = int(np.ceil(32 * tcols / scale[1] + rx)) + 2
-                lr_r = int(np.ceil(trows / scale[0] + ry)) + 2
-                if lr_c * lr_r > budget:
-                    continue
-                # measured cost model of one workgroup (tools/bench_kernels.py satu --stamps): ~155 cycles per staged
-                # record + ~6.9 k cycles per 32-pixel tile of a wave (4 waves), times the number of rounds the grid
-                # needs on the resident slots -- the round quantisation (1 800 workgroups = 3.5 -> 4 rounds at 16 rows)
-                # matters as much as the re-staging
-                nblk = -(-H // trows) * -(-W // (32 * tcols))
-                rounds = -(-nblk // slots)
-                cost = rounds * (155 * lr_c * lr_r + 6900 * -(-(trows * tcols) // 4))
-                if best is None or cost < best[0]:
-                    best = (cost, trows, tcols, lr_r, lr_c)
-        t = SatuTiling()
-        if best is None:                                               # no window fits: gathers go to global memory
-            t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = 8, 1, 0, 0
-            t.off_min_x, t.off_min_y, t.table_entries = 0.0, 0.0, ent["n_uh"] * ent["n_uw"]
-            ent["tiling"] = t
-            return
-        t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = best[1], best[2], min(best[3], h), min(best[4], w)
-        t.off_min_x, t.off_min_y = float(ox.min()), float(oy.min())
-        t.table_entries = ent["n_uh"] * ent["n_uw"]
-        ent["tiling"] = t
+        ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        forced = os.environ.get("SAVSR_HR_TILE")                                         # "rows,cols32": experiments only
+        for tail_form in (False, True):
+            occ = int(os.environ.get("SAVSR_HR_WGS", "0")) or int(self.lib.savsr_satu_hr_occupancy_target(int(tail_form)))
+            slots = occ * ncu                                                            # resident workgroups
+            lds_cap = (160 * 1024) // occ - 1024                                         # `occ` workgroups per CU
+            t = SatuTiling()
+            t.table_entries = ent["n_uh"] * ent["n_uw"]
+            t.step_x, t.step_y = 1.0 / float(scale[1]), 1.0 / float(scale[0])
+            best = None
+            if finite:
+                rx, ry = float(ox.max() - ox.min()), float(oy.max() - oy.min())
+                c_rec, c_tile, c_row = self.HR_COST[tail_form]
+                cands = [(int(forced.split(",")[0]), int(forced.split(",")[1]))] if forced else \
+                    [(r, c) for c in (1, 2, 4) for r in (4, 6, 8, 10, 12, 14, 15, 16, 18, 20, 22, 24, 28, 32)]
+                for trows, tcols in cands:
+                    lr_c = min(int(np.ceil(32 * tcols / scale[1] + rx)) + 2, w)
+                    lr_r = min(int(np.ceil(trows / scale[0] + ry)) + 2, h)
+                    if self.lib.savsr_satu_hr_lds_bytes(int(tail_form), trows, tcols, lr_r, lr_c) > lds_cap:
+                        continue
+                    # the round quantisation of the grid on the resident slots matters as much as the re-staging
+                    nblk = -(-H // trows) * -(-W // (32 * tcols))
+                    rounds = -(-nblk // slots)
+                    cost = rounds * (c_rec * lr_c * lr_r + c_tile * -(-(trows * tcols) // 4) + c_row * trows * tcols)
+                    if best is None or cost < best[0]:
+                        best = (cost, trows, tcols, lr_r, lr_c)
+            if best is None:                                           # no window fits (or non-finite offsets): gathers go to global memory
+                t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = 8, 1, 0, 0
+                t.off_min_x, t.off_min_y = 0.0, 0.0
+            else:
+                t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = best[1], best[2], best[3], best[4]
+                t.off_min_x, t.off_min_y = float(ox.min()), float(oy.min())
+            ent["tiling_tail" if tail_form else "tiling"] = t
 
     @staticmethod
     def hr_plane(H: int, W: int) -> int:
@@ -609,21 +702,48 @@ class HipEngine:
         16 KiB at 720x1280)."""
         return ((H * W + 255) // 256) * 256 + 1088
 
+    def satu_lr(self, x: Src, st: Src, row_px: int, h: int, w: int, tail_form: bool = False) -> torch.Tensor:
+        """LR stage of SATU (kernel_conv + LeakyReLU + sta_conv + LR-side projections, savsr_arch.py:226-228,297-320).
+        tail_form: the projections carry the tail conv's channel contraction (include/savsr_hip.h)."""
+        assert x.pix == st.pix
+        if tail_form:
+            lrcat = self.buf("satu.lrcat_tail", h, w, _lib.SATU_LRCAT_TAIL)
+            fn, wts = self.lib.savsr_satu_lr_stage_tail, self.satu_w_tail
+        else:
+            lrcat = self.buf("satu.lrcat", h, w, _lib.SATU_LRCAT)
+            fn, wts = self.lib.savsr_satu_lr_stage, self.satu_w
+        _lib.check(fn(C.byref(wts), x.ptr, st.ptr, x.pix, row_px, h, w, lrcat.data_ptr(), self._stream()), "savsr_satu_lr_stage")
+        return lrcat
+
+    def satu_hr(self, lrcat: torch.Tensor, h: int, w: int, scale, out: torch.Tensor, out_plane: Optional[int] = None, tail_form: bool = False):
+        """HR stage of SATU (grid_sample x2, expert mixing, fusion, savsr_arch.py:262-295,353-374) -> out [64] planes of [H][W];
+        tail_form: -> the 27 tail-projected planes P."""
+        ax = self.satu_axes(h, w, scale)       # incl. the phase table: a function of (size, scale, weights) only, evaluated once
+        fn, wts, til = (self.lib.savsr_satu_hr_tail, self.satu_w_tail, ax["tiling_tail"]) if tail_form else \
+            (self.lib.savsr_satu_hr_upsample, self.satu_w, ax["tiling"])
+        _lib.check(fn(C.byref(wts), lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(),
+                      ax["iw"].data_ptr(), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"], C.byref(til),
+                      out.data_ptr(), out_plane if out_plane is not None else ax["H"] * ax["W"], self._stream()),
+                   "savsr_satu_hr")
+        return out
+
     def satu(self, x: Src, st: Src, row_px: int, h: int, w: int, scale, out: torch.Tensor, out_plane: Optional[int] = None):
         """STAUpsample.forward (savsr_arch.py:315-376).  x, st: channel-last crops (row pitch row_px
         pixels) of [..][..][64] maps; out: [64][H][W] planar."""
-        ax = self.satu_axes(h, w, scale)       # incl. the phase table: a function of (size, scale, weights) only, evaluated once
-        s = self._stream()
-        sw = C.byref(self.satu_w)
-        assert x.pix == st.pix
-        lrcat = self.buf("satu.lrcat", h, w, _lib.SATU_LRCAT)
-        _lib.check(self.lib.savsr_satu_lr_stage(sw, x.ptr, st.ptr, x.pix, row_px, h, w, lrcat.data_ptr(), s), "savsr_satu_lr_stage")
-        _lib.check(self.lib.savsr_satu_hr_upsample(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(),
-                                                   ax["iw"].data_ptr(), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"],
-                                                   C.byref(ax["tiling"]) if ax["tiling"] is not None else None,
-                                                   out.data_ptr(), out_plane if out_plane is not None else ax["H"] * ax["W"], s),
-                   "savsr_satu_hr_upsample")
-        return out
+        return self.satu_hr(self.satu_lr(x, st, row_px, h, w), h, w, scale, out, out_plane)
+
+    def time_satu_parts(self, lq: torch.Tensor, scale, timer) -> dict:
+        """Diagnostics (tools/scale_sweep.py, bench.py): the SATU LR / HR launches and the tail of the product path, each timed
+        alone by `timer(fn) -> us` on the tensors of a real frame.  lq: [T, 3, h, w] on the device."""
+        lq = lq.contiguous()
+        self._select(lq.shape, scale)
+        c = self._stage_body(lq, scale)
+        out = torch.empty(3, c["H"], c["W"], device=self.dev)
+        lrcat = self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True)
+        self._stage_satu(c, scale)
+        return {"satu_lr_us": timer(lambda: self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True)),
+                "satu_hr_us": timer(lambda: self.satu_hr(lrcat, c["h"], c["w"], scale, c["p27"], c["plane"], tail_form=True)),
+                "tail_us": timer(lambda: self._stage_tail(c, lq, out))}
 
     # ------------------------------------------------------------------ whole frame
     def _stage_body(self, lq: torch.Tensor, scale) -> dict:
@@ -676,21 +796,31 @@ class HipEngine:
         hfeat = self.conv("conv_last", [hcur], self.full(self.buf("hfeat", hp, wp, nf)), hp, wp, res1=share)   # :733-734
         H, W = get_hw(h_in, w_in, scale)
         plane = self.hr_plane(H, W)
-        return dict(align=align, hfeat=hfeat, wp=wp, h=h_in, w=w_in, H=H, W=W, plane=plane, satu_out=self.buf("satu.out", nf, plane))
+        return dict(align=align, hfeat=hfeat, wp=wp, h=h_in, w=w_in, H=H, W=W, plane=plane, p27=self.sbuf("satu.p27", _lib.TAIL_PLANES, plane))
 
     def _stage_satu(self, c: dict, scale):
-        self.satu(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], scale, c["satu_out"], c["plane"])   # crops of :737 via (row pitch, h, w)
+        """SATU in the tail-projected form (savsr_arch.py:315-376 with the channel contraction of :738 folded in): -> P [27][H][W]."""
+        lrcat = self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True)       # crops of :737 via (row pitch, h, w)
+        self.satu_hr(lrcat, c["h"], c["w"], scale, c["p27"], c["plane"], tail_form=True)
 
     def _stage_tail(self, c: dict, lq: torch.Tensor, out: torch.Tensor):
+        """What is left of :738-739: the nine shifted taps per colour, the tail bias, the bilinear residual."""
         cfg = self.cfg
         T = lq.shape[0]
         center = T // 2 if cfg["center_frame_idx"] is None else cfg["center_frame_idx"]
         cptr = lq.data_ptr() + 4 * center * 3 * c["h"] * c["w"]                     # unpadded centre frame (:696)
-        _lib.check(self.lib.savsr_tail_residual(c["satu_out"].data_ptr(), c["plane"], self.tail_w.data_ptr(), self.tail_b.data_ptr(), cptr,
-                                                c["h"], c["w"], c["H"], c["W"], out.data_ptr(), self._stream()), "savsr_tail_residual")
+        _lib.check(self.lib.savsr_tail_gather(c["p27"].data_ptr(), c["plane"], self.tail_b.data_ptr(), cptr,
+                                              c["h"], c["w"], c["H"], c["W"], out.data_ptr(), self._stream()), "savsr_tail_gather")
+
+    def _satu_standalone(self, c: dict, scale) -> torch.Tensor:
+        """STAUpsample.forward as such ([64][H][W]; tests / taps only -- the product path never materialises it)."""
+        o = self.sbuf("satu.out", self.nf, c["plane"])
+        self.satu(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], scale, o, c["plane"])
+        return o[:, : c["H"] * c["W"]].view(self.nf, c["H"], c["W"])
 
     def forward_one(self, lq: torch.Tensor, scale, out: torch.Tensor, taps: Optional[dict] = None):
         """Eager launch sequence.  lq: [T, 3, h, w] fp32 contiguous on device; out: [3, H, W]."""
+        self._select(lq.shape, scale)
         c = self._stage_body(lq, scale)
         if self.satu_events is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -702,7 +832,8 @@ class HipEngine:
         if taps is not None:                    # channel-last [hp][wp][64] tensors; SATU output planar
             taps["align_feat"] = c["align"].t
             taps["h_feat"] = c["hfeat"].t
-            taps["satu"] = c["satu_out"][:, : c["H"] * c["W"]].view(self.nf, c["H"], c["W"])
+            taps["satu"] = self._satu_standalone(c, scale)
+            taps["p27"] = c["p27"][:, : c["H"] * c["W"]].view(_lib.TAIL_PLANES, c["H"], c["W"])
         self._stage_tail(c, lq, out)
         return out
 
@@ -710,8 +841,8 @@ class HipEngine:
         """hipGraph replay of the same launch sequence (three graphs: body | SATU | tail, so the SATU
         stage can be bracketed by HIP events).  The ~1400 launches of a frame cost ~11 us of host time
         each when issued from Python; captured once per (shape, scale) they replay in tens of us."""
-        key = (tuple(lq.shape), float(scale[0]), float(scale[1]))
-        g = self._graphs.get(key)
+        sc = self._select(lq.shape, scale)
+        g = sc["graphs"]
         if g is None:
             s_in = torch.empty_like(lq)
             s_out = torch.empty_like(out)
@@ -731,7 +862,7 @@ class HipEngine:
             finally:
                 self.satu_events = ev
             g = (s_in, s_out, graphs)
-            self._graphs[key] = g
+            sc["graphs"] = g
         s_in, s_out, graphs = g
         s_in.copy_(lq)
         graphs[0].replay()

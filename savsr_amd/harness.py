@@ -50,9 +50,9 @@ def window_indices(crt_idx: int, max_frame_num: int, num_frames: int = 7, paddin
 def gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int) -> torch.Tensor:
     """All ranks' per-frame rows in frame order.  local: [len(frame_indices(n_total, rank, world)), k].
     One padded all_gather (RCCL all_gather_into_tensor on GPU tensors; list all_gather on gloo)."""
-    if world == 1:
-        return local
     import torch.distributed as dist
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local                     # no process group: nothing to gather (a single-rank GROUP still runs the collective)
     per = (n_total + world - 1) // world
     k = local.shape[1]
     padded = torch.zeros(per, k, dtype=local.dtype, device=local.device)
@@ -84,6 +84,7 @@ def validate_folder(net: Callable, lq_frames: torch.Tensor, gt_frames: Sequence[
     on_gpu = device is not None and device.type == "cuda"
     if on_gpu:                                        # metrics stay on the device until the per-dataset gather
         from .metrics_gpu import psnr_ssim_y
+        from .resize_gpu import resize_bicubic_aa
         rows = rows.to(device)
     for k, idx in enumerate(mine):
         win = lq_frames[window_indices(idx, n, num_frame, padding)].unsqueeze(0)
@@ -91,8 +92,14 @@ def validate_folder(net: Callable, lq_frames: torch.Tensor, gt_frames: Sequence[
             win = win.to(device)
         out = net(win)
         if on_gpu:
-            psnr_ssim_y(out[0], gt_frames[idx].to(device), 0, out=rows[k])
+            gt = gt_frames[idx].to(device)
+            if out.shape[-2:] != gt.shape[-2:]:       # arbitrary-scale post-resize to the GT size (sr_model.py:290-294)
+                out = resize_bicubic_aa(out, tuple(gt.shape[-2:]))
+            psnr_ssim_y(out[0], gt, 0, out=rows[k])
         else:
+            # Host metrics (the reference's own numpy formulation, savsr_amd/metrics.py).  Only reached with a CPU `net`,
+            # i.e. by the world-size-2 gloo test of the sharding / gather logic (tests/test_dist_gloo.py) -- the real
+            # network refuses CPU tensors, so the product flow never computes here.
             sr, gt = tensor2img(out[0]), tensor2img(gt_frames[idx])
             rows[k, 0] = calculate_psnr(sr, gt, 0, test_y_channel=True)
             rows[k, 1] = calculate_ssim(sr, gt, 0, test_y_channel=True)
@@ -111,11 +118,8 @@ def validate_folder_from_gt(net: Callable, gt_frames: torch.Tensor, scale: Tuple
     from .resize_gpu import arbitrary_scale_downsample, as_mod_crop_hw
     H, W = as_mod_crop_hw(gt_frames.shape[-2], gt_frames.shape[-1], tuple(scale))
     gt = gt_frames[..., :H, :W].contiguous()
-    if device is not None and device.type == "cuda":
-        gt = gt.to(device)
-        lq = arbitrary_scale_downsample(gt, tuple(scale))
-    else:
-        import torch.nn.functional as F
-        lq = F.interpolate(gt, size=(round(H / scale[0]), round(W / scale[1])), mode="bicubic", align_corners=False, antialias=True)
+    if device is None or device.type != "cuda":
+        raise RuntimeError("validate_folder_from_gt synthesises the LR frames on the GPU (csrc/resize.hip); there is no CPU fallback")
+    gt = gt.to(device)
+    lq = arbitrary_scale_downsample(gt, tuple(scale))
     return validate_folder(net, lq, list(gt), scale, rank, world, num_frame, padding, device)
-

@@ -1,0 +1,179 @@
+"""Test-time model wrapper under the reference's registry name: `model_type: ASVSRModel` of
+options/test/SAVSR/*.yml resolves here through MODEL_REGISTRY.
+
+What is mirrored (inference only -- no optimisers, losses, EMA, loggers or training state):
+  SRModel.__init__            lbasicsr/models/sr_model.py:27-41   build_network(opt['network_g']) -> device -> load_network
+  BaseModel.feed_data         sr_model.py:91-98                  lq / gt onto the device
+  ASVSRModel.test             asvsr_model.py:31-61               set_scale(opt['scale']); eval; no_grad forward
+  VideoBaseModel.dist_validation / _log_validation_metric_values
+                              video_base_model.py:18-118,125-167 frame round-robin over ranks, per-frame metrics, per-folder
+                                                                 means, mean over folders
+  SRModel.get_current_visuals sr_model.py:290-294                bicubic-antialias post-resize when output and GT sizes differ
+
+MI355X-first placement: the post-resize (csrc/resize.hip), the uint8 quantisation + BT.601 luma + PSNR-Y / SSIM-Y
+(csrc/metrics.hip) run on the GPU on the un-copied output; the metric rows stay in HBM until ONE collective per dataset
+(RCCL all_gather_into_tensor of the [n_frames, n_metrics] rows -- the reference issues one dist.reduce per folder).
+Images are written by the host (PNG encode is host work) only when `val.save_img` asks for them.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from copy import deepcopy
+from typing import Dict, Optional
+
+import torch
+
+from . import io as sio
+from .archs import build_network
+from .harness import frame_indices, gather_rows
+from .metrics import tensor2img
+from .registry import METRIC_REGISTRY, MODEL_REGISTRY
+from .resize_gpu import resize_bicubic_aa
+
+
+def _gpu_metric_plan(metrics_opt) -> Optional[int]:
+    """The fused GPU kernel produces (PSNR-Y, SSIM-Y) of one crop_border in one pass.  Returns that crop_border when
+    every requested metric is one of the two with test_y_channel=True and a common crop_border (every shipped YAML),
+    else raises: there is deliberately no host fallback inside the product path."""
+    crop = None
+    for name, m in metrics_opt.items():
+        if m["type"] not in ("calculate_psnr", "calculate_ssim") or not m.get("test_y_channel", False) or m.get("input_order", "HWC") != "HWC":
+            raise NotImplementedError(f"metric '{name}' ({dict(m)}): the GPU metric kernel implements calculate_psnr / calculate_ssim with "
+                                      "test_y_channel: true (the metrics of options/test/SAVSR/*.yml)")
+        if m["type"] not in METRIC_REGISTRY:
+            raise KeyError(m["type"])
+        c = int(m.get("crop_border", 0))
+        if crop is not None and c != crop:
+            raise NotImplementedError("metrics with different crop_border values in one run are not supported by the fused kernel")
+        crop = c
+    return crop
+
+
+class BaseModel:
+    """The slice of lbasicsr/models/base_model.py the test flow touches."""
+
+    def __init__(self, opt):
+        self.opt = opt
+        if opt.get("num_gpu", 1) == 0 or not torch.cuda.is_available():
+            raise RuntimeError("savsr_amd models run on an AMD GPU only (num_gpu: 0 / CPU mode is not available: no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.is_train = opt.get("is_train", False)
+
+    def validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
+        """base_model.py:45-57."""
+        if self.opt.get("dist"):
+            return self.dist_validation(dataloader, current_iter, tb_logger, save_img)
+        return self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
+
+
+@MODEL_REGISTRY.register()
+class VideoBaseModel(BaseModel):
+    """video_base_model.py + the parts of sr_model.py it inherits, inference only."""
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        if self.is_train:
+            raise NotImplementedError("savsr_amd implements the test flow only (is_train: false)")
+        self.net_g = build_network(opt["network_g"]).eval()
+        load_path = opt["path"].get("pretrain_network_g")
+        if load_path is not None:                                     # sr_model.py:36-39
+            sio.load_network(self.net_g, load_path, opt["path"].get("strict_load_g", True), opt["path"].get("param_key_g", "params"))
+        self.net_g.to(self.device)
+        self.metric_results: Dict[str, torch.Tensor] = {}
+        self.last_validation: Optional[dict] = None
+
+    # ---- one frame -------------------------------------------------------------------------------------------------
+    def feed_data(self, data):
+        self.lq = data["lq"].to(self.device)
+        if "gt" in data:
+            self.gt = data["gt"].to(self.device)
+
+    def test(self):
+        with torch.no_grad():
+            self.output = self.net_g(self.lq)
+
+    def get_current_visuals(self):
+        """sr_model.py:277-307: arbitrary-scale outputs whose size differs from the ground truth's are resized to it with
+        torchvision's BICUBIC + antialias (here: csrc/resize.hip, the same ATen arithmetic)."""
+        if hasattr(self, "gt") and self.output.shape[-2:] != self.gt.shape[-2:]:
+            self.output = resize_bicubic_aa(self.output, tuple(self.gt.shape[-2:]))
+        out = OrderedDict(lq=self.lq, result=self.output)
+        if hasattr(self, "gt"):
+            out["gt"] = self.gt
+        return out
+
+    # ---- one dataset -----------------------------------------------------------------------------------------------
+    def dist_validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
+        from .metrics_gpu import psnr_ssim_y
+        dataset = getattr(dataloader, "dataset", dataloader)
+        if dataset.opt.get("downsampling_scale", 0) != 0:             # :21-22
+            self.opt["scale"] = dataset.opt["downsampling_scale"]
+        dataset_name = dataset.opt["name"]
+        metrics_opt = self.opt["val"].get("metrics")
+        with_metrics = metrics_opt is not None
+        rank, world = self.opt.get("rank", 0), self.opt.get("world_size", 1)
+        n = len(dataset)
+        mine = frame_indices(n, rank, world)                          # :50
+        names = list(metrics_opt.keys()) if with_metrics else []
+        crop = _gpu_metric_plan(metrics_opt) if with_metrics else None
+        rows = torch.zeros(len(mine), 2, dtype=torch.float64, device=self.device)
+        for k, idx in enumerate(mine):
+            val = dataset[idx]
+            val["lq"] = val["lq"].unsqueeze(0)
+            val["gt"] = val["gt"].unsqueeze(0)
+            self.feed_data(val)
+            self.test()
+            vis = self.get_current_visuals()
+            if save_img:
+                path = sio.result_img_path(self.opt["path"]["visualization"], dataset_name, val["folder"], val["lq_path"],
+                                           self.opt["name"], self.opt["val"].get("suffix"))
+                sio.imwrite(tensor2img(vis["result"]), path)
+            if with_metrics:
+                psnr_ssim_y(vis["result"][0], vis["gt"][0], crop, out=rows[k])
+            del self.lq, self.output, self.gt
+        if not with_metrics:
+            return None
+        allrows = gather_rows(rows, n, rank, world)                   # the one collective of the dataset (:108-113)
+        cols = [0 if metrics_opt[m]["type"] == "calculate_psnr" else 1 for m in names]
+        table = allrows[:, cols].to(torch.float32).cpu()              # the reference accumulates in float32 tensors (:36-37)
+        self.metric_results = {}
+        folders = dataset.data_info["folder"]
+        for f in dict.fromkeys(folders):
+            sel = [i for i, g in enumerate(folders) if g == f]
+            self.metric_results[f] = table[sel]
+        self.last_validation = self._log_validation_metric_values(current_iter, dataset_name, tb_logger, names)
+        return self.last_validation
+
+    def nondist_validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
+        return self.dist_validation(dataloader, current_iter, tb_logger, save_img)       # :120-123
+
+    def _log_validation_metric_values(self, current_iter, dataset_name, tb_logger, names):
+        """:125-167 -- per-folder means, then the mean over folders; returned instead of logged."""
+        avg = {f: torch.mean(t, dim=0) for f, t in self.metric_results.items()}
+        total = {m: 0.0 for m in names}
+        for f, t in avg.items():
+            for i, m in enumerate(names):
+                total[m] += t[i].item()
+        for m in names:
+            total[m] /= len(avg)
+        return {"dataset": dataset_name, "scale": self.opt.get("scale"), "metrics": total,
+                "folders": {f: {m: t[i].item() for i, m in enumerate(names)} for f, t in avg.items()},
+                "frames": {f: self.metric_results[f].clone() for f in avg}}
+
+
+@MODEL_REGISTRY.register()
+class ASVSRModel(VideoBaseModel):
+    """asvsr_model.py:12-61."""
+
+    def test(self):
+        net = self.net_g.module if hasattr(self.net_g, "module") else self.net_g
+        net.set_scale(self.opt["scale"])
+        net.eval()
+        with torch.no_grad():
+            self.output = self.net_g(self.lq)
+
+
+def build_model(opt):
+    """lbasicsr/models/__init__.py build_model: MODEL_REGISTRY lookup by `model_type`."""
+    opt = deepcopy(opt)
+    return MODEL_REGISTRY.get(opt["model_type"])(opt)

@@ -1,7 +1,8 @@
 """Parity of each HIP kernel family (through the C ABI) against the CPU oracle / ATen CPU ops.
 
-Run on the GPU box with `pytest -m gpu`.  Tolerances: fp32 re-association only, so 1e-4 absolute
-on O(1) values unless a test states otherwise (north_star: 1e-3 dB PSNR / 1e-4 SSIM end to end).
+Run on the GPU box with `pytest -m gpu`.  Tolerances: 2e-5 max-abs on O(1) values per kernel (fp32 re-association plus
+the ~2^-17 relative error of split-bf16 products; measured values are printed with `-rA`), 3e-5 where a test states so
+(north_star: 1e-3 dB PSNR / 1e-4 SSIM end to end).
 """
 import ctypes as C
 
@@ -48,8 +49,8 @@ def pl(t):
     (192, 64, 1, 3, 7, 50), (16, 128, 3, 1, 13, 31), (64, 16, 3, 1, 10, 12),
     (16, 16, 3, 1, 5, 6), (16, 1, 3, 1, 10, 12), (128, 64, 3, 1, 19, 11)])
 def test_conv2d(eng, cin, cout, ks, nsrc, h, w):
-    """savsr_conv2d (split-bf16 MFMA) vs F.conv2d fp32 incl. the fused epilogue; tolerance 1e-4
-    absolute on O(1) outputs (bf16x3 products carry ~2^-17 relative error)."""
+    """savsr_conv2d (split-bf16 MFMA) vs F.conv2d fp32 incl. the fused epilogue; tolerance 3e-5
+    absolute on outputs of magnitude ~4 (bf16x3 products carry ~2^-17 relative error)."""
     from savsr_amd import engine as E
     from savsr_amd._lib import ACT_LRELU
     g = np.random.RandomState(cin * 7 + cout)
@@ -72,7 +73,9 @@ def test_conv2d(eng, cin, cout, ks, nsrc, h, w):
     torch.cuda.synchronize()
     off = 4 if cout % 4 == 0 else 0
     got = pl(wide[..., off:off + cout])
-    assert _maxerr(got, ref) < 1e-4
+    e = _maxerr(got, ref)
+    print('conv', cin, cout, ks, 'max-abs', e)
+    assert e < 3e-5          # measured 0.8 - 1.8e-5 on outputs of magnitude ~4
 
 
 def test_conv2d_batch_wide_tiles(eng):
@@ -106,10 +109,10 @@ def test_conv2d_batch_wide_tiles(eng):
         eng.conv_launch([d])
     torch.cuda.synchronize()
     for k in range(n):
-        assert _maxerr(pl(outs[k]), refs[k]) < 1e-4
+        assert _maxerr(pl(outs[k]), refs[k]) < 3e-5          # outputs of magnitude ~4, K = 1152
         assert torch.equal(outs[k], outs1[k])
         assert torch.equal(parts[k], parts1[k])
-        assert _maxerr(parts[k].sum(0).cpu() / (h * w), refs[k].mean(dim=(1, 2))) < 1e-4
+        assert _maxerr(parts[k].sum(0).cpu() / (h * w), refs[k].mean(dim=(1, 2))) < 2e-5
 
 
 def test_conv2d_rejects_bad_args(eng):
@@ -135,7 +138,9 @@ def test_osconv_vs_golden(eng, golden, synth_sd, tag, pfx, cin):
         eng.conv(pfx, srcs, eng.full(out), 10, 12, weights=wd)
         torch.cuda.synchronize()
         gold = torch.from_numpy(golden[f"osconv/{tag}/{sc[0]}_{sc[1]}"])[0]
-        assert _maxerr(pl(out), gold) < 1e-4
+        e = _maxerr(pl(out), gold)
+        print(tag, sc, 'osconv max-abs', e)
+        assert e < 3e-5
         # attention vector itself against the oracle
         with torch.no_grad():
             b = 1
@@ -183,7 +188,9 @@ def test_osadapt_vs_golden(eng, golden):
     out = torch.empty(10, 12, 64, device="cuda:0")
     eng.osadapt(1, eng.full(cl(x[0])), None, eng.full(out), 10, 12, (2.5, 2.5))      # golden is OSAdapt alone
     torch.cuda.synchronize()
-    assert _maxerr(pl(out), torch.from_numpy(golden["osadapt/a1/2.5_2.5"])[0]) < 1e-4
+    e = _maxerr(pl(out), torch.from_numpy(golden["osadapt/a1/2.5_2.5"])[0])
+    print("osadapt max-abs", e)
+    assert e < 2e-5
 
 
 def _run_satu(eng, x, st, sc):
@@ -201,7 +208,9 @@ def test_satu_vs_golden(eng, golden, tag, h, w, sc):
     x = rnd((1, 64, h, w), 21, 1.0)
     st = rnd((1, 64, h, w), 22, 0.6)
     out = _run_satu(eng, x, st, sc)
-    assert _maxerr(out, torch.from_numpy(golden[f"satu/{tag}/out"])[0]) < 1e-4
+    err = _maxerr(out, torch.from_numpy(golden[f"satu/{tag}/out"])[0])
+    print(tag, "SATU max-abs vs reference golden", err)
+    assert err < 2e-5
 
 
 def test_satu_phase_table_and_integer_grid(eng, synth_sd):
@@ -237,7 +246,9 @@ def test_satu_large_offsets_and_borders(eng, synth_sd):
         out = _run_satu(e2, x, st, sc)
         with torch.no_grad():
             ref = O.sta_upsample(sd, "upsample", x, sc, st)[0]
-        assert _maxerr(out, ref) < 2e-4
+        e = _maxerr(out, ref)
+        print('large offsets', sc, e)
+        assert e < 3e-5
 
 
 def test_satu_strided_crop(eng, synth_sd):
@@ -252,7 +263,7 @@ def test_satu_strided_crop(eng, synth_sd):
     torch.cuda.synchronize()
     with torch.no_grad():
         ref = O.sta_upsample(synth_sd, "upsample", xf[..., :h, :w], sc, sf[..., :h, :w])[0]
-    assert _maxerr(out, ref) < 1e-4
+    assert _maxerr(out, ref) < 2e-5
 
 
 def test_tail_residual(eng, synth_sd):
@@ -267,7 +278,87 @@ def test_tail_residual(eng, synth_sd):
     torch.cuda.synchronize()
     ref = F.conv2d(feat, synth_sd["tail.weight"], synth_sd["tail.bias"], padding=1) + \
         F.interpolate(center, size=(H, W), mode="bilinear", align_corners=False)
-    assert _maxerr(out, ref[0]) < 1e-4
+    assert _maxerr(out, ref[0]) < 2e-5
+
+
+def _wt27(sd):
+    tw = sd["tail.weight"].double()
+    m = torch.zeros(27, 64, dtype=torch.float64)
+    for ky in range(3):
+        for kx in range(3):
+            for o in range(3):
+                m[3 * (3 * ky + kx) + o] = tw[o, :, ky, kx]
+    return m
+
+
+@pytest.mark.parametrize("tag,h,w,sc", SATU_CASES)
+def test_satu_tail_form_vs_reference(eng, golden, synth_sd, tag, h, w, sc):
+    """The tail-projected SATU (savsr_satu_lr_stage_tail + savsr_satu_hr_tail) writes P = Wt27 . F, F the REFERENCE's
+    STAUpsample output (tests/golden): 27 planes, each within 2e-5 of the float64 contraction of the golden."""
+    from savsr_amd import _lib
+    from savsr_amd.engine import get_hw
+    x = rnd((1, 64, h, w), 21, 1.0)
+    st = rnd((1, 64, h, w), 22, 0.6)
+    H, W = get_hw(h, w, sc)
+    p27 = torch.full((27, H * W + 20), float("nan"), device="cuda:0")
+    lrcat = eng.satu_lr(eng.full(cl(x[0])), eng.full(cl(st[0])), w, h, w, tail_form=True)
+    assert lrcat.shape[-1] == _lib.SATU_LRCAT_TAIL
+    eng.satu_hr(lrcat, h, w, sc, p27, H * W + 20, tail_form=True)
+    torch.cuda.synchronize()
+    ref = torch.einsum("pc,chw->phw", _wt27(synth_sd), torch.from_numpy(golden[f"satu/{tag}/out"])[0].double())
+    got = p27[:, : H * W].view(27, H, W).cpu().double()
+    assert bool(torch.isnan(p27[:, H * W:]).all()), "nothing is written between the planes"
+    err = float((got - ref).abs().max())
+    print(tag, "P max-abs", err, "magnitude", float(ref.abs().max()))
+    assert err < 2e-5
+
+
+def test_satu_tail_form_without_window_and_large_offsets(synth_sd):
+    """Gathers that leave the staged window (or run without one) take the global path; zero padding at the borders."""
+    from savsr_amd.engine import HipEngine, get_hw
+    from savsr_amd.archs.savsr_arch import SAVSR
+    sd = dict(synth_sd)
+    for k in ("upsample.offset.weight", "upsample.st_offset.weight"):
+        sd[k] = sd[k] * 6.0
+    e2 = HipEngine(sd, SAVSR().cfg, torch.device("cuda:0"))
+    x = rnd((1, 64, 9, 8), 31, 1.0)
+    st = rnd((1, 64, 9, 8), 32, 0.6)
+    for sc in [(4, 4), (2.5, 1.3)]:
+        H, W = get_hw(9, 8, sc)
+        with torch.no_grad():
+            ref = torch.einsum("pc,chw->phw", _wt27(sd), O.sta_upsample(sd, "upsample", x, sc, st)[0].double())
+        lrcat = e2.satu_lr(e2.full(cl(x[0])), e2.full(cl(st[0])), 8, 9, 8, tail_form=True)
+        for drop_window in (False, True):
+            ax = e2.satu_axes(9, 8, sc)
+            keep = (ax["tiling_tail"].lr_rows, ax["tiling_tail"].lr_cols)
+            if drop_window:
+                ax["tiling_tail"].lr_rows, ax["tiling_tail"].lr_cols = 0, 0
+            p27 = torch.empty(27, H * W, device="cuda:0")
+            e2.satu_hr(lrcat, 9, 8, sc, p27, tail_form=True)
+            torch.cuda.synchronize()
+            ax["tiling_tail"].lr_rows, ax["tiling_tail"].lr_cols = keep
+            assert _maxerr(p27.view(27, H, W).double(), ref) < 5e-5
+
+
+@pytest.mark.parametrize("h,w,sc", [(7, 9, (3.5, 2)), (8, 10, (2, 2.4)), (5, 16, (4, 4)), (6, 7, (1.5, 1.3))])
+def test_tail_gather(eng, synth_sd, h, w, sc):
+    """savsr_tail_gather: nine shifted taps per colour + bias + bilinear residual (savsr_arch.py:738-739), both the
+    16-B path (W % 4 == 0) and the per-pixel path, vs conv2d on the un-projected feature map."""
+    from savsr_amd import _lib
+    H, W = O.get_hw(h, w, sc)
+    feat = rnd((1, 64, H, W), 51, 1.0)
+    center = torch.from_numpy(np.random.RandomState(52).uniform(0, 1, (1, 3, h, w)).astype(np.float32))
+    P = torch.einsum("pc,chw->phw", _wt27(synth_sd), feat[0].double()).float()
+    pitch = ((H * W + 3) // 4) * 4 + 8
+    pd = torch.zeros(27, pitch, device="cuda:0")
+    pd[:, : H * W] = P.reshape(27, -1).to("cuda:0")
+    out = torch.empty(3, H, W, device="cuda:0")
+    cd = _dev(center[0])
+    _lib.check(eng.lib.savsr_tail_gather(pd.data_ptr(), pitch, eng.tail_b.data_ptr(), cd.data_ptr(), h, w, H, W, out.data_ptr(), None), "tail_gather")
+    torch.cuda.synchronize()
+    ref = F.conv2d(feat.double(), synth_sd["tail.weight"].double(), synth_sd["tail.bias"].double(), padding=1).float() + \
+        F.interpolate(center, size=(H, W), mode="bilinear", align_corners=False)
+    assert _maxerr(out, ref[0]) < 5e-6
 
 
 def test_small_elementwise(eng):

@@ -24,7 +24,7 @@ def net(synth_sd):
 
 @pytest.mark.parametrize("name,h,w,sc", NET_CASES)
 def test_network_vs_reference_golden(net, golden, name, h, w, sc):
-    """fp32 output within 2e-4 max-abs of the REFERENCE's own output (tests/golden)."""
+    """fp32 output within 5e-5 max-abs of the REFERENCE's own output (tests/golden); SATU tap within 2e-5 x its magnitude (~4)."""
     lq = synth.synth_clip(7, 3, h, w, seed=0)
     net.set_scale(sc)
     taps = {}
@@ -33,9 +33,10 @@ def test_network_vs_reference_golden(net, golden, name, h, w, sc):
     gold = torch.from_numpy(golden[f"net/{name}/sr"])
     assert tuple(out.shape) == tuple(gold.shape)
     err = float((out.cpu() - gold).abs().max())
-    satu_err = float((taps["satu"].cpu()[::4, ::3, ::3] - torch.from_numpy(golden[f"net/{name}/satu_s"])[0]).abs().max())
-    print(name, "max-abs", err, "satu", satu_err)
-    assert satu_err < 5e-4 and err < 2e-4
+    gs = torch.from_numpy(golden[f"net/{name}/satu_s"])[0]
+    satu_err = float((taps["satu"].cpu()[::4, ::3, ::3] - gs).abs().max()) / float(gs.abs().max())
+    print(name, "max-abs", err, "satu (relative to its magnitude %.1f)" % float(gs.abs().max()), satu_err)
+    assert satu_err < 1e-5 and err < 5e-5
 
 
 def test_stage_taps_vs_oracle(net, synth_sd):
@@ -52,10 +53,11 @@ def test_stage_taps_vs_oracle(net, synth_sd):
         got = taps[k].cpu()
         if k != "satu":                       # channel-last [hp][wp][64] -> planar
             got = got.permute(2, 0, 1)
-        e = float((got - otaps[k][0]).abs().max())
-        print(k, e)
-        assert e < 5e-4, (k, e)
-    assert float((out.cpu() - ref).abs().max()) < 2e-4
+        mag = float(otaps[k][0].abs().max())
+        e = float((got - otaps[k][0]).abs().max()) / mag
+        print(k, "relative max-abs", e, "magnitude", mag)
+        assert e < 1e-5, (k, e)            # intermediate feature maps reach magnitudes of ~10: relative to the tensor's maximum
+    assert float((out.cpu() - ref).abs().max()) < 5e-5
 
 
 def test_batch_and_determinism(net, synth_sd):
@@ -66,7 +68,7 @@ def test_batch_and_determinism(net, synth_sd):
     assert torch.equal(a, b), "kernels are deterministic: bitwise identical reruns"
     with torch.no_grad():
         ref = O.forward(synth_sd, lq[1:], (2, 2))
-    assert float((a[1:] - ref).abs().max()) < 2e-4
+    assert float((a[1:] - ref).abs().max()) < 5e-5
 
 
 def test_psnr_ssim_tolerance(net, synth_sd):
@@ -103,7 +105,7 @@ def test_full_size_config2(net, synth_sd):
     dp = abs(calculate_psnr(tensor2img(a[0].cpu()), gt, 0, test_y_channel=True) - calculate_psnr(tensor2img(ref[0]), gt, 0, test_y_channel=True))
     ds = abs(calculate_ssim(tensor2img(a[0].cpu()), gt, 0, test_y_channel=True) - calculate_ssim(tensor2img(ref[0]), gt, 0, test_y_channel=True))
     print("config2 max-abs", err, "dPSNR", dp, "dSSIM", ds)
-    assert err < 5e-4 and dp <= 1e-3 and ds <= 1e-4
+    assert err < 5e-5 and dp <= 1e-3 and ds <= 1e-4
 
 
 def test_full_size_satu_linearity(net):

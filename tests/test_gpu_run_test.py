@@ -1,0 +1,201 @@
+"""YAML surface end to end on the GPU: a YAML in the reference's format -> DATASET_REGISTRY /
+MODEL_REGISTRY -> PNG folders -> GPU LR synthesis -> SAVSR.forward -> GPU PSNR-Y / SSIM-Y -> metric table + result PNGs,
+checked against the host metric path and the CPU oracle; plus the RCCL path on one rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from savsr_amd import io as sio
+from savsr_amd import metrics as M
+from savsr_amd.options import parse_test_options
+from savsr_amd.resize_gpu import as_mod_crop_hw
+from savsr_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+
+YAML = """
+name: test_SAVSR_synth
+model_type: ASVSRModel
+num_gpu: 1
+manual_seed: 0
+datasets:
+  test_01:
+    name: Vid4_x2
+    type: ASVideoTestDataset
+    dataroot_gt: {root}/GT
+    dataroot_lq: {root}/unused
+    io_backend:
+      type: disk
+    cache_data: false
+    num_frame: 7
+    padding: reflection
+    use_arbitrary_scale_downsampling: true
+    downsampling_scale: !!python/tuple [2, 2]
+    downsampling_mode: torch
+  test_02:
+    name: Vid4_x1.5_x2.5
+    type: ASVideoTestDataset
+    dataroot_gt: {root}/GT
+    dataroot_lq: {root}/unused
+    io_backend:
+      type: disk
+    cache_data: false
+    num_frame: 7
+    padding: reflection
+    use_arbitrary_scale_downsampling: true
+    downsampling_scale: !!python/tuple [1.5, 2.5]
+    downsampling_mode: torch
+network_g:
+  type: SAVSR
+  num_in_ch: 3
+  num_feat: 64
+  num_frame: 7
+  slid_win: 3
+  fusion_win: 5
+  interval: 0
+  w1_num_block: 4
+  w2_num_block: 2
+  n_resgroups: 4
+  n_resblocks: 8
+  center_frame_idx: ~
+path:
+  pretrain_network_g: {root}/savsr_synth.pth
+  strict_load_g: true
+  resume_state: ~
+  results_root: {root}/results
+val:
+  save_img: true
+  suffix: ~
+  metrics:
+    psnr_y:
+      type: calculate_psnr
+      crop_border: 0
+      test_y_channel: true
+    ssim_y:
+      type: calculate_ssim
+      crop_border: 0
+      test_y_channel: true
+"""
+
+FOLDERS = {"calendar": (5, 45, 62), "city": (4, 45, 62)}       # name -> (frames, H, W); a 7-frame reflection window needs >= 4 frames
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory, synth_sd):
+    root = str(tmp_path_factory.mktemp("savsr_run"))
+    for name, (n, H, W) in FOLDERS.items():
+        for i in range(n):
+            img = synth.synth_gt(3, H, W, seed=17 * len(name) + i)                     # [3, H, W] RGB in [0, 1]
+            sio.imwrite(M.tensor2img(img), os.path.join(root, "GT", name, f"{i:08d}.png"))
+    sd = {"params": {k: v.clone() for k, v in synth_sd.items()}}
+    torch.save(sd, os.path.join(root, "savsr_synth.pth"))
+    return root
+
+
+def _opt(root):
+    return parse_test_options(YAML.format(root=root), root_path=root)
+
+
+def test_run_test_yaml_to_metric_table(workdir, synth_sd):
+    from oracle import savsr_oracle as O
+    from savsr_amd.test import run_test
+    opt = _opt(workdir)
+    results = run_test(opt)
+    assert [r["dataset"] for r in results] == ["Vid4_x2", "Vid4_x1.5_x2.5"]
+    for r, ds in zip(results, opt["datasets"].values()):
+        sc = ds["downsampling_scale"]
+        assert r["scale"] == sc and set(r["metrics"]) == {"psnr_y", "ssim_y"} and set(r["folders"]) == set(FOLDERS)
+        per_folder = []
+        for name, (n, H, W) in FOLDERS.items():
+            Hc, Wc = as_mod_crop_hw(H, W, sc)
+            rows = r["frames"][name]
+            assert tuple(rows.shape) == (n, 2) and bool(torch.isfinite(rows).all())
+            for i in range(n):
+                # the reference's layout: results/<name>/visualization/<dataset>/<folder>/<img>_<name>.png (video_base_model.py:79-92)
+                p = os.path.join(workdir, "results", opt["name"], "visualization", r["dataset"], name, f"{i:08d}_{opt['name']}.png")
+                assert os.path.isfile(p), p
+                sr = sio.imread(p)
+                gt = sio.imread(os.path.join(workdir, "GT", name, f"{i:08d}.png"))[:Hc, :Wc]
+                assert sr.shape == gt.shape
+                # host metric path on the SAME quantised images == the GPU kernel's rows (stored as float32 like the reference's)
+                assert abs(M.calculate_psnr(sr, gt, 0, test_y_channel=True) - float(rows[i, 0])) < 1e-4
+                assert abs(M.calculate_ssim(sr, gt, 0, test_y_channel=True) - float(rows[i, 1])) < 1e-6
+            per_folder.append(rows.mean(0))
+            assert abs(r["folders"][name]["psnr_y"] - float(rows[:, 0].mean())) < 1e-5
+        total = torch.stack(per_folder).mean(0)                                          # mean over folders of per-folder means (:132-146)
+        assert abs(r["metrics"]["psnr_y"] - float(total[0])) < 1e-4 and abs(r["metrics"]["ssim_y"] - float(total[1])) < 1e-6
+    # one frame against the CPU oracle fed with torch-CPU LR synthesis (the arithmetic the reference's torchvision call runs)
+    sc = (1.5, 2.5)
+    name, (n, H, W) = "city", FOLDERS["city"]
+    Hc, Wc = as_mod_crop_hw(H, W, sc)
+    gt = sio.read_img_seq(os.path.join(workdir, "GT", name), require_as_mod_crop=True, scale=sc)
+    lq = torch.nn.functional.interpolate(gt, size=(round(Hc / sc[0]), round(Wc / sc[1])), mode="bicubic", align_corners=False, antialias=True)
+    from savsr_amd.harness import window_indices
+    with torch.no_grad():
+        ref = O.forward(synth_sd, lq[window_indices(1, n, 7)].unsqueeze(0), sc)
+    want = M.tensor2img(ref[0])
+    got = sio.imread(os.path.join(workdir, "results", opt["name"], "visualization", "Vid4_x1.5_x2.5", name, f"{1:08d}_{opt['name']}.png"))
+    assert want.shape == got.shape
+    d = np.abs(want.astype(np.int32) - got.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3, (d.max(), (d > 0).mean())      # only round-half ties may flip a level
+
+
+def test_post_resize_when_output_and_gt_differ(workdir):
+    """sr_model.py:290-294: bicubic + antialias resize of the output to the GT size (GPU kernel vs torch CPU)."""
+    from savsr_amd.models import build_model
+    opt = _opt(workdir)
+    model = build_model(opt)
+    g = torch.Generator().manual_seed(5)
+    out = torch.rand(1, 3, 41, 57, generator=g)
+    model.lq = torch.zeros(1, 7, 3, 8, 8, device="cuda")
+    model.gt = torch.zeros(1, 3, 38, 60, device="cuda")
+    model.output = out.cuda()
+    vis = model.get_current_visuals()
+    ref = torch.nn.functional.interpolate(out, size=(38, 60), mode="bicubic", align_corners=False, antialias=True)
+    assert tuple(vis["result"].shape) == (1, 3, 38, 60)
+    assert float((vis["result"].cpu() - ref).abs().max()) < 2e-6
+
+
+def test_unsupported_metric_config_raises(workdir):
+    from savsr_amd.models import build_model
+    from savsr_amd.datasets import build_dataset
+    opt = _opt(workdir)
+    opt["val"]["metrics"]["psnr_y"]["test_y_channel"] = False
+    model = build_model(opt)
+    with pytest.raises(NotImplementedError):
+        model.validation(build_dataset(opt["datasets"]["test_01"]), "x", None, False)
+
+
+def test_rccl_single_rank_gather(workdir):
+    """The RCCL branch on the one GPU available here: process group "nccl" with world_size 1, the metric rows go through
+    dist.all_gather_into_tensor (harness.gather_rows) and the table equals the non-distributed run's."""
+    import torch.distributed as dist
+    from savsr_amd.test import run_test
+    base = run_test(_opt(workdir))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from savsr_amd import harness
+        calls = []
+        orig = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            opt = _opt(workdir)
+            opt["dist"] = True
+            opt["val"]["save_img"] = False
+            got = run_test(opt)
+        finally:
+            dist.all_gather_into_tensor = orig
+        assert len(calls) == 2, "one collective per dataset"
+        for a, b in zip(base, got):
+            assert a["metrics"] == b["metrics"]
+            for f in a["frames"]:
+                assert torch.equal(a["frames"][f], b["frames"][f])
+    finally:
+        dist.destroy_process_group()

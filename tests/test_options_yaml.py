@@ -83,3 +83,36 @@ def test_reference_yaml_parses_unchanged(name):
     assert len(opt["datasets"]) == 42
     assert yaml_load(path)["model_type"] == "ASVSRModel"
     _check(opt)
+
+
+def _resolves(opt):
+    """`model_type` and every dataset `type` resolve through the registries (YAML surface)."""
+    assert savsr_amd.MODEL_REGISTRY.get(opt["model_type"]).__name__ == opt["model_type"]
+    for d in opt["datasets"].values():
+        assert savsr_amd.DATASET_REGISTRY.get(d["type"]).__name__ == d["type"]
+
+
+def test_sample_yaml_registry_resolution():
+    _resolves(parse_test_options(SAMPLE))
+    with pytest.raises(KeyError):
+        savsr_amd.MODEL_REGISTRY.get("NoSuchModel")
+
+
+@pytest.mark.parametrize("name", ["test_SAVSR_Vid4_asBI.yml", "test_SAVSR_UDM10_asBI.yml"])
+def test_reference_yaml_registry_resolution(name):
+    path = os.path.join("/root/reference/options/test/SAVSR", name)
+    if not os.path.isfile(path):
+        pytest.skip("reference tree not present")
+    _resolves(parse_test_options(path))
+
+
+def test_model_and_dataset_refuse_cpu():
+    """No CPU fallback behind the YAML surface either: without a GPU both constructors raise."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    opt = parse_test_options(SAMPLE)
+    with pytest.raises(RuntimeError):
+        savsr_amd.build_model(opt)
+    with pytest.raises(RuntimeError):
+        savsr_amd.build_dataset(opt["datasets"]["test_01"])

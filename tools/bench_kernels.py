@@ -49,18 +49,18 @@ def main():
         x, st = torch.randn(h, w, 64, generator=g).to(dev), torch.randn(h, w, 64, generator=g).to(dev)
         H, W = E.get_hw(h, w, (4, 4))
         plane = eng.hr_plane(H, W)
-        out = torch.empty(64, plane, device=dev)
-        run = lambda: eng.satu(eng.full(x), eng.full(st), w, h, w, (4, 4), out, plane)
+        out = torch.empty(27, plane, device=dev)          # the product (tail-projected) form: 27 planes
+        run = lambda: eng.satu_hr(eng.satu_lr(eng.full(x), eng.full(st), w, h, w, tail_form=True), h, w, (4, 4), out, plane, tail_form=True)
         flop = 0.0
     else:
         from savsr_amd import _lib
         H, W = 4 * h, 4 * w
         plane = eng.hr_plane(H, W)
-        feat = torch.randn(64, plane, device=dev)
+        feat = torch.randn(27, plane, device=dev)
         center = torch.rand(3, h, w, device=dev)
         out = torch.empty(3, H, W, device=dev)
-        run = lambda: _lib.check(eng.lib.savsr_tail_residual(feat.data_ptr(), plane, eng.tail_w.data_ptr(), eng.tail_b.data_ptr(),
-                                                             center.data_ptr(), h, w, H, W, out.data_ptr(), eng._stream()), "tail")
+        run = lambda: _lib.check(eng.lib.savsr_tail_gather(feat.data_ptr(), plane, eng.tail_b.data_ptr(),
+                                                           center.data_ptr(), h, w, H, W, out.data_ptr(), eng._stream()), "tail")
         flop = 0.0
     for _ in range(5):
         run()
@@ -132,12 +132,13 @@ def main():
         from savsr_amd import _lib
         sw = C.byref(eng.satu_w)
         ax = eng.satu_axes(h, w, (4, 4))
-        lrcat = eng.buf("satu.lrcat", h, w, _lib.SATU_LRCAT)
+        sw = C.byref(eng.satu_w_tail)
+        lrcat = eng.buf("satu.lrcat_tail", h, w, _lib.SATU_LRCAT_TAIL)
         for name, call, nb in (
-            ("LR", lambda: eng.lib.savsr_satu_lr_stage(sw, x.data_ptr(), st.data_ptr(), 64, w, h, w, lrcat.data_ptr(), eng._stream()), ((w + 31) // 32) * ((h + 7) // 8)),
-            ("HR", lambda: eng.lib.savsr_satu_hr_upsample(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
-                                                          ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), H, W, C.byref(ax["tiling"]), out.data_ptr(), plane, eng._stream()),
-             ((W + 31) // 32) * ((H + ax["tiling"].tile_rows - 1) // ax["tiling"].tile_rows))):
+            ("LR", lambda: eng.lib.savsr_satu_lr_stage_tail(sw, x.data_ptr(), st.data_ptr(), 64, w, h, w, lrcat.data_ptr(), eng._stream()), ((w + 31) // 32) * ((h + 7) // 8)),
+            ("HR", lambda: eng.lib.savsr_satu_hr_tail(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
+                                                          ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), H, W, C.byref(ax["tiling_tail"]), out.data_ptr(), plane, eng._stream()),
+             ((W + 31) // 32) * ((H + ax["tiling_tail"].tile_rows - 1) // ax["tiling_tail"].tile_rows))):
             eng.lib.savsr_debug_satu_stamps(1)
             call()
             torch.cuda.synchronize()
@@ -152,8 +153,8 @@ def main():
                   (tot.mean(), np.percentile(tot, 10), np.percentile(tot, 50), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), nb))
         for flag, nm in ((0, "normal"), (2, "no output stores (invalid results)")):
             eng.lib.savsr_debug_satu_stamps(flag)
-            hr = lambda: eng.lib.savsr_satu_hr_upsample(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
-                                                        ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), H, W, C.byref(ax["tiling"]), out.data_ptr(), plane, eng._stream())
+            hr = lambda: eng.lib.savsr_satu_hr_tail(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
+                                                        ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), H, W, C.byref(ax["tiling_tail"]), out.data_ptr(), plane, eng._stream())
             for _ in range(3):
                 hr()
             ev0.record()
@@ -163,7 +164,7 @@ def main():
             torch.cuda.synchronize()
             print("HR kernel alone, %s: %.1f us" % (nm, 1e2 * ev0.elapsed_time(ev1)))
         eng.lib.savsr_debug_satu_stamps(0)
-        t = ax["tiling"]
+        t = ax["tiling_tail"]
         print("HR tiling: rows", t.tile_rows, "cols32", t.tile_cols32, "window", t.lr_rows, "x", t.lr_cols)
     print(f"{a.what} cin={a.cin} cout={a.cout} ks={a.ks} {h}x{w}: {us:.2f} us/iter" + (f"  {flop / us / 1e6:.1f} TFLOP/s fp32-equivalent" if flop else ""))
 
