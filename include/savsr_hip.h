@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 12
+#define SAVSR_ABI_VERSION 15
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -167,6 +167,7 @@ int savsr_pack_windows(const float* lq, float* out, int T, int h, int w, int hp,
  *   out = G(Wa sta, soff) + G(Wb x, off) + sum_n r_n (Wb E_n) (sum_m r_m C_m G(x, off)) + b
  * in three launches:
  *   savsr_satu_phase_table : coordinate MLP (:344-350) on the DISTINCT (coor_h, coor_w) values
+ *   savsr_satu_expand_table: that table per HR pixel (both: once per size / scale / weights, not per frame)
  *   savsr_satu_lr_stage    : kernel_conv + LeakyReLU(0.1) + sta_conv (:226-228,297-313,319-320)
  *                            and the three LR-side projections -> LRcat [h][w][160]
  *   savsr_satu_hr_upsample : bilinear gathers (:262-295), expert mixing (:353-370), fusion (:374)
@@ -198,31 +199,42 @@ int savsr_satu_phase_table(const savsr_satu_weights* wt, const float* uniq_ch, i
 int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const float* st,
                         int32_t pix, int32_t row_px, int h, int w, float* lrcat, void* stream);
 
-/* Optional LDS staging plan of the HR stage (a pure performance hint; results never depend on it):
- * each workgroup owns tile_rows x (32 * tile_cols32) HR pixels and stages an lr_rows x lr_cols window
- * of LRcat records whose origin is the tile's base sampling coordinate + (off_min_x, off_min_y).
- * Waves whose taps leave the window gather from global memory instead.  NULL = no window staging.
- * The workgroup also stages its own tile_rows x (32 tile_cols32) slice of the phase table, so the
- * LDS need is savsr_satu_hr_lds_bytes(form, tile_rows, tile_cols32, lr_rows, lr_cols) <= 160 KiB
- * (two workgroups per CU need <= ~80 KiB each). */
+/* LDS staging plan of the HR stage (a pure performance hint; results never depend on it).  The HR kernel is persistent:
+ * its workgroups walk tiles of tile_rows x (32 * tile_cols32) HR pixels and, for each, stage an lr_rows x lr_cols window of
+ * LRcat records whose origin is the tile's base sampling coordinate + (off_min_x, off_min_y), double-buffered (the next tile's
+ * window arrives by LDS-DMA while the current tile is computed).  Waves whose taps leave the window gather from global
+ * memory instead.  NULL = 8 x 32 tiles without a window.  tile_rows must be a multiple of 4.  The LDS need is
+ * savsr_satu_hr_lds_bytes(form, n_uh * n_uw, tile_rows, tile_cols32, lr_rows, lr_cols) <= 160 KiB (one workgroup per CU). */
 typedef struct savsr_satu_tiling {
     int32_t tile_rows, tile_cols32, lr_rows, lr_cols;
     float   off_min_x, off_min_y;
-    int32_t table_entries;   /* n_uh * n_uw; informational (every table size takes the same path) */
+    int32_t table_entries;   /* n_uh * n_uw; informational */
     float   step_x, step_y;  /* LR pixels per HR pixel (1 / scale_w, 1 / scale_h) for the window origin; <= 0: w / W, h / H */
 } savsr_satu_tiling;
-int64_t savsr_satu_hr_lds_bytes(int tail_form, int tile_rows, int tile_cols32, int lr_rows, int lr_cols);
-/* resident workgroups per CU the HR kernel of a form is compiled for (plan tiles so that this many fit 160 KiB of LDS) */
+int64_t savsr_satu_hr_lds_bytes(int tail_form, int n_table, int tile_rows, int tile_cols32, int lr_rows, int lr_cols);
+/* resident workgroups per CU the HR kernel is written for (plan tiles so that this many fit 160 KiB of LDS) */
 int savsr_satu_hr_occupancy_target(int tail_form);
+/* compute waves of an HR workgroup: a tile of tile_rows x tile_cols32 "wave tiles" (one row x 32 pixels) is dealt over them */
+int savsr_satu_hr_compute_waves(void);
 
-/* gxn[W], gyn[H]: normalised base grid coordinates (savsr_arch.py:270-280) computed by the caller
- * in fp32; idx_h[H], idx_w[W]: index of each row/column's (coor_h, coor_w) value in the table.
- * out: [64] planes of [H][W], `out_plane` floats apart (>= H*W; a pitch that is not a multiple of a
- * few KiB keeps the 64 planes of one pixel on different HBM channels). */
+/* Per-pixel expansion of the phase table, once per (size, scale, weights): ptab[Y][X][8] = table[idx_h[Y]][idx_w[X]] with the
+ * two offset pairs normalised as the reference normalises them per pixel ((off * 2) / (size - 1), savsr_arch.py:285-287).
+ * Needed by the HR stage only for tables of more than 256 entries (smaller ones are kept whole in LDS). */
+int savsr_satu_expand_table(const float* table, int n_uw, const int32_t* idx_h, const int32_t* idx_w,
+                            int h, int w, int H, int W, float* ptab, void* stream);
+
+/* table[n_uh][n_uw][8]: savsr_satu_phase_table's output; idx_h[H], idx_w[W]: index of each row's / column's (coor_h, coor_w)
+ * value in it; gxn[W], gyn[H]: normalised base grid coordinates (savsr_arch.py:270-280) computed by the caller in fp32.
+ * These four arrays are read in 16-byte groups: 16-byte aligned and READABLE up to the next multiple of 4 elements.
+ * ptab: savsr_satu_expand_table's output (may be NULL when n_uh * n_uw <= 256).
+ * sched: 16 int32 of device scratch for the kernel's tile queue, ZERO-FILLED ONCE by the caller (the kernel leaves them zero) and
+ * not shared by launches that may run concurrently (one per stream); NULL = static tile walk (no scratch, ~10 % slower).
+ * out: [64] planes of [H][W], `out_plane` floats apart (>= H*W; a pitch that is not a multiple of a few KiB keeps the
+ * 64 planes of one pixel on different HBM channels). */
 int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w,
-                           const float* table, int n_uw, const int32_t* idx_h, const int32_t* idx_w,
+                           const float* table, int n_uh, int n_uw, const int32_t* idx_h, const int32_t* idx_w, const float* ptab,
                            const float* gyn, const float* gxn, int H, int W,
-                           const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream);
+                           const savsr_satu_tiling* tiling, int32_t* sched, float* out, int64_t out_plane, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tail-projected form of SATU + tail = savsr_arch.py:315-376 followed by :738-739, the form SAVSR.forward runs.
@@ -237,9 +249,9 @@ int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int
 int savsr_satu_lr_stage_tail(const savsr_satu_weights* wt, const float* x, const float* st,
                              int32_t pix, int32_t row_px, int h, int w, float* lrcat, void* stream);
 int savsr_satu_hr_tail(const savsr_satu_weights* wt, const float* lrcat, int h, int w,
-                       const float* table, int n_uw, const int32_t* idx_h, const int32_t* idx_w,
+                       const float* table, int n_uh, int n_uw, const int32_t* idx_h, const int32_t* idx_w, const float* ptab,
                        const float* gyn, const float* gxn, int H, int W,
-                       const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream);
+                       const savsr_satu_tiling* tiling, int32_t* sched, float* out, int64_t out_plane, void* stream);
 /* p27: [27] planes of [H][W], p_plane floats apart; center: [3][h][w]; out: [3][H][W] contiguous. */
 int savsr_tail_gather(const float* p27, int64_t p_plane, const float* tail_b, const float* center,
                       int h, int w, int H, int W, float* out, void* stream);

@@ -7,18 +7,23 @@
 # and fails the script (every background job is waited for by PID).
 #   OUT=<name>.so    library to link (default libsavsr_hip.so; experiment builds use their own name)
 #   OBJDIR=<dir>     where objects go (default: this directory)
+#   EXTRA_ONLY="a.hip b.hip"   apply EXTRA_FLAGS to these sources only (the others keep the base flags and their objects)
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function ${EXTRA_FLAGS:-}"
+BASE_FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
 OUT=${OUT:-libsavsr_hip.so}
 OBJDIR=${OBJDIR:-.}
 mkdir -p "$OBJDIR"
-SIG=$(printf '%s' "$HIPCC $FLAGS" | sha1sum | cut -d' ' -f1)
+
+flags_for() {  # flags_for <src>
+  if [ -z "${EXTRA_ONLY:-}" ] || [[ " ${EXTRA_ONLY} " == *" $1 "* ]]; then echo "$BASE_FLAGS ${EXTRA_FLAGS:-}"; else echo "$BASE_FLAGS"; fi
+}
+sig_for() { printf '%s' "$HIPCC $(flags_for "$1")" | sha1sum | cut -d' ' -f1; }
 
 stale() {   # stale <src> <obj>
   local src=$1 obj=$2
-  [ ! -f "$obj" ] || [ ! -f "$obj.flags" ] || [ "$(cat "$obj.flags")" != "$SIG" ] ||
+  [ ! -f "$obj" ] || [ ! -f "$obj.flags" ] || [ "$(cat "$obj.flags")" != "$(sig_for "$src")" ] ||
     [ "$src" -nt "$obj" ] || [ common.hpp -nt "$obj" ] || [ ../../include/savsr_hip.h -nt "$obj" ]
 }
 
@@ -26,9 +31,9 @@ compile() { # compile <src> <obj> [extra hipcc args]
   local src=$1 obj=$2
   shift 2
   rm -f "$obj" "$obj.flags"
-  if $HIPCC $FLAGS "$@" -c "$src" -o "$obj.tmp"; then
+  if $HIPCC $(flags_for "$src") "$@" -c "$src" -o "$obj.tmp"; then
     mv "$obj.tmp" "$obj"
-    printf '%s' "$SIG" > "$obj.flags"
+    printf '%s' "$(sig_for "$src")" > "$obj.flags"
   else
     rm -f "$obj.tmp"
     return 1

@@ -410,32 +410,44 @@ struct HrParams {
     savsr_satu_weights wt;
     const float* lrcat;
     int h, w;
-    const float* table;
-    int n_uw;
-    const int* idx_h;
+    const float* table;          // [n_table][8] raw phase table (savsr_satu_phase_table); kept whole in LDS when n_table <= HR_TABLE_LDS
+    int n_table, n_uw;
+    const int* idx_h;            // [H] / [W] (+ padding to a multiple of 4): table row / column of each HR row / column
     const int* idx_w;
-    const float* gyn;
+    const float* ptab;           // [H][W][8] per-pixel entries, offsets normalised (savsr_satu_expand_table); used when n_table > HR_TABLE_LDS
+    const float* gyn;            // [H] / [W] (+ padding to a multiple of 4)
     const float* gxn;
     int H, W;
     float* out;
     long long out_plane;         // floats between output channel planes (>= H*W)
-    int ty, txw, lrh, lrw;       // HR tile rows, 32-px column tiles per workgroup, staged LR window
+    int ty, txw, lrh, lrw;       // HR tile rows, 32-px column tiles per tile, staged LR window
     float omin_x, omin_y;        // lower bound of the sampling offsets (window origin)
     float step_x, step_y;        // LR pixels per HR pixel (1 / scale), for the window origin only
+    int ntx, nty;                // tiles per row / per column of the HR image
+    int* sched;                  // [16] tile-queue heads (one per XCD chunk) + exit count, all zero between launches; NULL: static walk
 };
 
 constexpr int HR_MAX_ROWS = 64;
+constexpr int HR_TABLE_LDS = 256;   // phase tables of up to this many entries live whole in LDS (x4: 16, x2: 4, x1.5 x 4: 76)
 __host__ __device__ constexpr int hr_lds_rec(int nb) { return rec_floats(nb) + 4; }       // floats per staged record
 __host__ __device__ constexpr int hr_wimg_floats(int nb) { return nb * 2 * 2 * 64 * 4; }  // (Wb E) image [t][ks][part][lane][8 bf16]
-// floats of LDS behind the window: image | bias [half][16 NB] (padded to 64) | table [ty][32 txw][8] | gyn [64] | gxn [32 txw] | idx_h [64] | idx_w [32 txw]
-__host__ __device__ inline int hr_const_floats(int nb, int ty, int txw) { return hr_wimg_floats(nb) + 64 + ty * 32 * txw * 8 + 2 * (HR_MAX_ROWS + 32 * txw); }
+// LDS of a workgroup, in floats: once  = image | bias [half][16 NB] (padded to 64) | whole table (small tables only)
+//                                per staging buffer (two of them) = window | tile slice of the per-pixel table (large tables only) |
+//                                gyn [64] | gxn [32 txw] | idx_h [64] | idx_w [32 txw] (small tables only)
+__host__ __device__ inline int hr_once_floats(int nb, bool small) { return hr_wimg_floats(nb) + 64 + 16 + (small ? HR_TABLE_LDS * SAVSR_SATU_TABLE : 0); }
+__host__ __device__ inline int hr_buf_floats(int nb, int ty, int txw, int lrh, int lrw, bool small) {
+    return lrh * lrw * hr_lds_rec(nb) + (small ? 0 : ty * 32 * txw * SAVSR_SATU_TABLE) + HR_MAX_ROWS + 32 * txw + (small ? HR_MAX_ROWS + 32 * txw : 0);
+}
 
 struct Taps {
-    int ty[4], tx[4];  // LR coordinates of the 4 taps (nw, ne, sw, se), clamped into the image
-    float wgt[4];      // bilinear weights, 0 for taps outside the image
+    int y0, x0;        // LR coordinates of the north-west tap, clamped into the image
+    int dy, dx;        // step to the southern / eastern taps: 1, or 0 where that neighbour is the same (clamped) pixel
+    float wgt[4];      // bilinear weights (nw, ne, sw, se), 0 for taps outside the image (zeros padding)
 };
 
-// onx, ony: the sampling offset already normalised as the reference does, (off * 2) / (size - 1)  (:285-287)
+// onx, ony: the sampling offset already normalised as the reference does, (off * 2) / (size - 1)  (:285-287).
+// An out-of-image tap contributes 0; its coordinate is clamped into the image (never widening the window a wave needs):
+// whatever record it then reads is finite data multiplied by a zero weight.
 __device__ __forceinline__ Taps make_taps(float gxn, float gyn, float onx, float ony, int h, int w) {
     const float fw1 = (float)(w - 1), fh1 = (float)(h - 1);
     const float gx = gxn + onx;
@@ -447,23 +459,26 @@ __device__ __forceinline__ Taps make_taps(float gxn, float gyn, float onx, float
     const float xw = floorf(ix), yn = floorf(iy);
     const float lx = ix - xw, ly = iy - yn;
     const float ex = 1.f - lx, sy = 1.f - ly;
-    const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
-    const bool vx0 = x0 >= 0 && x0 < w, vx1 = x1 >= 0 && x1 < w;
-    const bool vy0 = y0 >= 0 && y0 < h, vy1 = y1 >= 0 && y1 < h;
-    // an out-of-image tap contributes 0 (zeros padding); park it on its in-image neighbour so
-    // that it never widens the window a wave needs
-    const int cx0 = vx0 ? x0 : (vx1 ? x1 : (x0 < 0 ? 0 : w - 1)), cx1 = vx1 ? x1 : cx0;
-    const int cy0 = vy0 ? y0 : (vy1 ? y1 : (y0 < 0 ? 0 : h - 1)), cy1 = vy1 ? y1 : cy0;
+    const int x0 = (int)xw, y0 = (int)yn;
+    // per-axis weights with the validity folded in: the four products are the reference's (y weight) * (x weight) or exactly 0
+    const float wx0 = (unsigned)x0 < (unsigned)w ? ex : 0.f, wx1 = (unsigned)(x0 + 1) < (unsigned)w ? lx : 0.f;
+    const float wy0 = (unsigned)y0 < (unsigned)h ? sy : 0.f, wy1 = (unsigned)(y0 + 1) < (unsigned)h ? ly : 0.f;
     Taps t;
-    t.ty[0] = cy0; t.tx[0] = cx0; t.wgt[0] = (vy0 && vx0) ? sy * ex : 0.f;
-    t.ty[1] = cy0; t.tx[1] = cx1; t.wgt[1] = (vy0 && vx1) ? sy * lx : 0.f;
-    t.ty[2] = cy1; t.tx[2] = cx0; t.wgt[2] = (vy1 && vx0) ? ly * ex : 0.f;
-    t.ty[3] = cy1; t.tx[3] = cx1; t.wgt[3] = (vy1 && vx1) ? ly * lx : 0.f;
+    t.x0 = min(max(x0, 0), w - 1);
+    t.y0 = min(max(y0, 0), h - 1);
+    t.dx = min(max(x0 + 1, 0), w - 1) - t.x0;
+    t.dy = min(max(y0 + 1, 0), h - 1) - t.y0;
+    t.wgt[0] = wy0 * wx0; t.wgt[1] = wy0 * wx1; t.wgt[2] = wy1 * wx0; t.wgt[3] = wy1 * wx1;
     return t;
 }
 
 // acc[4g .. 4g+3] += w * v as two v_pk_fma_f32 (explicit 2-vectors: the SLP vectoriser packs only about half of these)
 __device__ __forceinline__ void fma_quad(f32x16& acc, int g, float w, const f32x4& v) {
+#if HR_SCALAR_FMA
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[4 * g + i] = __builtin_fmaf(w, v[i], acc[4 * g + i]);
+    return;
+#endif
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 w2 = {w, w};
     const f32x2 a01 = __builtin_elementwise_fma(w2, f32x2{v[0], v[1]}, f32x2{acc[4 * g], acc[4 * g + 1]});
@@ -475,13 +490,25 @@ template <bool FROM_LDS, int NB>
 __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int ly0, int lx0, const Taps& to, const Taps& ts,
                                         const f32x4 rr, int half, int lane, bool valid, unsigned o_off, const float* cst) {
     constexpr int REC = rec_floats(NB), LREC = hr_lds_rec(NB);
-    auto rec_of = [&](int ty, int tx) -> const f32x4* {
-        // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): window coordinates are tiny
-        if (FROM_LDS) return reinterpret_cast<const f32x4*>(lds + __mul24(__mul24(ty - ly0, p.lrw) + (tx - lx0), LREC));
-        return reinterpret_cast<const f32x4*>(p.lrcat + ((long long)ty * p.w + tx) * REC);
+    // the four records of a gather: north-west one + the (0 or 1) steps; 24-bit multiplies (full rate; v_mul_lo_u32 is quarter
+    // rate): window coordinates are tiny
+    auto recs = [&](const Taps& t, const f32x4* (&r)[4]) {
+        if (FROM_LDS) {
+            const float* b = lds + __mul24(__mul24(t.y0 - ly0, p.lrw) + (t.x0 - lx0), LREC);
+            const int sx = t.dx ? LREC : 0, sy = t.dy ? __mul24(p.lrw, LREC) : 0;
+            r[0] = reinterpret_cast<const f32x4*>(b); r[1] = reinterpret_cast<const f32x4*>(b + sx);
+            r[2] = reinterpret_cast<const f32x4*>(b + sy); r[3] = reinterpret_cast<const f32x4*>(b + sy + sx);
+        } else {
+            const float* b = p.lrcat + ((long long)t.y0 * p.w + t.x0) * REC;
+            const int sx = t.dx ? REC : 0, sy = t.dy ? p.w * REC : 0;
+            r[0] = reinterpret_cast<const f32x4*>(b); r[1] = reinterpret_cast<const f32x4*>(b + sx);
+            r[2] = reinterpret_cast<const f32x4*>(b + sy); r[3] = reinterpret_cast<const f32x4*>(b + sy + sx);
+        }
     };
-    const f32x4* ro[4] = {rec_of(to.ty[0], to.tx[0]), rec_of(to.ty[1], to.tx[1]), rec_of(to.ty[2], to.tx[2]), rec_of(to.ty[3], to.tx[3])};
-    const f32x4* rs[4] = {rec_of(ts.ty[0], ts.tx[0]), rec_of(ts.ty[1], ts.tx[1]), rec_of(ts.ty[2], ts.tx[2]), rec_of(ts.ty[3], ts.tx[3])};
+    const f32x4* ro[4];
+    const f32x4* rs[4];
+    recs(to, ro);
+    recs(ts, rs);
     // ---- the 32 compressed channels G(C x, off); t_j = sum_m r_m (C_m f0)_j -------------------------
     // Both lanes of a pixel need all 8 t_j: each computes 4 of them (j = 4 half .. 4 half + 3: half the LDS reads
     // and FMAs of this part) and the halves are exchanged with v_permlane32_swap.
@@ -585,163 +612,268 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
     }
 }
 
-#ifndef HR_OCC_TAIL
-#define HR_OCC_TAIL 3             // resident workgroups per CU the tail-projected kernel is compiled for (146 VGPRs: 3 waves per SIMD fit 168)
+#ifndef HR_SCALAR_FMA
+#define HR_SCALAR_FMA 0           // experiment: plain v_fma_f32 instead of v_pk_fma_f32 in the gathers
 #endif
-constexpr int HR_WAVES = 4;       // waves per workgroup (the kernel needs ~180-250 VGPRs: 2 waves per SIMD; at 128 it spills and runs 3.6x slower)
-// DIAG = the instrumented build (section stamps, no-store experiment); the product launch uses DIAG = false: kept as a
-// run-time switch the stamp accumulators cost ~30 vector instructions per tile in a VALU-issue-bound kernel.
+// ONE workgroup per CU: HR_WAVES compute waves (wave tiles are dealt round-robin over them) + HR_PRODUCERS producer waves that
+// only issue the next tile's LDS-DMAs.  A wave's gather chain is latency-bound (LDS round trips): alone on its SIMD a wave
+// needs ~4.1 k cycles per 32-pixel tile, three waves sharing a SIMD finish one every ~1.3 k, so the kernel wants as many
+// compute waves per SIMD as the register file holds (HR_MINW waves per SIMD <-> the VGPR cap the kernel is compiled for).
+// A producer wave gets ~4-5 LDS-DMAs in flight (one 1-KiB DMA per ~450 cycles, measured).
+#ifndef HR_WAVES
+#define HR_WAVES 8         // measured at 180x320 x4: 8 + 4 -> 42-44 us, 10 + 2 -> 43-46, 12 + 4 and 14 + 2 (128 VGPRs, spills) -> 47-58
+#endif
+#ifndef HR_PRODUCERS
+#define HR_PRODUCERS 4
+#endif
+#ifndef HR_MINW
+#define HR_MINW ((HR_WAVES + HR_PRODUCERS + 3) / 4)
+#endif
+constexpr int HR_THREADS = 64 * (HR_WAVES + HR_PRODUCERS);
+// One LDS-DMA: the active lanes move 16 B each, global (uniform 64-bit base in SGPRs + a 32-bit byte offset per lane) ->
+// lds_base + 16 * lane (no registers, no ds_write).  The scalar-base form keeps the whole address computation of a staging
+// loop on the scalar unit: with a per-lane 64-bit address every DMA cost ~40 vector instructions (quarter-rate 64-bit
+// multiply-adds, an integer division) and issuing a tile's ~18 DMAs took a wave 5 k cycles.
+// hipcc does not count these loads: the consumer waits with an explicit s_waitcnt vmcnt in front of its barrier.
+#define HR_DMA16(sbase, voff, lds_base) do { \
+        const unsigned dst_ = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_base)); \
+        const unsigned long long sb_ = (unsigned long long)(uintptr_t)(sbase); \
+        const unsigned sb_lo_ = __builtin_amdgcn_readfirstlane((unsigned)sb_), sb_hi_ = __builtin_amdgcn_readfirstlane((unsigned)(sb_ >> 32)); \
+        unsigned keep_; \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(voff), "s"((((unsigned long long)sb_hi_) << 32) | sb_lo_), "s"(dst_) : "memory"); \
+    } while (0)
+
+// PERSISTENT kernel: gridDim.x workgroups (a multiple of 8, `occupancy x CUs`) walk the HR tiles.
+//   * Tile order is XCD-aware: workgroups b, b + 8, b + 16, ... share an XCD (round-robin dispatch), so XCD x = b % 8 is given the
+//     x-th eighth of the row-major tile sequence and its workgroups take consecutive tiles of it: the LRcat band an XCD
+//     gathers from (1/8 of 22 MB + halos) stays in its own 4 MiB L2 and neighbouring tiles are staged at the same time.
+//     (Placement is a speed assumption only; results never depend on it.)
+//   * Staging is double-buffered and has its own wave: while the four compute waves gather the current tile from one LDS
+//     buffer, the PRODUCER waves (waves 4, 5) issue the LDS-DMAs of the next tile into the other (window records, its slice of the
+//     table, gyn / gxn / table indices -- every address is arithmetic on kernel arguments, on the scalar unit), waits for them
+//     (its vmcnt holds nothing else) and meets the compute waves at the one barrier per tile.  Measured before this split
+//     (DESIGN.md): staging alone 16-21 us, gathers + stores alone 37 us, together 50 us in a one-tile-per-workgroup kernel
+//     (workgroups launched together stage together), and 52-55 us with the compute waves issuing the DMAs themselves -- the
+//     CU's memory pipe queues them behind the output stores, ~200 cycles of issue stall per DMA, 3.7 k cycles per tile.
+// DIAG = the instrumented build (section stamps, timing experiments); the product launch uses DIAG = false.
 template <bool DIAG, int NB>
-__global__ __launch_bounds__(64 * HR_WAVES, NB == 1 ? HR_OCC_TAIL : 2) void satu_hr_kernel(const HrParams p) {
+__global__ __launch_bounds__(HR_THREADS, HR_MINW) void satu_hr_kernel(const HrParams p) {
     constexpr int REC = rec_floats(NB), LREC = hr_lds_rec(NB);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
-    const int X0 = blockIdx.x * 32 * p.txw, Y0 = blockIdx.y * p.ty;
-    const long long t_entry = DIAG ? SATU_T() : 0;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);      // tile walk and row / column tests as scalar code
     const int ncol = 32 * p.txw;
+    const bool small = p.n_table <= HR_TABLE_LDS;                 // (uniform) whole table in LDS vs per-pixel slices
+    const long long t_entry = DIAG ? SATU_T() : 0;
+    const long long rt_entry = DIAG ? (long long)__builtin_amdgcn_s_memrealtime() : 0;     // 100 MHz wall clock
 
-    // ---- stage the LRcat window of this tile, the expert-MFMA A operands, the bias and the tile's table entries -------
-    float* cst = lds + p.lrh * p.lrw * LREC;
-    float* tab = cst + hr_wimg_floats(NB) + 64;                   // [ty][ncol][8]
-    float* rowg = tab + p.ty * ncol * 8;                          // [HR_MAX_ROWS] gyn of the tile's rows
-    float* colg = rowg + HR_MAX_ROWS;                             // [ncol] gxn of the tile's columns
-    int* rowi = reinterpret_cast<int*>(colg + ncol);              // [HR_MAX_ROWS] table row of the tile's rows
-    int* coli = rowi + HR_MAX_ROWS;                               // [ncol] table column of the tile's columns
-    // (1) the per-row / per-column lookups: issued first, they land under the window's DMA issue
-    const int Yr = Y0 + tid < p.H ? Y0 + tid : p.H - 1;           // (threads >= ty load a valid address and drop the value)
-    const int Xr0 = X0 + tid < p.W ? X0 + tid : p.W - 1;
-    const int ih_v = p.idx_h[Yr];
-    const float gy_v = p.gyn[Yr];
-    const int iw_v = p.idx_w[Xr0];
-    const float gx_v = p.gxn[Xr0];
-    // (2) the window.  Its origin is the tile's base sampling coordinate + the lower bound of the offsets, evaluated from
-    // kernel arguments only (no load in front of the DMA issue); being a plan, it needs no bit-exactness (a wave whose
-    // taps fall outside gathers from global memory).
-    int ly0 = 0, lx0 = 0;
-    if (p.lrh > 0) {
-        const float by = ((float)Y0 + 0.5f) * p.step_y - 0.5f + p.omin_y - 0.01f;
-        const float bx = ((float)X0 + 0.5f) * p.step_x - 0.5f + p.omin_x - 0.01f;
-        ly0 = (int)floorf(fminf(fmaxf(by, 0.f), (float)(p.h - 1)));
-        lx0 = (int)floorf(fminf(fmaxf(bx, 0.f), (float)(p.w - 1)));
-        // one LDS-DMA per record: lanes 0 .. REC/4-1 move it straight into its padded slot (no registers, no
-        // ds_write, every record of the wave in flight at once; the register-staged loop this replaces was a third
-        // of the kernel).  Records outside the image are never read (taps are clamped into it) and stay unwritten.
-        const int nrec = p.lrh * p.lrw;
-        for (int r = wave; r < nrec; r += HR_WAVES) {
-            const int ry = r / p.lrw, rx = r - ry * p.lrw;
-            const int gy = ly0 + ry, gx = lx0 + rx;
-            if (gy < p.h && gx < p.w && lane < REC / 4) {
-                const float* src = p.lrcat + ((long long)gy * p.w + gx) * REC + 4 * lane;
-                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds + r * LREC));
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    // ---- this workgroup's tiles --------------------------------------------------------------------------------
+    const int ntile_img = p.ntx * p.nty;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int chunk0 = (int)(((long long)xcd * ntile_img) >> 3), chunk_n = (int)(((long long)(xcd + 1) * ntile_img) >> 3) - chunk0;
+    // Tile walk.  Static: tiles slot, slot + nslot, ... of the chunk.  Dynamic (p.sched): the first two tiles are the static ones
+    // (no atomic in front of the first DMAs), every later one comes from the chunk's queue head -- a workgroup that got cheap
+    // tiles (image borders) or a fast CU simply takes more, instead of every CU waiting for the one with ceil(tiles / CUs).
+    // The last workgroup to leave zeroes the heads again, so the caller zero-fills `sched` once, not per launch.
+    auto leave = [&]() {
+        if (p.sched && tid == 64 * HR_WAVES) {
+            const int old = __hip_atomic_fetch_add(p.sched + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (int)gridDim.x - 1) {
+                for (int i = 0; i < 9; ++i) __hip_atomic_store(p.sched + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-    }
-    if (tid < p.ty) { rowi[tid] = ih_v; rowg[tid] = gy_v; }
-    if (tid < ncol) { coli[tid] = iw_v; colg[tid] = gx_v; }
-    for (int e = tid + 64 * HR_WAVES; e < ncol; e += 64 * HR_WAVES) {           // (tiles wider than 256 columns)
-        const int Xc = X0 + e < p.W ? X0 + e : p.W - 1;
-        coli[e] = p.idx_w[Xc];
-        colg[e] = p.gxn[Xc];
-    }
-    {
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wt.wbe_w);
-        for (int e = tid; e < hr_wimg_floats(NB) / 4; e += 64 * HR_WAVES) reinterpret_cast<f32x4*>(cst)[e] = wsrc[e];
-        if (tid < 8 * NB) reinterpret_cast<f32x4*>(cst + hr_wimg_floats(NB))[tid] = reinterpret_cast<const f32x4*>(p.wt.fusion_b)[tid];
-    }
-    __syncthreads();
-    {
-        // (3) the tile's own slice of the phase table: entry (row, col) = table[idx_h[Y]][idx_w[X]]; the offset quad is normalised
-        // here, once per workgroup, as the reference does per pixel ((off * 2) / (size - 1), :285-287).  Four independent
-        // 16-B loads in flight per thread and round.
-        const float fw1 = (float)(p.w - 1), fh1 = (float)(p.h - 1);
-        const int nq = p.ty * ncol * 2;
-        for (int e0 = tid; e0 < nq; e0 += 4 * 64 * HR_WAVES) {
-            f32x4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * 64 * HR_WAVES;
-                const int ec = e < nq ? e : tid;                  // (clamped: loaded, not stored)
-                const int q = ec & 1, pe = ec >> 1;
-                const int trow = pe / ncol, col = pe - trow * ncol;
-                v[u] = *reinterpret_cast<const f32x4*>(p.table + ((long long)rowi[trow] * p.n_uw + coli[col]) * SAVSR_SATU_TABLE + 4 * q);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * 64 * HR_WAVES;
-                if (e < nq) {
-                    f32x4 t = v[u];
-                    if (e & 1) { t[0] = (t[0] * 2.f) / fw1; t[1] = (t[1] * 2.f) / fh1; t[2] = (t[2] * 2.f) / fw1; t[3] = (t[3] * 2.f) / fh1; }
-                    *reinterpret_cast<f32x4*>(tab + (e >> 1) * 8 + 4 * (e & 1)) = t;
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the window DMA (not counted by the compiler)
-    __syncthreads();
+    };
+    if (slot >= chunk_n) { leave(); return; }                     // (uniform) more workgroups than tiles
+
+    // ---- LDS carve-up -------------------------------------------------------------------------------------------
+    float* cst = lds;                                             // image | bias
+    int* ring = reinterpret_cast<int*>(cst + hr_wimg_floats(NB) + 64);   // [4] tile ids handed out by the queue (dynamic walk)
+    float* tabl = cst + hr_wimg_floats(NB) + 64 + 16;             // whole table, offsets normalised (small tables)
+    const int once = hr_once_floats(NB, small), bufsz = hr_buf_floats(NB, p.ty, p.txw, p.lrh, p.lrw, small);
+    const int win_floats = p.lrh * p.lrw * LREC, slice_floats = small ? 0 : p.ty * ncol * SAVSR_SATU_TABLE;
 
     const int dbg_all = DIAG ? __builtin_amdgcn_readfirstlane(g_satu_stamps_on) : 0;
     const int stamps_on = dbg_all & 1;
-    const bool dbg_nostore = dbg_all & 2;                            // timing experiment only: skip the output stores
-    long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long t_prev = stamps_on ? SATU_T() : 0;
-    const long long t_begin = t_entry;
-    tacc[4] = t_prev - t_entry;                                      // staging of the LDS window + constants
-#define HR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
-    const int ntile = p.ty * p.txw;
-    // No global load may be pending, as far as hipcc can tell, when the tile loop is entered or continued: its waits count only
-    // what it can see on every path, so one conditional load in the loop (or one issued in front of it) turns into
-    // s_waitcnt vmcnt(0..1) at the top of EVERY tile -- behind the previous tile's output stores, i.e. a full write
-    // round trip per tile.  Everything a tile looks up is therefore in LDS.
-    for (int T = wave_s; T < ntile; T += HR_WAVES) {
-        const int trow = p.txw == 1 ? T : T / p.txw;                // (a run-time integer division is ~14 vector instructions)
-        const int tcol = T - trow * p.txw;
-        const int Y = Y0 + trow;
-        const int Xb = X0 + tcol * 32;
-        if (Y >= p.H || Xb >= p.W) continue;                      // wave-uniform
-        const int X = Xb + px;
-        const bool valid = X < p.W && !dbg_nostore;
-        const float* te = tab + (trow * ncol + tcol * 32 + px) * 8;
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
-        const f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
-        const float gxn = colg[tcol * 32 + px];
-        const float gyn = rowg[trow];
-        if (stamps_on) { asm volatile("" :: "v"(rr[0]), "v"(oo[0])); }
-        HR_MARK(0);                                                  // table lookup
-        const Taps to = make_taps(gxn, gyn, oo[0], oo[1], p.h, p.w);
-        const Taps ts = make_taps(gxn, gyn, oo[2], oo[3], p.h, p.w);
-        if (stamps_on) { asm volatile("" :: "v"(to.wgt[3]), "v"(ts.wgt[3])); }
-        HR_MARK(1);                                                  // tap arithmetic
+    const bool dbg_nostore = dbg_all & 2, dbg_stage_only = dbg_all & 4, dbg_nostage = dbg_all & 8;     // timing experiments (results invalid)
 
-        bool inside = p.lrh > 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            inside = inside && (unsigned)(to.ty[k] - ly0) < (unsigned)p.lrh && (unsigned)(to.tx[k] - lx0) < (unsigned)p.lrw;
-            inside = inside && (unsigned)(ts.ty[k] - ly0) < (unsigned)p.lrh && (unsigned)(ts.tx[k] - lx0) < (unsigned)p.lrw;
+    // window origin of a tile: its base sampling coordinate + the lower bound of the offsets, evaluated from kernel arguments
+    // only; being a plan, it needs no bit-exactness (a wave whose taps fall outside gathers from global memory)
+    // (the window is then shifted back inside the image: every staged record exists, so the DMAs need no per-record test)
+    auto origin = [&](int Y0, int X0, int& ly0, int& lx0) {
+        const float by = ((float)Y0 + 0.5f) * p.step_y - 0.5f + p.omin_y - 0.01f;
+        const float bx = ((float)X0 + 0.5f) * p.step_x - 0.5f + p.omin_x - 0.01f;
+        const int iy = (int)floorf(fminf(fmaxf(by, 0.f), (float)(p.h - 1)));
+        const int ix = (int)floorf(fminf(fmaxf(bx, 0.f), (float)(p.w - 1)));
+        ly0 = __builtin_amdgcn_readfirstlane(iy < p.h - p.lrh ? iy : p.h - p.lrh);
+        lx0 = __builtin_amdgcn_readfirstlane(ix < p.w - p.lrw ? ix : p.w - p.lrw);
+    };
+    // every DMA of one tile into staging buffer `buf`, dealt over the producer waves
+    const unsigned lane16 = 16u * (unsigned)lane;
+    const bool producer = wave_s >= HR_WAVES;                      // (uniform per wave)
+    const int pk = wave_s - HR_WAVES;                              // producer index
+    auto stage = [&](int tile, float* buf) {
+        if (dbg_nostage) return;
+        const int tyi = tile / p.ntx, txi = tile - tyi * p.ntx;
+        const int Y0 = tyi * p.ty, X0 = txi * ncol;
+        if (p.lrh > 0) {
+            int ly0, lx0;
+            origin(Y0, X0, ly0, lx0);
+            // The window is a linear array of padded records (REC / 4 data chunks of 16 B + one pad chunk: the pitch that keeps
+            // the b128 gathers conflict-free), filled by FULL 1-KiB DMAs: lane i of DMA j owns LDS chunk q = 64 j + i, i.e.
+            // chunk q % CHP of record q / CHP, and fetches it from its record's place in LRcat (the pad chunk's lane sits out).
+            // One DMA per record (24 of 64 lanes) needed 2.7x as many DMAs, and a DMA costs its wave ~250 cycles whatever its size.
+            constexpr int CHP = REC / 4 + 1;
+            const int nq = p.lrh * p.lrw * CHP;
+            const float* sbase = p.lrcat + ((long long)ly0 * p.w + lx0) * REC;
+            for (int j = pk; j * 64 < nq; j += HR_PRODUCERS) {
+                const int q = j * 64 + lane;
+                const int rec = q / CHP, c = q - rec * CHP;
+                const int ry = rec / p.lrw, rx = rec - ry * p.lrw;
+                if (q < nq && c < REC / 4) HR_DMA16(sbase, (unsigned)(((ry * p.w + rx) * REC + 4 * c) * 4), buf + j * 256);
+            }
         }
-        // byte offset of this lane's pixel inside channel plane acc_row(r, 0); the half's +4 channels are folded in
-        const unsigned o_off = 4u * (unsigned)(Y * p.W + X) + (half ? 16u * (unsigned)p.out_plane : 0u);
-        if (__all(inside)) hr_tile<true, NB>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
-        else {
-            hr_tile<false, NB>(p, lds, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
-            __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the fallback's gathers are not left pending either (see above the loop)
+        float* slice = buf + win_floats;
+        float* rowg = slice + slice_floats;
+        float* colg = rowg + HR_MAX_ROWS;
+        if (!small) {
+            // the tile's slice of the per-pixel table: one DMA (1 KiB = 32 entries of 32 B) per (tile row, 32-pixel column tile)
+            for (int trow = pk; trow < p.ty; trow += HR_PRODUCERS) {
+                const int Yc = Y0 + trow < p.H ? Y0 + trow : p.H - 1;
+                for (int tcol = 0; tcol < p.txw; ++tcol) {
+                    const int Xb = X0 + tcol * 32;
+                    if (Xb + (lane >> 1) < p.W) HR_DMA16(p.ptab + ((long long)Yc * p.W + Xb) * SAVSR_SATU_TABLE, lane16, slice + (trow * ncol + tcol * 32) * 8);
+                }
+            }
         }
-        HR_MARK(2);                                                  // gathers + MFMA + store issue
-    }
-    if (stamps_on) {
-        __builtin_amdgcn_s_waitcnt(0);
-        HR_MARK(3);                                                  // store drain
-        if (tid == 0) {
-            const int b = blockIdx.x + gridDim.x * blockIdx.y;
-            if (b < SSTAMP_BLOCKS) {
-                for (int i = 0; i < 7; ++i) g_satu_stamps[b * SSTAMP_N + i] = tacc[i];
-                g_satu_stamps[b * SSTAMP_N + 7] = SATU_T() - t_begin;
+        // per-row / per-column scalars, 4 per lane (the arrays are padded to a multiple of 4 elements by the caller)
+        const int H4 = (p.H + 3) & ~3, W4 = (p.W + 3) & ~3;
+        if (pk == 0) {
+            if (4 * lane < p.ty && Y0 + 4 * lane < H4) HR_DMA16(p.gyn + Y0, lane16, rowg);
+            if (4 * lane < ncol && X0 + 4 * lane < W4) HR_DMA16(p.gxn + X0, lane16, colg);
+        }
+        if (small && pk == HR_PRODUCERS - 1) {
+            int* rowi = reinterpret_cast<int*>(colg + ncol);
+            int* coli = rowi + HR_MAX_ROWS;
+            if (4 * lane < p.ty && Y0 + 4 * lane < H4) HR_DMA16(p.idx_h + Y0, lane16, rowi);
+            if (4 * lane < ncol && X0 + 4 * lane < W4) HR_DMA16(p.idx_w + X0, lane16, coli);
+        }
+    };
+
+    // ---- prologue: first tile's DMAs, then the once-per-workgroup constants under them --------------------------
+    float* buf_cur = lds + once;
+    float* buf_nxt = buf_cur + bufsz;
+    int idx = slot;                                                // index of the current tile inside the chunk
+    int idx_n = slot + nslot;                                      // ... of the next one (>= chunk_n: none)
+    if (producer) stage(chunk0 + idx, buf_cur);
+    else {
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wt.wbe_w);
+        for (int e = tid; e < hr_wimg_floats(NB) / 4; e += 64 * HR_WAVES) reinterpret_cast<f32x4*>(cst)[e] = wsrc[e];
+        if (tid < 8 * NB) reinterpret_cast<f32x4*>(cst + hr_wimg_floats(NB))[tid] = reinterpret_cast<const f32x4*>(p.wt.fusion_b)[tid];
+        if (small) {
+            const float fw1 = (float)(p.w - 1), fh1 = (float)(p.h - 1);
+            for (int e = tid; e < p.n_table * 2; e += 64 * HR_WAVES) {
+                f32x4 v = reinterpret_cast<const f32x4*>(p.table)[e];
+                if (e & 1) {               // the offset quad: normalised once here, as the reference does per pixel ((off * 2) / (size - 1), :285-287)
+                    v[0] = (v[0] * 2.f) / fw1; v[1] = (v[1] * 2.f) / fh1; v[2] = (v[2] * 2.f) / fw1; v[3] = (v[3] * 2.f) / fh1;
+                }
+                reinterpret_cast<f32x4*>(tabl)[e] = v;
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_prev = stamps_on ? SATU_T() : 0;
+    tacc[4] = t_prev - t_entry;                                      // prologue (stamps are written by wave 0, a compute wave)
+#define HR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+    const int ntile = p.ty * p.txw;
+    for (int it = 0;; ++it) {
+        const int tile = chunk0 + idx;
+        if (producer) {
+            if (idx_n < chunk_n) stage(chunk0 + idx_n, buf_nxt);      // next tile's DMAs fly under this tile's gathers
+            if (p.sched && tid == 64 * HR_WAVES)                      // the tile after that: one queue pop per iteration
+                ring[(it + 2) & 3] = 2 * nslot + __hip_atomic_fetch_add(p.sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (these waves issue nothing else on vmcnt)
+        } else {
+        const int tyi = tile / p.ntx, txi = tile - tyi * p.ntx;
+        const int Y0 = tyi * p.ty, X0 = txi * ncol;
+        int ly0 = 0, lx0 = 0;
+        if (p.lrh > 0) origin(Y0, X0, ly0, lx0);
+        const float* slice = buf_cur + win_floats;
+        const float* rowg = slice + slice_floats;
+        const float* colg = rowg + HR_MAX_ROWS;
+        const int* rowi = reinterpret_cast<const int*>(colg + ncol);
+        const int* coli = rowi + HR_MAX_ROWS;
+        if (!dbg_stage_only)
+        for (int T = wave_s; T < ntile; T += HR_WAVES) {
+            const int trow = p.txw == 1 ? T : T / p.txw;                // (a run-time integer division is ~14 vector instructions)
+            const int tcol = T - trow * p.txw;
+            const int Y = Y0 + trow;
+            const int Xb = X0 + tcol * 32;
+            if (Y >= p.H || Xb >= p.W) continue;                      // wave-uniform
+            const int X = Xb + px;
+            const bool valid = X < p.W && !dbg_nostore;
+            // everything a tile looks up is in LDS: no global load is pending, as far as hipcc can tell, anywhere in this loop
+            // (one would turn into s_waitcnt vmcnt(0..1) behind the previous tile's output stores: a write round trip per tile)
+            const float* te = small ? tabl + (rowi[trow] * p.n_uw + coli[tcol * 32 + px]) * SAVSR_SATU_TABLE
+                                    : slice + (trow * ncol + tcol * 32 + px) * SAVSR_SATU_TABLE;
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
+            const f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
+            const float gxn = colg[tcol * 32 + px];
+            const float gyn = rowg[trow];
+            const Taps to = make_taps(gxn, gyn, oo[0], oo[1], p.h, p.w);
+            const Taps ts = make_taps(gxn, gyn, oo[2], oo[3], p.h, p.w);
+            // all 8 taps inside the staged window?  (unsigned compare: below the origin wraps to a huge value)
+            const bool inside = p.lrh > 0 &&
+                (unsigned)(to.y0 - ly0) < (unsigned)(p.lrh - to.dy) && (unsigned)(to.x0 - lx0) < (unsigned)(p.lrw - to.dx) &&
+                (unsigned)(ts.y0 - ly0) < (unsigned)(p.lrh - ts.dy) && (unsigned)(ts.x0 - lx0) < (unsigned)(p.lrw - ts.dx);
+            // byte offset of this lane's pixel inside channel plane acc_row(r, 0); the half's +4 channels are folded in
+            const unsigned o_off = 4u * (unsigned)(Y * p.W + X) + (half ? 16u * (unsigned)p.out_plane : 0u);
+            if (__all(inside)) hr_tile<true, NB>(p, buf_cur, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
+            else {
+                hr_tile<false, NB>(p, buf_cur, ly0, lx0, to, ts, rr, half, lane, valid, o_off, cst);
+                __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the fallback's gathers are not left pending (see above)
+            }
+        }
+        }
+        HR_MARK(2);                                                  // compute waves: gathers + MFMA + store issue; producer: DMA issue + landing
+        if (idx_n >= chunk_n) break;                                  // (uniform) last tile
+        __syncthreads();                                              // buffer hand-over: the staged tile is complete, the computed one is free
+        HR_MARK(3);                                                  // barrier
+        float* t_ = buf_cur; buf_cur = buf_nxt; buf_nxt = t_;
+        idx = idx_n;
+        idx_n = p.sched ? ring[(it + 2) & 3] : idx + nslot;
+    }
+    leave();
+    if (stamps_on) {
+        __builtin_amdgcn_s_waitcnt(0);
+        if (tid == 0 && blockIdx.x < SSTAMP_BLOCKS) {
+            for (int i = 0; i < 5; ++i) g_satu_stamps[blockIdx.x * SSTAMP_N + i] = tacc[i];
+            g_satu_stamps[blockIdx.x * SSTAMP_N + 5] = rt_entry;                                     // wall-clock start / end (100 MHz ticks)
+            g_satu_stamps[blockIdx.x * SSTAMP_N + 6] = (long long)__builtin_amdgcn_s_memrealtime();
+            g_satu_stamps[blockIdx.x * SSTAMP_N + 7] = SATU_T() - t_entry;
+        }
+    }
+}
+
+// Per-pixel expansion of the phase table, once per (size, scale, weights): ptab[Y][X] = table[idx_h[Y]][idx_w[X]] with the two
+// offset pairs normalised exactly as the reference normalises them per pixel ((off * 2) / (size - 1), savsr_arch.py:285-287).
+// The HR stage then stages a tile's entries with address arithmetic only (no index -> entry dependency in its prologue).
+__global__ __launch_bounds__(256) void satu_expand_table_kernel(const float* __restrict__ table, int n_uw, const int* __restrict__ idx_h,
+                                                                const int* __restrict__ idx_w, int h, int w, int H, int W, float* __restrict__ ptab) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;           // one 16-B half of an entry per thread
+    if (e >= (long long)H * W * 2) return;
+    const int q = (int)(e & 1);
+    const long long px = e >> 1;
+    const int Y = (int)(px / W), X = (int)(px - (long long)Y * W);
+    f32x4 v = *reinterpret_cast<const f32x4*>(table + ((long long)idx_h[Y] * n_uw + idx_w[X]) * SAVSR_SATU_TABLE + 4 * q);
+    if (q) {
+        const float fw1 = (float)(w - 1), fh1 = (float)(h - 1);
+        v[0] = (v[0] * 2.f) / fw1; v[1] = (v[1] * 2.f) / fh1; v[2] = (v[2] * 2.f) / fw1; v[3] = (v[3] * 2.f) / fh1;
+    }
+    *reinterpret_cast<f32x4*>(ptab + e * 4) = v;
 }
 
 }  // namespace savsr
@@ -756,12 +888,13 @@ extern "C" int savsr_debug_satu_stamps(int enable) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
-extern "C" int savsr_satu_hr_occupancy_target(int tail_form) { return tail_form ? HR_OCC_TAIL : 2; }
+extern "C" int savsr_satu_hr_occupancy_target(int tail_form) { (void)tail_form; return 1; }
+extern "C" int savsr_satu_hr_compute_waves(void) { return HR_WAVES; }
 
 // Diagnostics: resident workgroups per CU the runtime predicts for the HR / LR kernels (tail-projected form) with `lds_bytes` of dynamic LDS.
 extern "C" int savsr_debug_satu_occupancy(int which, int lds_bytes) {
     int n = -1;
-    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel<false, 1>, 64 * HR_WAVES, (size_t)lds_bytes)
+    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel<false, 1>, HR_THREADS, (size_t)lds_bytes)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_kernel<false, 1>, 512, (size_t)lds_bytes);
     return e == hipSuccess ? n : -(int)e;
 }
@@ -820,57 +953,84 @@ extern "C" int savsr_satu_lr_stage_tail(const savsr_satu_weights* wt, const floa
     return lr_stage<1>(wt, x, st, pix, row_px, h, w, lrcat, stream);
 }
 
-extern "C" int64_t savsr_satu_hr_lds_bytes(int tail_form, int tile_rows, int tile_cols32, int lr_rows, int lr_cols) {
-    if (tile_rows < 1 || tile_rows > HR_MAX_ROWS || tile_cols32 < 1 || lr_rows < 0 || lr_cols < 0) return -1;
+extern "C" int64_t savsr_satu_hr_lds_bytes(int tail_form, int n_table, int tile_rows, int tile_cols32, int lr_rows, int lr_cols) {
+    if (tile_rows < 1 || tile_rows > HR_MAX_ROWS || tile_cols32 < 1 || lr_rows < 0 || lr_cols < 0 || n_table < 1) return -1;
     const int nb = tail_form ? 1 : 2;
-    return ((int64_t)lr_rows * lr_cols * hr_lds_rec(nb) + hr_const_floats(nb, tile_rows, tile_cols32)) * (int64_t)sizeof(float);
+    const bool small = n_table <= HR_TABLE_LDS;
+    return ((int64_t)hr_once_floats(nb, small) + 2 * (int64_t)hr_buf_floats(nb, tile_rows, tile_cols32, lr_rows, lr_cols, small)) * (int64_t)sizeof(float);
+}
+
+extern "C" int savsr_satu_expand_table(const float* table, int n_uw, const int32_t* idx_h, const int32_t* idx_w, int h, int w, int H, int W,
+                                       float* ptab, void* stream) {
+    if (!table || !idx_h || !idx_w || !ptab) return fail_arg("satu_expand_table: null pointer");
+    if (h < 2 || w < 2 || H < 1 || W < 1 || n_uw < 1) return fail_arg("satu_expand_table: shape");
+    if ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(ptab)) & 15) {
+        set_error("satu_expand_table: table / ptab must be 16-byte aligned");
+        return SAVSR_E_ALIGN;
+    }
+    const long long n = (long long)H * W * 2;
+    hipLaunchKernelGGL(satu_expand_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), table, n_uw,
+                       idx_h, idx_w, h, w, H, W, ptab);
+    return check_launch("satu_expand_table_kernel");
 }
 
 template <int NB>
-static int hr_stage(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uw, const int32_t* idx_h,
-                    const int32_t* idx_w, const float* gyn, const float* gxn, int H, int W, const savsr_satu_tiling* tiling, float* out,
-                    int64_t out_plane, void* stream) {
+static int hr_stage(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uh, int n_uw, const int32_t* idx_h,
+                    const int32_t* idx_w, const float* ptab, const float* gyn, const float* gxn, int H, int W, const savsr_satu_tiling* tiling,
+                    int32_t* sched, float* out, int64_t out_plane, void* stream) {
     if (!satu_weights_ok(wt) || !lrcat || !table || !idx_h || !idx_w || !gyn || !gxn || !out) return fail_arg("satu_hr: null pointer");
-    if (h < 2 || w < 2 || H < 1 || W < 1 || n_uw < 1 || out_plane < (int64_t)H * W) return fail_arg("satu_hr: shape (h, w >= 2, out_plane >= H*W required)");
+    if (h < 2 || w < 2 || H < 1 || W < 1 || n_uh < 1 || n_uw < 1 || out_plane < (int64_t)H * W) return fail_arg("satu_hr: shape (h, w >= 2, out_plane >= H*W required)");
     if (out_plane * 32 * NB * 4 >= ((int64_t)1 << 32)) return fail_arg("satu_hr: output of 4 GiB or more is not supported (32-bit store offsets)");
-    if ((reinterpret_cast<uintptr_t>(lrcat) | reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(wt->fusion_b) |
-         reinterpret_cast<uintptr_t>(wt->wbe_w)) & 15) {
-        set_error("satu_hr: lrcat / table / fusion_b / wbe_w must be 16-byte aligned");
+    const bool small = (int64_t)n_uh * n_uw <= HR_TABLE_LDS;
+    if (!small && !ptab) return fail_arg("satu_hr: tables of more than 256 entries need the per-pixel expansion (savsr_satu_expand_table)");
+    if ((reinterpret_cast<uintptr_t>(lrcat) | reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(ptab) | reinterpret_cast<uintptr_t>(wt->fusion_b) |
+         reinterpret_cast<uintptr_t>(wt->wbe_w) | reinterpret_cast<uintptr_t>(gyn) | reinterpret_cast<uintptr_t>(gxn) | reinterpret_cast<uintptr_t>(idx_h) |
+         reinterpret_cast<uintptr_t>(idx_w)) & 15) {
+        set_error("satu_hr: lrcat / table / ptab / fusion_b / wbe_w / gyn / gxn / idx_h / idx_w must be 16-byte aligned");
         return SAVSR_E_ALIGN;
     }
     HrParams p;
-    p.wt = *wt; p.lrcat = lrcat; p.h = h; p.w = w; p.table = table; p.n_uw = n_uw; p.idx_h = idx_h; p.idx_w = idx_w;
-    p.gyn = gyn; p.gxn = gxn; p.H = H; p.W = W; p.out = out; p.out_plane = out_plane;
+    p.wt = *wt; p.lrcat = lrcat; p.h = h; p.w = w; p.table = table; p.n_table = small ? n_uh * n_uw : (1 << 30); p.n_uw = n_uw;
+    p.idx_h = idx_h; p.idx_w = idx_w; p.ptab = ptab;
+    p.gyn = gyn; p.gxn = gxn; p.H = H; p.W = W; p.out = out; p.out_plane = out_plane; p.sched = sched;
     p.ty = 8; p.txw = 1; p.lrh = 0; p.lrw = 0; p.omin_x = 0.f; p.omin_y = 0.f;      // default: no window staging, gathers from global
     p.step_x = (float)w / (float)W; p.step_y = (float)h / (float)H;
     if (tiling) {
-        if (tiling->tile_rows < 1 || tiling->tile_rows > HR_MAX_ROWS || tiling->tile_cols32 < 1 || tiling->tile_cols32 > 8 || tiling->lr_rows < 0 ||
-            tiling->lr_cols < 0)
-            return fail_arg("satu_hr: tiling");
+        if (tiling->tile_rows < 4 || tiling->tile_rows > HR_MAX_ROWS || (tiling->tile_rows & 3) || tiling->tile_cols32 < 1 || tiling->tile_cols32 > 8 ||
+            tiling->lr_rows < 0 || tiling->lr_cols < 0)
+            return fail_arg("satu_hr: tiling (tile_rows a multiple of 4 in 4..64, tile_cols32 in 1..8)");
         p.ty = tiling->tile_rows; p.txw = tiling->tile_cols32; p.lrh = tiling->lr_rows; p.lrw = tiling->lr_cols;
         p.omin_x = tiling->off_min_x; p.omin_y = tiling->off_min_y;
         if (tiling->step_x > 0.f && tiling->step_y > 0.f) { p.step_x = tiling->step_x; p.step_y = tiling->step_y; }
-        if (p.lrh == 0 || p.lrw == 0) { p.lrh = 0; p.lrw = 0; }
+        if (p.lrh == 0 || p.lrw < 2) { p.lrh = 0; p.lrw = 0; }
+        if (p.lrh > h || p.lrw > w) return fail_arg("satu_hr: tiling (the LR window must fit the LR image: lr_rows <= h, lr_cols <= w)");
     }
-    const size_t lds = ((size_t)p.lrh * p.lrw * hr_lds_rec(NB) + hr_const_floats(NB, p.ty, p.txw)) * sizeof(float);
-    if (lds > 160 * 1024) return fail_arg("satu_hr: staged window + tile tables exceed 160 KiB of LDS");
+    p.ntx = (W + 32 * p.txw - 1) / (32 * p.txw);
+    p.nty = (H + p.ty - 1) / p.ty;
+    const size_t lds = ((size_t)hr_once_floats(NB, small) + 2 * (size_t)hr_buf_floats(NB, p.ty, p.txw, p.lrh, p.lrw, small)) * sizeof(float);
+    if (lds > 160 * 1024) return fail_arg("satu_hr: staged windows + tile tables exceed 160 KiB of LDS");
     const bool diag = NB == 1 && g_satu_diag_host;
     const void* fn = diag ? reinterpret_cast<const void*>(&satu_hr_kernel<true, 1>) : reinterpret_cast<const void*>(&satu_hr_kernel<false, NB>);
     if (int rc = ensure_dynamic_lds(fn, 160 * 1024, "satu_hr")) return rc;
-    dim3 grid((W + 32 * p.txw - 1) / (32 * p.txw), (H + p.ty - 1) / p.ty);
-    if (diag) hipLaunchKernelGGL((satu_hr_kernel<true, 1>), grid, dim3(64 * HR_WAVES), lds, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL((satu_hr_kernel<false, NB>), grid, dim3(64 * HR_WAVES), lds, static_cast<hipStream_t>(stream), p);
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    long long ntile = (long long)p.ntx * p.nty;
+    int grid = ncu;                                                    // one fat workgroup per CU
+    if (grid > ntile) grid = (int)ntile;
+    grid = (grid + 7) & ~7;                                            // the XCD split needs a multiple of 8
+    if (diag) hipLaunchKernelGGL((satu_hr_kernel<true, 1>), dim3(grid), dim3(HR_THREADS), lds, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL((satu_hr_kernel<false, NB>), dim3(grid), dim3(HR_THREADS), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_hr_kernel");
 }
 
-extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uw,
-                                      const int32_t* idx_h, const int32_t* idx_w, const float* gyn, const float* gxn, int H, int W,
-                                      const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream) {
-    return hr_stage<2>(wt, lrcat, h, w, table, n_uw, idx_h, idx_w, gyn, gxn, H, W, tiling, out, out_plane, stream);
+extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uh, int n_uw,
+                                      const int32_t* idx_h, const int32_t* idx_w, const float* ptab, const float* gyn, const float* gxn, int H, int W,
+                                      const savsr_satu_tiling* tiling, int32_t* sched, float* out, int64_t out_plane, void* stream) {
+    return hr_stage<2>(wt, lrcat, h, w, table, n_uh, n_uw, idx_h, idx_w, ptab, gyn, gxn, H, W, tiling, sched, out, out_plane, stream);
 }
 
-extern "C" int savsr_satu_hr_tail(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uw,
-                                  const int32_t* idx_h, const int32_t* idx_w, const float* gyn, const float* gxn, int H, int W,
-                                  const savsr_satu_tiling* tiling, float* out, int64_t out_plane, void* stream) {
-    return hr_stage<1>(wt, lrcat, h, w, table, n_uw, idx_h, idx_w, gyn, gxn, H, W, tiling, out, out_plane, stream);
+extern "C" int savsr_satu_hr_tail(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uh, int n_uw,
+                                  const int32_t* idx_h, const int32_t* idx_w, const float* ptab, const float* gyn, const float* gxn, int H, int W,
+                                  const savsr_satu_tiling* tiling, int32_t* sched, float* out, int64_t out_plane, void* stream) {
+    return hr_stage<1>(wt, lrcat, h, w, table, n_uh, n_uw, idx_h, idx_w, ptab, gyn, gxn, H, W, tiling, sched, out, out_plane, stream);
 }

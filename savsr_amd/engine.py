@@ -389,6 +389,7 @@ class HipEngine:
         self._axes: "OrderedDict[tuple, dict]" = OrderedDict()
         self._default_ctx = dict(bufs={}, scales=OrderedDict())      # direct kernel-level calls (tests, tools) outside a forward
         self._default_sc = dict(bufs={}, graphs=None)
+        self.hr_sched = torch.zeros(16, dtype=torch.int32, device=self.dev)     # tile-queue scratch of the SATU HR kernel (one per engine = per stream)
         self._cur, self._cur_sc = self._default_ctx, self._default_sc
 
     def _select(self, shape: tuple, scale) -> dict:
@@ -631,31 +632,43 @@ class HipEngine:
             cw, _, gxn = satu_axis_tables(W, w, scale[1])
             uh, ih = np.unique(ch, return_inverse=True)
             uw, iw = np.unique(cw, return_inverse=True)
-            up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(self.dev)
+            def up(a, dt):          # device copy padded to a multiple of 4 elements (the HR stage reads these arrays in 16-byte groups)
+                a = np.ascontiguousarray(a.astype(dt)).reshape(-1)
+                pad = (-len(a)) % 4
+                return torch.from_numpy(np.concatenate([a, np.repeat(a[-1:], pad)]) if pad else a).to(self.dev)
             ent = dict(H=H, W=W, n_uh=len(uh), n_uw=len(uw), uh=up(uh, np.float32), uw=up(uw, np.float32),
                        ih=up(ih.reshape(-1), np.int32), iw=up(iw.reshape(-1), np.int32), gyn=up(gyn, np.float32), gxn=up(gxn, np.float32),
                        table=torch.empty(len(uh) * len(uw) * _lib.SATU_TABLE, device=self.dev))
             self._plan_hr_tiling(ent, h, w, scale)
             self._axes[key] = ent
-            while len(self._axes) > self.max_shapes * self.max_scales:
+            while len(self._axes) > max(self.max_shapes, self.max_scales):
                 self._axes.popitem(last=False)
         else:
             self._axes.move_to_end(key)
         return ent
 
-    # measured cost model of one HR workgroup, cycles (tools/bench_kernels.py satu --stamps): per staged record, per 32-pixel
-    # tile of a wave (4 waves), per tile row of table staging -- [standalone 64-channel form, tail-projected form]
-    HR_COST = {False: (155, 6900, 60), True: (100, 4300, 60)}
+    # cost model of one HR tile in cycles (tools/bench_kernels.py satu --stamps and the staging / compute ablation in DESIGN.md):
+    # per 32-pixel tile of a wave (4 waves per workgroup), per staged byte (LDS-DMA runs at ~5.6 TB/s chip-wide = ~6 B/cycle for
+    # each of a CU's two workgroups), fixed per tile (barrier, DMA issue) -- [standalone 64-channel form, tail-projected form]
+    HR_COST = {False: (6900, 1.0 / 12.0, 1500), True: (3600, 1.0 / 12.0, 1500)}
+    HR_TABLE_LDS = 256          # phase tables up to this size live whole in LDS (mirrors satu.hip)
 
     def _plan_hr_tiling(self, ent: dict, h: int, w: int, scale):
-        """One-time (per size/scale) choice of the HR stage's LDS window: evaluate the phase table,
-        read the range of the sampling offsets back and pick the HR tile whose LRcat window
-        (tile footprint + offset range + bilinear tap) plus its slice of the table fits two workgroups per CU at the
-        lowest modelled cost.  Purely a performance plan: waves whose taps leave the window gather from global memory."""
+        """One-time (per size/scale) choice of the HR stage's tiles and LDS windows: evaluate the phase table (and, for tables
+        too large for LDS, its per-pixel expansion), read the range of the sampling offsets back and pick the HR tile whose
+        double-buffered LRcat window (tile footprint + offset range + bilinear tap) fits two workgroups per CU at the lowest
+        modelled cost = tile rounds of the busiest workgroup x max(gather time, staging time).  Purely a performance plan:
+        waves whose taps leave the window gather from global memory."""
         sw = C.byref(self.satu_w)
         _lib.check(self.lib.savsr_satu_phase_table(sw, ent["uh"].data_ptr(), ent["n_uh"], ent["uw"].data_ptr(), ent["n_uw"],
                                                    1.0 / scale[1], 1.0 / scale[0], ent["table"].data_ptr(), self._stream()),
                    "savsr_satu_phase_table")
+        n_table = ent["n_uh"] * ent["n_uw"]
+        ent["ptab"] = None
+        if n_table > self.HR_TABLE_LDS:
+            ent["ptab"] = torch.empty(ent["H"] * ent["W"] * _lib.SATU_TABLE, device=self.dev)     # the table per HR pixel, offsets normalised
+            _lib.check(self.lib.savsr_satu_expand_table(ent["table"].data_ptr(), ent["n_uw"], ent["ih"].data_ptr(), ent["iw"].data_ptr(), h, w,
+                                                        ent["H"], ent["W"], ent["ptab"].data_ptr(), self._stream()), "savsr_satu_expand_table")
         tab = ent["table"].view(-1, _lib.SATU_TABLE).cpu().numpy()       # synchronises once
         ox = np.concatenate([tab[:, 4], tab[:, 6]])
         oy = np.concatenate([tab[:, 5], tab[:, 7]])
@@ -664,27 +677,29 @@ class HipEngine:
         ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count
         forced = os.environ.get("SAVSR_HR_TILE")                                         # "rows,cols32": experiments only
         for tail_form in (False, True):
-            occ = int(os.environ.get("SAVSR_HR_WGS", "0")) or int(self.lib.savsr_satu_hr_occupancy_target(int(tail_form)))
-            slots = occ * ncu                                                            # resident workgroups
+            occ = int(self.lib.savsr_satu_hr_occupancy_target(int(tail_form)))
+            cw = int(self.lib.savsr_satu_hr_compute_waves())                             # compute waves of a workgroup
             lds_cap = (160 * 1024) // occ - 1024                                         # `occ` workgroups per CU
+            nslot = max(1, occ * ncu // 8)                                               # workgroups per XCD chunk of the tile sequence
+            rec_bytes = 4 * (_lib.SATU_LRCAT_TAIL if tail_form else _lib.SATU_LRCAT)
             t = SatuTiling()
-            t.table_entries = ent["n_uh"] * ent["n_uw"]
+            t.table_entries = n_table
             t.step_x, t.step_y = 1.0 / float(scale[1]), 1.0 / float(scale[0])
             best = None
             if finite:
                 rx, ry = float(ox.max() - ox.min()), float(oy.max() - oy.min())
-                c_rec, c_tile, c_row = self.HR_COST[tail_form]
+                c_tile, c_byte, c_fix = self.HR_COST[tail_form]
                 cands = [(int(forced.split(",")[0]), int(forced.split(",")[1]))] if forced else \
-                    [(r, c) for c in (1, 2, 4) for r in (4, 6, 8, 10, 12, 14, 15, 16, 18, 20, 22, 24, 28, 32)]
+                    [(r, c) for c in (1, 2, 4) for r in (4, 8, 12, 16, 20, 24, 28, 32)]
                 for trows, tcols in cands:
-                    lr_c = min(int(np.ceil(32 * tcols / scale[1] + rx)) + 2, w)
+                    lr_c = min(max(int(np.ceil(32 * tcols / scale[1] + rx)) + 2, 2), w)
                     lr_r = min(int(np.ceil(trows / scale[0] + ry)) + 2, h)
-                    if self.lib.savsr_satu_hr_lds_bytes(int(tail_form), trows, tcols, lr_r, lr_c) > lds_cap:
+                    if self.lib.savsr_satu_hr_lds_bytes(int(tail_form), n_table, trows, tcols, lr_r, lr_c) > lds_cap:
                         continue
-                    # the round quantisation of the grid on the resident slots matters as much as the re-staging
-                    nblk = -(-H // trows) * -(-W // (32 * tcols))
-                    rounds = -(-nblk // slots)
-                    cost = rounds * (c_rec * lr_c * lr_r + c_tile * -(-(trows * tcols) // 4) + c_row * trows * tcols)
+                    ntile = -(-H // trows) * -(-W // (32 * tcols))
+                    rounds = -(-(-(-ntile // 8)) // nslot)                               # tiles of the busiest workgroup
+                    staged = lr_r * lr_c * rec_bytes + (0 if n_table <= self.HR_TABLE_LDS else trows * tcols * 32 * 32)
+                    cost = rounds * (max(c_tile * -(-(trows * tcols) // cw), c_byte * staged) + c_fix)
                     if best is None or cost < best[0]:
                         best = (cost, trows, tcols, lr_r, lr_c)
             if best is None:                                           # no window fits (or non-finite offsets): gathers go to global memory
@@ -721,8 +736,9 @@ class HipEngine:
         ax = self.satu_axes(h, w, scale)       # incl. the phase table: a function of (size, scale, weights) only, evaluated once
         fn, wts, til = (self.lib.savsr_satu_hr_tail, self.satu_w_tail, ax["tiling_tail"]) if tail_form else \
             (self.lib.savsr_satu_hr_upsample, self.satu_w, ax["tiling"])
-        _lib.check(fn(C.byref(wts), lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(),
-                      ax["iw"].data_ptr(), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"], C.byref(til),
+        _lib.check(fn(C.byref(wts), lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uh"], ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
+                      _ptr(ax["ptab"]), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"],
+                      C.byref(til), self.hr_sched.data_ptr() if os.environ.get("SAVSR_HR_STATIC") != "1" else None,
                       out.data_ptr(), out_plane if out_plane is not None else ax["H"] * ax["W"], self._stream()),
                    "savsr_satu_hr")
         return out

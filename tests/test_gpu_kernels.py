@@ -222,7 +222,7 @@ def test_satu_phase_table_and_integer_grid(eng, synth_sd):
         ax = eng.satu_axes(h, w, sc)
         H, W = ax["H"], ax["W"]
         tab = ax["table"].cpu().view(ax["n_uh"], ax["n_uw"], 8)
-        per_px = tab[ax["ih"].cpu().long()][:, ax["iw"].cpu().long()]        # [H, W, 8]
+        per_px = tab[ax["ih"][:H].cpu().long()][:, ax["iw"][:W].cpu().long()]        # [H, W, 8] (the index arrays are padded to a multiple of 4)
         with torch.no_grad():
             off, soff, r = O.satu_heads(synth_sd, "upsample", h, w, sc)
         ref = torch.cat([r[0], off[0], soff[0]], 0).permute(1, 2, 0)

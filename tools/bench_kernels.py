@@ -136,9 +136,9 @@ def main():
         lrcat = eng.buf("satu.lrcat_tail", h, w, _lib.SATU_LRCAT_TAIL)
         for name, call, nb in (
             ("LR", lambda: eng.lib.savsr_satu_lr_stage_tail(sw, x.data_ptr(), st.data_ptr(), 64, w, h, w, lrcat.data_ptr(), eng._stream()), ((w + 31) // 32) * ((h + 7) // 8)),
-            ("HR", lambda: eng.lib.savsr_satu_hr_tail(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
-                                                          ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), H, W, C.byref(ax["tiling_tail"]), out.data_ptr(), plane, eng._stream()),
-             ((W + 31) // 32) * ((H + ax["tiling_tail"].tile_rows - 1) // ax["tiling_tail"].tile_rows))):
+            ("HR", lambda: eng.lib.savsr_satu_hr_tail(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uh"], ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
+                                                      E._ptr(ax["ptab"]), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), H, W, C.byref(ax["tiling_tail"]), eng.hr_sched.data_ptr() if os.environ.get("SAVSR_HR_STATIC") != "1" else None, out.data_ptr(), plane, eng._stream()),
+             512)):
             eng.lib.savsr_debug_satu_stamps(1)
             call()
             torch.cuda.synchronize()
@@ -151,10 +151,21 @@ def main():
             tot = stt[:, 7]
             print(name, "workgroup totals: mean %d  p10 %d  p50 %d  p90 %d  p99 %d  max %d  (n = %d)" %
                   (tot.mean(), np.percentile(tot, 10), np.percentile(tot, 50), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), nb))
-        for flag, nm in ((0, "normal"), (2, "no output stores (invalid results)")):
+            if name == "HR":
+                t0, t1 = stt[:, 5], stt[:, 6]
+                ok = t1 > 0
+                t0, t1 = t0[ok], t1[ok]
+                til = ax["tiling_tail"]
+                lds_b = int(eng.lib.savsr_satu_hr_lds_bytes(1, ax["n_uh"] * ax["n_uw"], til.tile_rows, til.tile_cols32, til.lr_rows, til.lr_cols))
+                print("HR wall clock (100 MHz ticks): last start %.1f us after the first, first end %.1f us, last end %.1f us; workgroup duration p50 %.1f us -> %.2f GHz; "
+                      "LDS %d B, occupancy query: %d workgroups / CU" %
+                      ((t0.max() - t0.min()) / 100.0, (t1.min() - t0.min()) / 100.0, (t1.max() - t0.min()) / 100.0, np.median(t1 - t0) / 100.0,
+                       np.median(tot[ok]) / (np.median(t1 - t0) * 10.0), lds_b, eng.lib.savsr_debug_satu_occupancy(0, lds_b)))
+        for flag, nm in ((0, "normal"), (2, "no output stores (invalid results)"), (4, "staging only"), (8, "no window / table staging (invalid results)"),
+                         (10, "no staging, no stores")):
             eng.lib.savsr_debug_satu_stamps(flag)
-            hr = lambda: eng.lib.savsr_satu_hr_tail(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
-                                                        ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), H, W, C.byref(ax["tiling_tail"]), out.data_ptr(), plane, eng._stream())
+            hr = lambda: eng.lib.savsr_satu_hr_tail(sw, lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uh"], ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
+                                                    E._ptr(ax["ptab"]), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), H, W, C.byref(ax["tiling_tail"]), eng.hr_sched.data_ptr() if os.environ.get("SAVSR_HR_STATIC") != "1" else None, out.data_ptr(), plane, eng._stream())
             for _ in range(3):
                 hr()
             ev0.record()
