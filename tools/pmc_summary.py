@@ -25,7 +25,7 @@ def main():
             if "savsr" not in k:
                 continue
             v = list(per.values())
-            print("%s,%s,%s,%d,%.1f" % (os.path.basename(d.rstrip("/")), k, c, len(v), sum(v) / len(v)))
+            print('%s,"%s",%s,%d,%.1f' % (os.path.basename(d.rstrip("/")), k, c, len(v), sum(v) / len(v)))     # (kernel names hold commas: quoted)
 
 
 if __name__ == "__main__":
