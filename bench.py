@@ -327,7 +327,7 @@ def run_cases(args, rank, world, dev, dist, cases, workload, config_id):
 
 def run_config5(args, rank, world, dev, dist):
     """Vimeo90K-shape mixed-scale throughput: every step draws `clips-per-step` (shape, scale) pairs from the 60-entry training
-    list (random.Random(seed = rank)), groups equal pairs into batches (kept in flight on the HIP streams) and runs them."""
+    list (random.Random(seed = rank)) and runs them as a stream of independent clips over the engine's HIP streams."""
     from savsr_amd.engine import get_hw
     from savsr_amd.utils import synth, workloads
     net, sd = build_net(dev)
@@ -339,18 +339,13 @@ def run_config5(args, rank, world, dev, dist):
     clips = {k: synth.synth_clip(7, 3, k[0], k[1], seed=11, batch=1).to(dev) for k in uniq}
 
     def run_step(i):
-        grp = {}
-        for k in draws[i * cps:(i + 1) * cps]:
-            grp[k] = grp.get(k, 0) + 1
-        px = 0
-        for k, n in grp.items():
-            net.set_scale(k[2])
-            out = net(clips[k].expand(n, -1, -1, -1, -1))
-            px += n * out.shape[-1] * out.shape[-2]
-        return px
-    for k in uniq:                                        # capture every (shape, scale) once, untimed
-        net.set_scale(k[2])
-        net(clips[k])
+        ks = draws[i * cps:(i + 1) * cps]
+        outs = net.forward_many([clips[k][0] for k in ks], [k[2] for k in ks])       # clip j on HIP stream j % n_streams
+        return sum(o.shape[-1] * o.shape[-2] for o in outs)
+    for j in range(0, len(uniq), eng.n_streams):          # capture every (shape, scale) once on every stream's engine, untimed
+        for r in range(eng.n_streams):
+            ks = [uniq[(j + (q + r) % eng.n_streams) % len(uniq)] for q in range(eng.n_streams)]
+            net.forward_many([clips[k][0] for k in ks], [k[2] for k in ks])
     for i in range(args.warmup):
         run_step(i)
     px = [0]

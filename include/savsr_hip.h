@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 15
+#define SAVSR_ABI_VERSION 16
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -152,6 +152,11 @@ int savsr_se_gate(const float* partial, int nblk, float inv_n, const float* w1, 
                   const float* w2, const float* b2, int c, int cmid, float* gate, void* stream);
 /* out[px][c] = r[px][c] * gate[c] + x[px][c]   (savsr_arch.py:524,548-549); contiguous [npx][c] */
 int savsr_scale_residual(const float* r, const float* gate, const float* x, float* out, int c, int64_t npx, void* stream);
+/* the two above in ONE launch (what SAVSR.forward runs, 32 x per frame): every workgroup re-evaluates the gate from the pooled
+ * partial sums, then out = r * gate + x.  Bit-identical to savsr_se_gate followed by savsr_scale_residual. */
+int savsr_se_scale_residual(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
+                            const float* w2, const float* b2, int c, int cmid,
+                            const float* r, const float* x, float* out, int64_t npx, void* stream);
 
 /* nn.AvgPool2d(2) (savsr_arch.py:193): [h][w][c] -> [h/2][w/2][c], h and w even, contiguous. */
 int savsr_avgpool2(const float* in, float* out, int c, int h, int w, void* stream);

@@ -17,7 +17,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 15
+ABI_VERSION = 16
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
 
@@ -86,6 +86,7 @@ SIGNATURES = {
     "savsr_osconv_weights_batch": (C.c_int, [C.POINTER(OSConvAttnDesc), C.c_int, C.c_void_p]),
     "savsr_se_gate": (C.c_int, [fptr, C.c_int, C.c_float, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, C.c_void_p]),
     "savsr_scale_residual": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int64, C.c_void_p]),
+    "savsr_se_scale_residual": (C.c_int, [fptr, C.c_int, C.c_float, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int64, C.c_void_p]),
     "savsr_avgpool2": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "savsr_upsample2x": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "savsr_pack_windows": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

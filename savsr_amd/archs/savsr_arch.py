@@ -213,6 +213,14 @@ class SAVSR(nn.Module):
             self._engine_sig = self._signature()
         return self._engine
 
+    def forward_many(self, clips, scales):
+        """Extension for mixed-scale streams (BASELINE config 5; the reference's flow would call set_scale + forward per clip):
+        clips[i]: [t, c, h, w] on the GPU, scales[i]: (sh, sw) -> list of [c, H, W]; independent clips overlap on HIP streams."""
+        if self.training:
+            raise RuntimeError("savsr_amd.SAVSR implements the inference path only; call .eval() first")
+        with torch.no_grad():
+            return self.engine().forward_many(list(zip(clips, [tuple(s) if not isinstance(s, (int, float)) else (s, s) for s in scales])))
+
     def forward(self, x: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
         if self.training:
             raise RuntimeError("savsr_amd.SAVSR implements the inference path only; call .eval() first")

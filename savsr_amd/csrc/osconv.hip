@@ -297,8 +297,10 @@ __global__ __launch_bounds__(512) void osconv_aggregate_kernel(const OscBatch bt
 // RCAN ChannelAttention MLP (savsr_arch.py:514-520); one workgroup of 1024 threads (latency-bound: the pooled-sum
 // reduction runs as 16 short interleaved row slices per channel).
 constexpr int SE_PARTS = 16;
-__global__ __launch_bounds__(1024) void se_gate_kernel(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
-                                                     const float* w2, const float* b2, int c, int cmid, float* gate) {
+// The gate of one RCAB, computed by a 1024-thread workgroup into LDS (g[c]); every summation order is fixed, so every workgroup
+// that evaluates it gets the same bits.
+__device__ __forceinline__ void se_gate_block(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
+                                               const float* w2, const float* b2, int c, int cmid, float* g) {
     __shared__ float scr[SE_PARTS * 128];
     __shared__ float m[128];
     __shared__ float z[64];
@@ -350,7 +352,40 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* partial, int
         for (int k = 0; k < 8; ++k)
             if (k < cmid) acc += w2v[k] * z[k];
         for (int k = 8; k < cmid; ++k) acc += w2[t * cmid + k] * z[k];
-        gate[t] = sigmoidf_(acc);
+        g[t] = sigmoidf_(acc);
+    }
+    __syncthreads();
+}
+
+
+__global__ __launch_bounds__(1024) void se_gate_kernel(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
+                                                     const float* w2, const float* b2, int c, int cmid, float* gate) {
+    __shared__ float g[128];
+    se_gate_block(partial, nblk, inv_n, w1, b1, w2, b2, c, cmid, g);
+    if (threadIdx.x < c) gate[threadIdx.x] = g[threadIdx.x];
+}
+
+// ChannelAttention + RCAB residual in ONE launch (savsr_arch.py:514-524,548-549): every workgroup re-evaluates the gate from the
+// pooled partial sums (a 59 KB read from L2 and a few thousand MACs per workgroup, one workgroup per CU) and then scales its
+// share of the pixels: out[px][c] = r[px][c] * gate[c] + x[px][c].  Replaces the se_gate -> scale_residual pair: one launch
+// boundary and one dependent kernel less per RCAB (32 per frame).
+__global__ __launch_bounds__(1024) void se_scale_residual_kernel(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
+                                                               const float* w2, const float* b2, int c, int cmid, const f32x4* __restrict__ r,
+                                                               const f32x4* __restrict__ x, f32x4* __restrict__ out, long long n4) {
+    __shared__ __attribute__((aligned(16))) float g[128];
+    // the streaming operands of this workgroup's first elements do not depend on the gate: their loads go out first
+    const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, b0 = a0;
+    if (i0 < n4) { a0 = r[i0]; b0 = x[i0]; }
+    se_gate_block(partial, nblk, inv_n, w1, b1, w2, b2, c, cmid, g);
+    const int c4 = c >> 2;
+    for (long long i = i0; i < n4; i += (long long)gridDim.x * 1024) {
+        const f32x4 gq = *reinterpret_cast<const f32x4*>(g + 4 * (int)(i % c4));
+        f32x4 a, b2_;
+        if (i == i0) { a = a0; b2_ = b0; } else { a = r[i]; b2_ = x[i]; }
+        f32x4 o;
+        o[0] = a[0] * gq[0] + b2_[0]; o[1] = a[1] * gq[1] + b2_[1]; o[2] = a[2] * gq[2] + b2_[2]; o[3] = a[3] * gq[3] + b2_[3];
+        out[i] = o;
     }
 }
 
@@ -435,6 +470,22 @@ extern "C" int savsr_se_gate(const float* partial, int nblk, float inv_n, const 
     if (c < 1 || c > 128 || cmid < 1 || cmid > 64 || nblk < 1) return fail_arg("se_gate: shape");
     hipLaunchKernelGGL(se_gate_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), partial, nblk, inv_n, w1, b1, w2, b2, c, cmid, gate);
     return check_launch("se_gate_kernel");
+}
+
+extern "C" int savsr_se_scale_residual(const float* partial, int nblk, float inv_n, const float* w1, const float* b1, const float* w2,
+                                       const float* b2, int c, int cmid, const float* r, const float* x, float* out, int64_t npx, void* stream) {
+    if (!partial || !w1 || !b1 || !w2 || !b2 || !r || !x || !out) return fail_arg("se_scale_residual: null pointer");
+    if (c < 4 || c > 128 || (c % 4) || cmid < 1 || cmid > 64 || nblk < 1 || npx < 1) return fail_arg("se_scale_residual: shape (c a multiple of 4, <= 128)");
+    if ((reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) {
+        set_error("se_scale_residual: r / x / out must be 16-byte aligned");
+        return SAVSR_E_ALIGN;
+    }
+    const long long n4 = npx * (c / 4);
+    long long g = (n4 + 1023) / 1024;
+    if (g > 256) g = 256;                                              // one workgroup per CU: each re-evaluates the gate
+    hipLaunchKernelGGL(se_scale_residual_kernel, dim3((unsigned)g), dim3(1024), 0, static_cast<hipStream_t>(stream), partial, nblk, inv_n, w1, b1, w2, b2,
+                       c, cmid, reinterpret_cast<const f32x4*>(r), reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(out), n4);
+    return check_launch("se_scale_residual_kernel");
 }
 
 extern "C" int savsr_scale_residual(const float* r, const float* gate, const float* x, float* out, int c, int64_t npx, void* stream) {

@@ -28,6 +28,9 @@
 #ifndef LR_INTERLEAVE
 #define LR_INTERLEAVE 1
 #endif
+#ifndef LR_XPREFETCH
+#define LR_XPREFETCH 1
+#endif
 
 namespace savsr {
 
@@ -207,7 +210,8 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
             // staged under this phase: the next kernel row's slabs; at the end of a channel group also the next x tile;
             // under the very last phase the projection weights (same 40 KB) and the centre pixel's x
             if (ph + 1 < 10) dma_phase(ph + 1, buf ^ 1);
-            else {                                    // projection image: (2 NB + 1) x 8 KB
+            if (LR_XPREFETCH && ph == 4) xt_load(1);   // the second channel group's x tile: its loads fly under this phase (28 registers; written to LDS behind the barrier)
+            if (ph + 1 >= 10) {                                    // projection image: (2 NB + 1) x 8 KB
 #pragma unroll
                 for (int i = 0; i < 2 * NB + 1; ++i)
                     glds16(reinterpret_cast<const bf16x8*>(p.wt.proj_w) + (i * 8 + wave) * 64 + lane, wbuf + (buf ^ 1) * LR_PHASE + (i * 8 + wave) * 64);
@@ -297,8 +301,8 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the staged slabs (and x loads) have landed
             LR_MARK(2);
             __syncthreads();
-            if (ky == 4 && cg == 0) {                 // every wave is done with the old x tile: swap it (once per workgroup; loading
-                xt_load(1);                           // it under phase 4 would hold 28 registers across the loop and spills)
+            if (ky == 4 && cg == 0) {                 // every wave is done with the old x tile: swap it (once per workgroup)
+                if (!LR_XPREFETCH) xt_load(1);
                 xt_store();
                 __syncthreads();
             }

@@ -372,6 +372,7 @@ class HipEngine:
             e.osc[k] = c
         e.se_gate = torch.empty_like(self.se_gate)
         e._init_caches()
+        e.max_shapes, e.max_scales = self.max_shapes, self.max_scales
         e.satu_events, e.use_graphs = None, self.use_graphs
         e._siblings, e._streams = [], []
         return e
@@ -595,11 +596,9 @@ class HipEngine:
         nblk = self.pool_rows(hp, wp)
         w1, b1, w2, b2, cm = self.se[pfx]
         st = self._stream()
-        _lib.check(self.lib.savsr_se_gate(part.data_ptr(), nblk, 1.0 / (hp * wp), w1.data_ptr(), b1.data_ptr(),
-                                          w2.data_ptr(), b2.data_ptr(), nf, cm, self.se_gate.data_ptr(), st), "savsr_se_gate")
         assert x.pix == nf and out.pix == nf
-        _lib.check(self.lib.savsr_scale_residual(r2.ptr, self.se_gate.data_ptr(), x.ptr, out.ptr, nf, hp * wp, st),
-                   "savsr_scale_residual")
+        _lib.check(self.lib.savsr_se_scale_residual(part.data_ptr(), nblk, 1.0 / (hp * wp), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                    nf, cm, r2.ptr, x.ptr, out.ptr, hp * wp, st), "savsr_se_scale_residual")
         return out
 
     def osadapt(self, g: int, x: Src, share: Optional[Src], out: Src, hp: int, wp: int, scale, pooled: bool = False) -> Src:
@@ -893,6 +892,37 @@ class HipEngine:
         out.copy_(s_out)
         return out
 
+    def _ensure_streams(self, ns: int):
+        while len(self._siblings) < ns - 1:
+            self._siblings.append(self.clone_for_stream())
+        while len(self._streams) < ns:
+            self._streams.append(torch.cuda.Stream(device=self.dev))
+        return [self] + self._siblings
+
+    def forward_many(self, items) -> List[torch.Tensor]:
+        """A stream of independent clips of MIXED shapes / scales (BASELINE config 5): items = [(lq [T, 3, h, w], (sh, sw))] ->
+        [out [3, H, W]].  Clip i runs on HIP stream i % n_streams with that stream's sibling engine, so small clips (whose ~360
+        launches are latency-bound) overlap; results are those of forward() clip by clip."""
+        if not self.use_graphs or self.n_streams < 2 or len(items) < 2:
+            return [self.forward(lq.unsqueeze(0), sc)[0] for lq, sc in items]
+        ns = min(self.n_streams, len(items))
+        engines = self._ensure_streams(ns)
+        cur = torch.cuda.current_stream()
+        outs = []
+        for lq, sc in items:
+            if lq.device != self.dev:
+                raise RuntimeError(f"input on {lq.device}, engine on {self.dev}")
+            H, W = get_hw(lq.shape[-2], lq.shape[-1], sc)
+            outs.append(torch.empty(3, H, W, device=self.dev, dtype=torch.float32))
+        for k in range(ns):
+            self._streams[k].wait_stream(cur)
+        for i, (lq, sc) in enumerate(items):
+            with torch.cuda.stream(self._streams[i % ns]):
+                engines[i % ns]._forward_graphed(lq.to(torch.float32).contiguous(), sc, outs[i])
+        for k in range(ns):
+            cur.wait_stream(self._streams[k])
+        return outs
+
     def forward(self, lq: torch.Tensor, scale, taps: Optional[dict] = None) -> torch.Tensor:
         """lq: [b, T, 3, h, w] -> [b, 3, H, W] (savsr_arch.py:692-742)."""
         if lq.device != self.dev:
@@ -905,11 +935,7 @@ class HipEngine:
             # clips are independent (no cross-clip state, savsr_arch.py:705-706): keep n_streams of them in flight
             # on separate HIP streams so one clip's load/store-bound kernel phases overlap another's MFMA phases
             ns = min(self.n_streams, b)
-            while len(self._siblings) < ns - 1:
-                self._siblings.append(self.clone_for_stream())
-            while len(self._streams) < ns:
-                self._streams.append(torch.cuda.Stream(device=self.dev))
-            engines = [self] + self._siblings
+            engines = self._ensure_streams(ns)
             cur = torch.cuda.current_stream()
             for k in range(ns):
                 self._streams[k].wait_stream(cur)

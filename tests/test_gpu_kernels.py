@@ -361,6 +361,30 @@ def test_tail_gather(eng, synth_sd, h, w, sc):
     assert _maxerr(out, ref[0]) < 5e-6
 
 
+def test_se_scale_residual_fused_equals_pair(eng):
+    """savsr_se_scale_residual == savsr_se_gate followed by savsr_scale_residual, bit for bit (savsr_arch.py:514-524,548-549),
+    and both match the reference formulation of the ChannelAttention gate."""
+    from savsr_amd import _lib
+    g = np.random.RandomState(7)
+    npx, c, cm, nblk = 23 * 37, 64, 4, 230
+    part = _dev(torch.from_numpy(g.standard_normal((nblk, c)).astype(np.float32)))
+    w1, b1 = _dev(torch.from_numpy(g.standard_normal((cm, c)).astype(np.float32) * 0.2)), _dev(torch.from_numpy(g.standard_normal(cm).astype(np.float32)))
+    w2, b2 = _dev(torch.from_numpy(g.standard_normal((c, cm)).astype(np.float32) * 0.5)), _dev(torch.from_numpy(g.standard_normal(c).astype(np.float32)))
+    r, x = _dev(torch.from_numpy(g.standard_normal((npx, c)).astype(np.float32))), _dev(torch.from_numpy(g.standard_normal((npx, c)).astype(np.float32)))
+    gate = torch.empty(c, device="cuda:0")
+    o1, o2 = torch.empty_like(r), torch.full_like(r, float("nan"))
+    inv_n = 1.0 / 57600
+    _lib.check(eng.lib.savsr_se_gate(part.data_ptr(), nblk, inv_n, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), c, cm, gate.data_ptr(), None), "se_gate")
+    _lib.check(eng.lib.savsr_scale_residual(r.data_ptr(), gate.data_ptr(), x.data_ptr(), o1.data_ptr(), c, npx, None), "scale_residual")
+    _lib.check(eng.lib.savsr_se_scale_residual(part.data_ptr(), nblk, inv_n, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), c, cm,
+                                               r.data_ptr(), x.data_ptr(), o2.data_ptr(), npx, None), "se_scale_residual")
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+    m = part.cpu().double().sum(0) * inv_n
+    gref = torch.sigmoid(w2.cpu().double() @ torch.relu(w1.cpu().double() @ m + b1.cpu().double()) + b2.cpu().double())
+    assert _maxerr(o2, r.cpu().double() * gref + x.cpu().double()) < 2e-6
+
+
 def test_small_elementwise(eng):
     from savsr_amd import _lib
     x = rnd((16, 8, 10), 61)
