@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 16
+#define SAVSR_ABI_VERSION 17
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -221,6 +221,7 @@ int64_t savsr_satu_hr_lds_bytes(int tail_form, int n_table, int tile_rows, int t
 int savsr_satu_hr_occupancy_target(int tail_form);
 /* compute waves of an HR workgroup: a tile of tile_rows x tile_cols32 "wave tiles" (one row x 32 pixels) is dealt over them */
 int savsr_satu_hr_compute_waves(void);
+int savsr_satu_hr_rows_per_wave_tile(int tail_form);   /* HR rows one wave tile covers (32 pixels wide) */
 
 /* Per-pixel expansion of the phase table, once per (size, scale, weights): ptab[Y][X][8] = table[idx_h[Y]][idx_w[X]] with the
  * two offset pairs normalised as the reference normalises them per pixel ((off * 2) / (size - 1), savsr_arch.py:285-287).

@@ -17,7 +17,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 16
+ABI_VERSION = 17
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
 
@@ -103,6 +103,7 @@ SIGNATURES = {
                                      C.c_int, C.c_int, C.POINTER(SatuTiling), fptr, fptr, C.c_int64, C.c_void_p]),
     "savsr_satu_hr_occupancy_target": (C.c_int, [C.c_int]),
     "savsr_satu_hr_compute_waves": (C.c_int, []),
+    "savsr_satu_hr_rows_per_wave_tile": (C.c_int, [C.c_int]),
     "savsr_satu_hr_lds_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "savsr_tail_gather": (C.c_int, [fptr, C.c_int64, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
     "savsr_debug_conv_stamps": (C.c_int, [C.c_int]),

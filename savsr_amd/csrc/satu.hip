@@ -619,11 +619,149 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
 #ifndef HR_SCALAR_FMA
 #define HR_SCALAR_FMA 0           // experiment: plain v_fma_f32 instead of v_pk_fma_f32 in the gathers
 #endif
+// Tail-projected form, LANE = PIXEL: a wave tile is 32 pixels x 2 rows (lanes 0-31 row Y, lanes 32-63 row Y + 1); every lane
+// gathers all 32 output rows of ITS pixel, so the per-pixel work that both lanes of a pixel repeated in hr_tile (table lookup,
+// tap arithmetic, window test, record addresses, the expert operand) is done once: ~300 vector instructions per 32 pixels
+// instead of ~424 in a kernel whose vector issue is 64 % busy.  The 32x32x16 MFMA wants (pixel, row half) lanes, so the
+// accumulators and the expert B operands are transposed in registers in front of it: with a = rows of half 0 and b = rows of
+// half 1 of the lane's own pixel, v_permlane32_swap(a, b) leaves [a of lanes 0-31 | b of lanes 0-31] = the accumulator layout
+// of the first row's 32 pixels in a, and that of the second row's in b (one instruction per register pair).
+template <bool FROM_LDS>
+__device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, int ly0, int lx0, const Taps& to, const Taps& ts,
+                                           const f32x4 rr, int lane, bool valid0, bool valid1, unsigned o_off0, unsigned o_off1,
+                                           const float* cst) {
+    constexpr int REC = rec_floats(1), LREC = hr_lds_rec(1);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int half = lane >> 5;
+    auto recs = [&](const Taps& t, const f32x4* (&r)[4]) {
+        if (FROM_LDS) {
+            const float* b = lds + __mul24(__mul24(t.y0 - ly0, p.lrw) + (t.x0 - lx0), LREC);
+            const int sx = t.dx ? LREC : 0, sy = t.dy ? __mul24(p.lrw, LREC) : 0;
+            r[0] = reinterpret_cast<const f32x4*>(b); r[1] = reinterpret_cast<const f32x4*>(b + sx);
+            r[2] = reinterpret_cast<const f32x4*>(b + sy); r[3] = reinterpret_cast<const f32x4*>(b + sy + sx);
+        } else {
+            const float* b = p.lrcat + ((long long)t.y0 * p.w + t.x0) * REC;
+            const int sx = t.dx ? REC : 0, sy = t.dy ? p.w * REC : 0;
+            r[0] = reinterpret_cast<const f32x4*>(b); r[1] = reinterpret_cast<const f32x4*>(b + sx);
+            r[2] = reinterpret_cast<const f32x4*>(b + sy); r[3] = reinterpret_cast<const f32x4*>(b + sy + sx);
+        }
+    };
+    const f32x4* ro[4];
+    const f32x4* rs[4];
+    recs(to, ro);
+    recs(ts, rs);
+    // ---- t_j = sum_m r_m (C_m G(x, off))_j : the record's 32 compressed channels (quads 16 .. 23 = (m, j) at 8 m + j) ----
+    f32x2 tq[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float wk = to.wgt[k];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 v0 = ro[k][16 + 2 * m], v1 = ro[k][16 + 2 * m + 1];
+            const float wr = wk * rr[m];
+            const f32x2 w2 = {wr, wr};
+            tq[0] = __builtin_elementwise_fma(w2, f32x2{v0[0], v0[1]}, tq[0]);
+            tq[1] = __builtin_elementwise_fma(w2, f32x2{v0[2], v0[3]}, tq[1]);
+            tq[2] = __builtin_elementwise_fma(w2, f32x2{v1[0], v1[1]}, tq[2]);
+            tq[3] = __builtin_elementwise_fma(w2, f32x2{v1[2], v1[3]}, tq[3]);
+        }
+    }
+    // ---- B operands of the expert MFMA: v[(n, j)] = r_n t_j; k = 16 ks + 8 kh + j <-> n = 2 ks + kh.  Own-pixel values for
+    // n = 2 ks (X) and 2 ks + 1 (Y); swap -> X = operand of the first row's pixels, Y = of the second row's ----
+    bf16x8 bh[2][2], bl[2][2];                       // [pixel row][ks]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 xh, xl, yh, yl;
+        {
+            const float r0 = rr[2 * ks], r1 = rr[2 * ks + 1];
+            const f32x4 a0 = {r0 * tq[0][0], r0 * tq[0][1], r0 * tq[1][0], r0 * tq[1][1]}, a1 = {r0 * tq[2][0], r0 * tq[2][1], r0 * tq[3][0], r0 * tq[3][1]};
+            const f32x4 c0 = {r1 * tq[0][0], r1 * tq[0][1], r1 * tq[1][0], r1 * tq[1][1]}, c1 = {r1 * tq[2][0], r1 * tq[2][1], r1 * tq[3][0], r1 * tq[3][1]};
+            split8v(a0, a1, xh, xl);
+            split8v(c0, c1, yh, yl);
+        }
+        u32x4 uxh = __builtin_bit_cast(u32x4, xh), uxl = __builtin_bit_cast(u32x4, xl), uyh = __builtin_bit_cast(u32x4, yh), uyl = __builtin_bit_cast(u32x4, yl);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const auto sh = __builtin_amdgcn_permlane32_swap(uxh[d], uyh[d], false, false);
+            uxh[d] = sh[0]; uyh[d] = sh[1];
+            const auto sl = __builtin_amdgcn_permlane32_swap(uxl[d], uyl[d], false, false);
+            uxl[d] = sl[0]; uyl[d] = sl[1];
+        }
+        bh[0][ks] = __builtin_bit_cast(bf16x8, uxh); bl[0][ks] = __builtin_bit_cast(bf16x8, uxl);
+        bh[1][ks] = __builtin_bit_cast(bf16x8, uyh); bl[1][ks] = __builtin_bit_cast(bf16x8, uyl);
+    }
+    // ---- gathers into a (rows acc_row(r, 0)) and b (rows acc_row(r, 1)) of the lane's own pixel, bias first ----
+    const f32x4* fb4 = reinterpret_cast<const f32x4*>(cst + hr_wimg_floats(1));     // LDS copy of the bias, packed [half][16]
+    f32x16 a, b;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ba = fb4[g], bb = fb4[4 + g];
+        a[4 * g] = ba[0]; a[4 * g + 1] = ba[1]; a[4 * g + 2] = ba[2]; a[4 * g + 3] = ba[3];
+        b[4 * g] = bb[0]; b[4 * g + 1] = bb[1]; b[4 * g + 2] = bb[2]; b[4 * g + 3] = bb[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                    // G(Wt27 Wb x, off): record quads 4 .. 7 (half 0), 12 .. 15 (half 1)
+        const float wk = to.wgt[k];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { fma_quad(a, g, wk, ro[k][4 + g]); fma_quad(b, g, wk, ro[k][12 + g]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                    // G(Wt27 Wa sta, soff): record quads 0 .. 3, 8 .. 11
+        const float wk = ts.wgt[k];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { fma_quad(a, g, wk, rs[k][g]); fma_quad(b, g, wk, rs[k][8 + g]); }
+    }
+    // ---- to the MFMA's (pixel, row half) layout, then + (Wt27 Wb E) v on the bf16 matrix cores ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[r]), __float_as_uint(b[r]), false, false);
+        a[r] = __uint_as_float(sw[0]);
+        b[r] = __uint_as_float(sw[1]);
+    }
+    const bf16x8* wimg = reinterpret_cast<const bf16x8*>(cst) + lane;               // LDS copy of [ks][part][lane]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 wh = wimg[(ks * 2 + 0) * 64], wl = wimg[(ks * 2 + 1) * 64];
+        a = mma3(wh, wl, bh[0][ks], bl[0][ks], a);
+        b = mma3(wh, wl, bh[1][ks], bl[1][ks], b);
+    }
+    // ---- stores (see hr_tile): rows 27 .. 31 are padding ----
+    const long long HW = p.out_plane;
+    float* outp = p.out;
+    asm volatile("" : "+s"(outp));
+#pragma unroll
+    for (int G = 0; G < 2; ++G) {
+        const f32x16& acc = G ? b : a;
+        if (G ? valid1 : valid0) {
+            unsigned oo = G ? o_off1 : o_off0;
+            asm volatile("" : "+v"(oo));
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                float* pl = outp + (long long)acc_row(r, 0) * HW;
+                asm volatile("" : "+s"(pl));
+                *(__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)pl + oo) = acc[r];
+            }
+            if (half == 0) {
+#pragma unroll
+                for (int r = 12; r < 15; ++r) {
+                    float* pl = outp + (long long)acc_row(r, 0) * HW;
+                    asm volatile("" : "+s"(pl));
+                    *(__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)pl + oo) = acc[r];
+                }
+            }
+        }
+    }
+}
+
 // ONE workgroup per CU: HR_WAVES compute waves (wave tiles are dealt round-robin over them) + HR_PRODUCERS producer waves that
 // only issue the next tile's LDS-DMAs.  A wave's gather chain is latency-bound (LDS round trips): alone on its SIMD a wave
 // needs ~4.1 k cycles per 32-pixel tile, three waves sharing a SIMD finish one every ~1.3 k, so the kernel wants as many
 // compute waves per SIMD as the register file holds (HR_MINW waves per SIMD <-> the VGPR cap the kernel is compiled for).
 // A producer wave gets ~4-5 LDS-DMAs in flight (one 1-KiB DMA per ~450 cycles, measured).
+#ifndef HR_LANE_PX
+#define HR_LANE_PX 1              // tail-projected form: lane = pixel wave tiles (hr_tile_px); 0 = two lanes per pixel (hr_tile)
+#endif
 #ifndef HR_WAVES
 #define HR_WAVES 8         // measured at 180x320 x4: 8 + 4 -> 42-44 us, 10 + 2 -> 43-46, 12 + 4 and 14 + 2 (128 VGPRs, spills) -> 47-58
 #endif
@@ -810,7 +948,40 @@ __global__ __launch_bounds__(HR_THREADS, HR_MINW) void satu_hr_kernel(const HrPa
         const float* colg = rowg + HR_MAX_ROWS;
         const int* rowi = reinterpret_cast<const int*>(colg + ncol);
         const int* coli = rowi + HR_MAX_ROWS;
-        if (!dbg_stage_only)
+        if (!dbg_stage_only && NB == 1 && HR_LANE_PX) {
+            // lane = pixel: wave tiles of 32 pixels x 2 rows (tile_rows is a multiple of 4)
+            const int npair = (p.ty >> 1) * p.txw, hl = lane >> 5;
+            for (int T = wave_s; T < npair; T += HR_WAVES) {
+                const int trow2 = p.txw == 1 ? T : T / p.txw;
+                const int tcol = T - trow2 * p.txw;
+                const int Y = Y0 + 2 * trow2;
+                const int Xb = X0 + tcol * 32;
+                if (Y >= p.H || Xb >= p.W) continue;                  // wave-uniform
+                const bool row1 = Y + 1 < p.H;                        // (uniform) odd image height: the second row of the last pair is absent
+                const int trow = 2 * trow2 + (row1 ? hl : 0);         // its lanes recompute the first row (nothing stored)
+                const int X = Xb + px;
+                const float* te = small ? tabl + (rowi[trow] * p.n_uw + coli[tcol * 32 + px]) * SAVSR_SATU_TABLE
+                                        : slice + (trow * ncol + tcol * 32 + px) * SAVSR_SATU_TABLE;
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(te);
+                const f32x4 oo = *reinterpret_cast<const f32x4*>(te + 4);
+                const float gxn = colg[tcol * 32 + px];
+                const float gyn = rowg[trow];
+                const Taps to = make_taps(gxn, gyn, oo[0], oo[1], p.h, p.w);
+                const Taps ts = make_taps(gxn, gyn, oo[2], oo[3], p.h, p.w);
+                const bool inside = p.lrh > 0 &&
+                    (unsigned)(to.y0 - ly0) < (unsigned)(p.lrh - to.dy) && (unsigned)(to.x0 - lx0) < (unsigned)(p.lrw - to.dx) &&
+                    (unsigned)(ts.y0 - ly0) < (unsigned)(p.lrh - ts.dy) && (unsigned)(ts.x0 - lx0) < (unsigned)(p.lrw - ts.dx);
+                // after the transposes lane (px, hl) holds rows acc_row(r, hl) of pixel (row, Xb + px) for each of the two rows
+                const bool vx = X < p.W && !dbg_nostore;
+                const unsigned o_off0 = 4u * (unsigned)(Y * p.W + X) + (hl ? 16u * (unsigned)p.out_plane : 0u);
+                const unsigned o_off1 = o_off0 + 4u * (unsigned)p.W;
+                if (__all(inside)) hr_tile_px<true>(p, buf_cur, ly0, lx0, to, ts, rr, lane, vx, vx && row1, o_off0, o_off1, cst);
+                else {
+                    hr_tile_px<false>(p, buf_cur, ly0, lx0, to, ts, rr, lane, vx, vx && row1, o_off0, o_off1, cst);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the fallback's gathers are not left pending
+                }
+            }
+        } else if (!dbg_stage_only)
         for (int T = wave_s; T < ntile; T += HR_WAVES) {
             const int trow = p.txw == 1 ? T : T / p.txw;                // (a run-time integer division is ~14 vector instructions)
             const int tcol = T - trow * p.txw;
@@ -894,6 +1065,7 @@ extern "C" int savsr_debug_satu_stamps(int enable) {
 
 extern "C" int savsr_satu_hr_occupancy_target(int tail_form) { (void)tail_form; return 1; }
 extern "C" int savsr_satu_hr_compute_waves(void) { return HR_WAVES; }
+extern "C" int savsr_satu_hr_rows_per_wave_tile(int tail_form) { return tail_form && HR_LANE_PX ? 2 : 1; }
 
 // Diagnostics: resident workgroups per CU the runtime predicts for the HR / LR kernels (tail-projected form) with `lds_bytes` of dynamic LDS.
 extern "C" int savsr_debug_satu_occupancy(int which, int lds_bytes) {

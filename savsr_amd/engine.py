@@ -678,6 +678,7 @@ class HipEngine:
         for tail_form in (False, True):
             occ = int(self.lib.savsr_satu_hr_occupancy_target(int(tail_form)))
             cw = int(self.lib.savsr_satu_hr_compute_waves())                             # compute waves of a workgroup
+            rpw = int(self.lib.savsr_satu_hr_rows_per_wave_tile(int(tail_form)))         # rows of a wave tile
             lds_cap = (160 * 1024) // occ - 1024                                         # `occ` workgroups per CU
             nslot = max(1, occ * ncu // 8)                                               # workgroups per XCD chunk of the tile sequence
             rec_bytes = 4 * (_lib.SATU_LRCAT_TAIL if tail_form else _lib.SATU_LRCAT)
@@ -698,7 +699,7 @@ class HipEngine:
                     ntile = -(-H // trows) * -(-W // (32 * tcols))
                     rounds = -(-(-(-ntile // 8)) // nslot)                               # tiles of the busiest workgroup
                     staged = lr_r * lr_c * rec_bytes + (0 if n_table <= self.HR_TABLE_LDS else trows * tcols * 32 * 32)
-                    cost = rounds * (max(c_tile * -(-(trows * tcols) // cw), c_byte * staged) + c_fix)
+                    cost = rounds * (max(c_tile * rpw * -(-((trows // rpw) * tcols) // cw), c_byte * staged) + c_fix)
                     if best is None or cost < best[0]:
                         best = (cost, trows, tcols, lr_r, lr_c)
             if best is None:                                           # no window fits (or non-finite offsets): gathers go to global memory
