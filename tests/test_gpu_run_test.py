@@ -143,6 +143,23 @@ def test_run_test_yaml_to_metric_table(workdir, synth_sd):
     assert d.max() <= 1 and (d > 0).mean() < 5e-3, (d.max(), (d > 0).mean())      # only round-half ties may flip a level
 
 
+def test_frames_in_flight_equal_one_at_a_time(workdir, monkeypatch):
+    """The validation loop keeps SAVSR_STREAMS frames in flight on HIP streams; per-frame results are bitwise those of the
+    reference's one-frame-at-a-time flow (video_base_model.py:51-53)."""
+    from savsr_amd.test import run_test
+    opt = _opt(workdir)
+    opt["val"]["save_img"] = False
+    multi = run_test(opt)
+    monkeypatch.setenv("SAVSR_STREAMS", "1")
+    opt1 = _opt(workdir)
+    opt1["val"]["save_img"] = False
+    single = run_test(opt1)
+    for a, b in zip(multi, single):
+        assert a["metrics"] == b["metrics"]
+        for f in a["frames"]:
+            assert torch.equal(a["frames"][f], b["frames"][f])
+
+
 def test_post_resize_when_output_and_gt_differ(workdir):
     """sr_model.py:290-294: bicubic + antialias resize of the output to the GT size (GPU kernel vs torch CPU)."""
     from savsr_amd.models import build_model
