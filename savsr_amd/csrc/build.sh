@@ -16,8 +16,12 @@ OUT=${OUT:-libsavsr_hip.so}
 OBJDIR=${OBJDIR:-.}
 mkdir -p "$OBJDIR"
 
+# per-file flags: satu.hip keeps its scalar fp32 arithmetic scalar -- packed fp32 instructions (v_pk_mul / v_pk_fma) are an
+# anti-lever beside MFMAs on gfx950 (MI355X_MICROARCH.md); the explicit 2-vector code of the HR stage is unaffected
+file_flags() { case "$1" in satu.hip) echo "-fno-slp-vectorize";; *) echo "";; esac; }
 flags_for() {  # flags_for <src>
-  if [ -z "${EXTRA_ONLY:-}" ] || [[ " ${EXTRA_ONLY} " == *" $1 "* ]]; then echo "$BASE_FLAGS ${EXTRA_FLAGS:-}"; else echo "$BASE_FLAGS"; fi
+  local f="$BASE_FLAGS $(file_flags "$1")"
+  if [ -z "${EXTRA_ONLY:-}" ] || [[ " ${EXTRA_ONLY} " == *" $1 "* ]]; then echo "$f ${EXTRA_FLAGS:-}"; else echo "$f"; fi
 }
 sig_for() { printf '%s' "$HIPCC $(flags_for "$1")" | sha1sum | cut -d' ' -f1; }
 

@@ -1,0 +1,129 @@
+// Developer micro-benchmark: does the v_mfma_f32_16x16x32_bf16 shape buy wall time over v_mfma_f32_32x32x16_bf16 in the conv
+// kernel's regime (MI355X_MICROARCH.md, "DVFS give-back" item 7: 1.12-1.15x the FLOP/s at equal cycles with every operand
+// re-read from LDS)?  Both kernels: 8 waves per CU, each wave a 64 co x 64 px fp32 output tile (64 accumulator registers),
+// split-bf16 products (3 MFMAs per product), per K = 32 slice 16 fragment reads of 1 KiB from LDS (random bf16 data), one
+// barrier per 9 slices -- 24 MFMAs of 32 cycles vs 48 of 16 cycles per slice.
+// Build: hipcc --offload-arch=gfx950 -O3 mfma_shape.hip -o mfma_shape
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+
+constexpr int LDS_UNITS = 8192;     // 128 KiB of fragments
+
+template <int SHAPE, int NVALU>
+__global__ __launch_bounds__(512) void k(const bf16x8* __restrict__ src, float* out, long long* cyc, int phases) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    bf16x8* lds = reinterpret_cast<bf16x8*>(raw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < LDS_UNITS; i += 512) lds[i] = src[i];
+    __syncthreads();
+    float vx[4] = {1.f + lane, 2.f, 3.f, 4.f};
+    const float vy = 1.0001f;
+    float sum = 0.f;
+    long long t0, t1;
+    if (SHAPE == 0) {
+        f32x16 acc[4];
+        for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        bf16x8 f[2][8];
+        for (int i = 0; i < 8; ++i) { f[0][i] = lds[i * 64 + lane]; f[1][i] = lds[512 + i * 64 + lane]; }
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int ph = 0; ph < phases; ++ph) {
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {                       // 18 K = 16 steps = 9 K = 32 slices
+                if (s == 16) __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[(s + 1) & 1][i] = lds[(((s * 8 + i) * 5 + ph) & 63) * 64 + (i < 4 ? wave * 512 : 4096) % LDS_UNITS + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8* fr = f[s & 1];
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(a & 1) * 2 + (part & 1)], fr[4 + (a >> 1) * 2 + (part >> 1)], acc[a], 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < NVALU; ++v) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(vx[v & 3]) : "v"(vy));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        t1 = __builtin_amdgcn_s_memtime();
+        for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) sum += acc[a][r];
+    } else {
+        f32x4 acc[16];
+        for (int a = 0; a < 16; ++a) for (int r = 0; r < 4; ++r) acc[a][r] = 0.f;
+        bf16x8 f[2][16];
+        for (int i = 0; i < 16; ++i) { f[0][i] = lds[i * 64 + lane]; f[1][i] = lds[1024 + i * 64 + lane]; }
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int ph = 0; ph < phases; ++ph) {
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {                        // 9 K = 32 slices
+                if (s == 8) __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 16; ++i) f[(s + 1) & 1][i] = lds[(((s * 16 + i) * 5 + ph) & 63) * 64 + (i < 8 ? wave * 512 : 4096) % LDS_UNITS + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8* fr = f[s & 1];                      // [0..7]: B (4 px tiles x hi, lo), [8..15]: A (4 co tiles x hi, lo)
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+#pragma unroll
+                    for (int a = 0; a < 16; ++a) {
+                        acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[8 + (a & 3) * 2 + (part & 1)], fr[(a >> 2) * 2 + (part >> 1)], acc[a], 0, 0, 0);
+                        if ((a & 1) == 0) {
+#pragma unroll
+                            for (int v = 0; v < NVALU; ++v) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(vx[v & 3]) : "v"(vy));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        t1 = __builtin_amdgcn_s_memtime();
+        for (int a = 0; a < 16; ++a) for (int r = 0; r < 4; ++r) sum += acc[a][r];
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = sum + vx[0] + vx[1] + vx[2] + vx[3];
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int SHAPE, int NVALU>
+void run(const char* name, const bf16x8* src, int reps) {
+    float* out; long long* cyc;
+    hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8);
+    const int phases = 400;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k<SHAPE, NVALU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_UNITS * 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<SHAPE, NVALU>), dim3(256), dim3(512), LDS_UNITS * 16, 0, src, out, cyc, phases);
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<SHAPE, NVALU>), dim3(256), dim3(512), LDS_UNITS * 16, 0, src, out, cyc, phases);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    const double flop = 2.0 * 64 * 64 * 32 * 3 * 9 * phases * 8 * 256;      // issued bf16 flops per launch
+    printf("%-52s %8.1f us  %7.1f TFLOP/s issued  %9lld cycles  %.2f GHz\n", name, ms * 1e3, flop / (ms * 1e-3) / 1e12, h[0], h[0] / (ms * 1e6));
+    hipFree(out); hipFree(cyc);
+}
+
+int main() {
+    bf16x8* src;
+    hipMalloc(&src, LDS_UNITS * 16);
+    {
+        unsigned short* h = (unsigned short*)malloc(LDS_UNITS * 16);
+        srand(1);
+        for (int i = 0; i < LDS_UNITS * 8; ++i) {               // random bf16 in [-2, 2): sign, exponent 125..127, 7 random mantissa bits
+            const unsigned short sign = (rand() & 1) << 15, ex = (unsigned short)(125 + rand() % 3) << 7, man = rand() & 127;
+            h[i] = sign | ex | man;
+        }
+        hipMemcpy(src, h, LDS_UNITS * 16, hipMemcpyHostToDevice);
+        free(h);
+    }
+    for (int round = 0; round < 2; ++round) {                   // interleaved rounds in one process
+        run<0, 0>("32x32x16, fragment reads + barrier", src, 10);
+        run<1, 0>("16x16x32, fragment reads + barrier", src, 10);
+        run<0, 3>("32x32x16, + 3 VALU per MFMA", src, 10);
+        run<1, 3>("16x16x32, + 3 VALU per 2 MFMAs (same VALU per flop)", src, 10);
+    }
+    return 0;
+}
