@@ -37,9 +37,6 @@
 #ifndef LR_PACKED
 #define LR_PACKED 0               // LeakyReLU * x accumulation with v_pk_mul / v_pk_fma (1) or plain v_mul / v_max / v_fmac (0)
 #endif
-#ifndef LR_ROWS2
-#define LR_ROWS2 0                // 1: LR stage with two pixel rows per wave, one wave per SIMD (satu_lr2_kernel; measured 55 us against 46); 0 = one row per wave, 8 waves
-#endif
 
 namespace savsr {
 
@@ -405,282 +402,6 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
     for (int g = 0; g < 4; ++g) {
         f32x4 c = {accC[4 * g], accC[4 * g + 1], accC[4 * g + 2], accC[4 * g + 3]};
         *reinterpret_cast<f32x4*>(recf + 64 * NB + 8 * g + 4 * half) = c;     // rows 8g + 4 half + {0..3} = C-stack channels
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// LR stage, TWO pixel rows per wave (LR_ROWS2): the same tile (8 rows x 32 px per workgroup) and the same phases, but four
-// waves -- ONE per SIMD -- each owning rows w and w + 4.  Every weight fragment read from LDS now feeds two rows' MFMAs
-// (0.33 instead of 0.67 fragment reads per MFMA; 0.83 instead of 1.33 LDS reads per MFMA in all), a SIMD's matrix pipe is
-// fed by one in-order stream instead of two waves arbitrating for it (PMC of the 8-wave kernel: MFMA busy 42 %, 49 % of the
-// wave cycles stalled at issue), and four waves meet at the phase barriers instead of eight.
-// ------------------------------------------------------------------------------------------
-template <bool DIAG, int NB>
-__global__ __launch_bounds__(256, 1) void satu_lr2_kernel(const LrParams p) {
-    constexpr int REC = rec_floats(NB);
-    constexpr int NW = 4, NTHR = 64 * NW, ROWS = 2;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xt = smem;                                                   // [432][36]: replicate-padded x tile of one channel group
-    bf16x8* wbuf = reinterpret_cast<bf16x8*>(smem + LR_NPX * LR_XS);    // [2][LR_PHASE]: weight slabs of a kernel row, double buffered
-    float* kbl = smem + LR_NPX * LR_XS + 2 * LR_PHASE * 4;              // [25][64] kernel_conv bias
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
-    const int x0 = blockIdx.x * LR_TW, y0 = blockIdx.y * LR_TH;
-    const int gx = x0 + px;
-    const int cx = gx < p.w ? gx : p.w - 1;
-    int gy[ROWS];
-    long long cpix[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        gy[r] = y0 + wave + NW * r;
-        const int cy = gy[r] < p.h ? gy[r] : p.h - 1;
-        cpix[r] = ((long long)cy * p.row_px + cx) * p.pix + 8 * half;
-    }
-
-    const int stamps_on = DIAG ? __builtin_amdgcn_readfirstlane(g_satu_stamps_on) & 1 : 0;
-    long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long t_prev = stamps_on ? SATU_T() : 0;
-    const long long t_begin = t_prev;
-#define LR2_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
-
-    const bf16x8* kw = reinterpret_cast<const bf16x8*>(p.wt.kconv_w);
-    // weight slabs of phase ph (= channel group ph / 5, kernel row ph % 5) -> LDS buffer b: 40 pieces of 1 KiB, 10 per wave
-    auto dma_phase = [&](int ph, int b) {
-        const int cg = ph / 5, ky = ph - 5 * cg;
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                glds16(kw + (long long)((ky * 5 + i) * 2 + cg) * LR_SLAB + (wave + NW * q) * 64 + lane, wbuf + b * LR_PHASE + i * LR_SLAB + (wave + NW * q) * 64);
-    };
-    constexpr int XT_IT = (LR_NPX * 8 + NTHR - 1) / NTHR;              // 14 float4 per thread
-    f32x4 xv[XT_IT];
-    auto xt_load = [&](int cg) {
-#pragma unroll
-        for (int i = 0; i < XT_IT; ++i) {
-            const int e = tid + i * NTHR;
-            const int pl = (e < LR_NPX * 8 ? e : 0) >> 3, c4 = e & 7;
-            const int r = pl / LR_XC, c = pl - r * LR_XC;
-            int sy = y0 - LR_HALO + r, sx = x0 - LR_HALO + c;
-            sy = sy < 0 ? 0 : (sy > p.h - 1 ? p.h - 1 : sy);
-            sx = sx < 0 ? 0 : (sx > p.w - 1 ? p.w - 1 : sx);
-            xv[i] = *reinterpret_cast<const f32x4*>(p.x + ((long long)sy * p.row_px + sx) * p.pix + 32 * cg + 4 * c4);
-        }
-    };
-    auto xt_store = [&]() {
-#pragma unroll
-        for (int i = 0; i < XT_IT; ++i) {
-            const int e = tid + i * NTHR;
-            if (e < LR_NPX * 8) *reinterpret_cast<f32x4*>(xt + (e >> 3) * LR_XS + 4 * (e & 7)) = xv[i];
-        }
-    };
-
-    // ---- prologue ---------------------------------------------------------------------------------------------
-    dma_phase(0, 0);
-    xt_load(0);
-    bf16x8 sth[ROWS][4], stl[ROWS][4];                // B operands of the kernel-prediction GEMM: st[16 ks + 8 half + j][pixel]
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const f32x4* g = reinterpret_cast<const f32x4*>(p.st + cpix[r] + 16 * ks);
-            split8v(g[0], g[1], sth[r][ks], stl[r][ks]);
-        }
-    for (int e = tid; e < 25 * 64 / 4; e += NTHR) reinterpret_cast<f32x4*>(kbl)[e] = reinterpret_cast<const f32x4*>(p.wt.kconv_b)[e];
-    xt_store();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    LR2_MARK(0);
-
-    struct AFrag { bf16x8 ah[4], al[4]; };
-    f32x16 sta[2][ROWS];
-#pragma unroll
-    for (int cg = 0; cg < 2; ++cg) {                  // unrolled: sta[cg] must stay in registers
-        f32x16 sacc[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[r][i] = 0.f;
-#pragma unroll 1
-        for (int ky = 0; ky < 5; ++ky) {
-            const int ph = cg * 5 + ky, buf = ph & 1;
-            if (ph + 1 < 10) dma_phase(ph + 1, buf ^ 1);
-            if (ph == 4) xt_load(1);                  // the second channel group's x tile flies under this phase
-            if (ph + 1 >= 10) {                       // projection image: (2 NB + 1) x 8 KB
-#pragma unroll
-                for (int i = 0; i < 2 * NB + 1; ++i)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        glds16(reinterpret_cast<const bf16x8*>(p.wt.proj_w) + (i * 8 + wave + NW * q) * 64 + lane, wbuf + (buf ^ 1) * LR_PHASE + (i * 8 + wave + NW * q) * 64);
-            }
-            const bf16x8* wl = wbuf + buf * LR_PHASE + lane;
-            auto bias_read = [&](int kx, int g) -> f32x4 {       // kernel_conv bias (the initial accumulator), quad g
-                return *reinterpret_cast<const f32x4*>(kbl + (ky * 5 + kx) * 64 + cg * 32 + 4 * half + 8 * g);
-            };
-            auto x_read = [&](int kx, int g, int r) -> f32x4 {   // x_pad at tap (ky, kx), channel quad g of this half, row r of this wave
-                return *reinterpret_cast<const f32x4*>(xt + ((wave + NW * r + ky) * LR_XC + px + kx) * LR_XS + 4 * half + 8 * g);
-            };
-            auto lrelu_x = [&](int g, const f32x16& acc, const f32x4 xq, f32x16& sa) {   // sta += LeakyReLU_0.1(K) * x_pad   (:228, :297-313)
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-#if !LR_PACKED
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {         // plain VALU: packed fp32 instructions are an anti-lever beside MFMAs (MI355X_MICROARCH.md)
-                    float sv = sa[4 * g + q], m_tmp = 0.1f * acc[4 * g + q];      // (see satu_lr_kernel)
-                    asm volatile("v_max_f32 %0, %2, %0\n\tv_fmac_f32 %1, %0, %3" : "+v"(m_tmp), "+v"(sv) : "v"(acc[4 * g + q]), "v"(xq[q]));
-                    sa[4 * g + q] = sv;
-                }
-                return;
-#endif
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const f32x2 k = {acc[4 * g + 2 * h2], acc[4 * g + 2 * h2 + 1]};
-                    const f32x2 t = k * f32x2{0.1f, 0.1f};
-                    float m0, m1;
-                    asm volatile("v_max_f32 %0, %2, %3\n\tv_max_f32 %1, %4, %5" : "=&v"(m0), "=&v"(m1) : "v"(k[0]), "v"(t[0]), "v"(k[1]), "v"(t[1]));
-                    f32x2 sv = {sa[4 * g + 2 * h2], sa[4 * g + 2 * h2 + 1]};
-                    const f32x2 m = {m0, m1}, x2 = {xq[2 * h2], xq[2 * h2 + 1]};
-                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(sv) : "v"(m), "v"(x2));
-                    sa[4 * g + 2 * h2] = sv[0];
-                    sa[4 * g + 2 * h2 + 1] = sv[1];
-                }
-            };
-            AFrag fr;
-            f32x16 acc[2][ROWS];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { fr.ah[ks] = wl[(ks * 2 + 0) * 64]; fr.al[ks] = wl[(ks * 2 + 1) * 64]; }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = bias_read(0, g);
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) { acc[0][r][4 * g] = b4[0]; acc[0][r][4 * g + 1] = b4[1]; acc[0][r][4 * g + 2] = b4[2]; acc[0][r][4 * g + 3] = b4[3]; }
-            }
-            f32x4 b_pf = bias_read(1, 0), x_pf[ROWS] = {b_pf, b_pf};
-            // 20 groups of 6 MFMAs (tap kx = G / 4, k-step ks = G % 4, both rows); the previous tap's LeakyReLU * x and the next
-            // tap's bias go BETWEEN the MFMAs, their LDS operands read one group ahead
-#pragma unroll
-            for (int G = 0; G < 20; ++G) {
-                const int kx = G / 4, ks = G % 4;
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) acc[kx & 1][r] = mma3(fr.ah[ks], fr.al[ks], sth[r][ks], stl[r][ks], acc[kx & 1][r]);
-                if (kx + 1 < 5) { fr.ah[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 0) * 64]; fr.al[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 1) * 64]; }
-                if (kx > 0) {
-#pragma unroll
-                    for (int r = 0; r < ROWS; ++r) lrelu_x(ks, acc[(kx - 1) & 1][r], x_pf[r], sacc[r]);
-                }
-                if (kx + 1 < 5) {
-#pragma unroll
-                    for (int r = 0; r < ROWS; ++r) {
-                        f32x16& an = acc[(kx + 1) & 1][r];
-                        an[4 * ks] = b_pf[0]; an[4 * ks + 1] = b_pf[1]; an[4 * ks + 2] = b_pf[2]; an[4 * ks + 3] = b_pf[3];
-                    }
-                }
-                const int G1 = G + 1, kx1 = G1 / 4, ks1 = G1 % 4;
-                if (G1 < 20) {
-                    if (kx1 > 0) {
-#pragma unroll
-                        for (int r = 0; r < ROWS; ++r) x_pf[r] = x_read(kx1 - 1, ks1, r);
-                    }
-                    if (kx1 + 1 < 5) b_pf = bias_read(kx1 + 1, ks1);
-                }
-                // the group is one basic block: ~5 vector instructions and at most one LDS read behind each of its 6 MFMAs
-#pragma unroll
-                for (int i = 0; i < 3 * ROWS; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                f32x4 xq[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) xq[g] = x_read(4, g, r);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) lrelu_x(g, acc[0][r], xq[g], sacc[r]);
-            }
-            LR2_MARK(1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the staged slabs (and x loads) have landed
-            LR2_MARK(2);
-            __syncthreads();
-            if (ky == 4 && cg == 0) {                 // every wave is done with the old x tile: swap it
-                xt_store();
-                __syncthreads();
-            }
-            LR2_MARK(3);
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) sta[cg][r] = sacc[r];
-    }
-
-    // ---- LR-side projections (bf16x3), weights in LDS buffer 0; row by row (register budget) ----
-    const bf16x8* pa = wbuf + lane;
-    const bf16x8* pb = pa + NB * 4 * 2 * 64;
-    const bf16x8* pc = pb + NB * 4 * 2 * 64;
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        f32x4 xc[8];                                  // the centre pixel's x: B operand of the Wb / C projections
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const f32x4* g = reinterpret_cast<const f32x4*>(p.x + cpix[r] + 16 * ks);
-            xc[2 * ks] = g[0];
-            xc[2 * ks + 1] = g[1];
-        }
-        f32x16 accA[NB], accB[NB], accC;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-#pragma unroll
-            for (int t = 0; t < NB; ++t) { accA[t][i] = 0.f; accB[t][i] = 0.f; }
-            accC[i] = 0.f;
-        }
-#pragma unroll
-        for (int cg = 0; cg < 2; ++cg)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const f32x4 lo4 = {sta[cg][r][8 * s2], sta[cg][r][8 * s2 + 1], sta[cg][r][8 * s2 + 2], sta[cg][r][8 * s2 + 3]};
-                const f32x4 hi4 = {sta[cg][r][8 * s2 + 4], sta[cg][r][8 * s2 + 5], sta[cg][r][8 * s2 + 6], sta[cg][r][8 * s2 + 7]};
-                bf16x8 bh, bl;
-                split8v(lo4, hi4, bh, bl);
-                const int kidx = cg * 2 + s2;
-#pragma unroll
-                for (int t = 0; t < NB; ++t)
-                    accA[t] = mma3(pa[((t * 4 + kidx) * 2 + 0) * 64], pa[((t * 4 + kidx) * 2 + 1) * 64], bh, bl, accA[t]);
-            }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 xh, xl;
-            split8v(xc[2 * ks], xc[2 * ks + 1], xh, xl);
-#pragma unroll
-            for (int t = 0; t < NB; ++t)
-                accB[t] = mma3(pb[((t * 4 + ks) * 2 + 0) * 64], pb[((t * 4 + ks) * 2 + 1) * 64], xh, xl, accB[t]);
-            accC = mma3(pc[(ks * 2 + 0) * 64], pc[(ks * 2 + 1) * 64], xh, xl, accC);
-        }
-        if (gy[r] < p.h && gx < p.w) {
-            float* recf = p.lrcat + ((long long)gy[r] * p.w + gx) * REC;
-            f32x4* rec = reinterpret_cast<f32x4*>(recf + half * 32 * NB);
-#pragma unroll
-            for (int t = 0; t < NB; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 a = {accA[t][4 * g], accA[t][4 * g + 1], accA[t][4 * g + 2], accA[t][4 * g + 3]};
-                    f32x4 b = {accB[t][4 * g], accB[t][4 * g + 1], accB[t][4 * g + 2], accB[t][4 * g + 3]};
-                    rec[t * 4 + g] = a;
-                    rec[4 * NB + t * 4 + g] = b;
-                }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 c = {accC[4 * g], accC[4 * g + 1], accC[4 * g + 2], accC[4 * g + 3]};
-                *reinterpret_cast<f32x4*>(recf + 64 * NB + 8 * g + 4 * half) = c;     // rows 8g + 4 half + {0..3} = C-stack channels
-            }
-        }
-    }
-    LR2_MARK(4);
-    if (stamps_on && tid == 0) {
-        const int b = blockIdx.x + gridDim.x * blockIdx.y;
-        if (b < SSTAMP_BLOCKS) {
-            for (int i = 0; i < 7; ++i) g_satu_stamps[b * SSTAMP_N + i] = tacc[i];
-            g_satu_stamps[b * SSTAMP_N + 7] = SATU_T() - t_begin;
-        }
     }
 }
 
@@ -1412,17 +1133,10 @@ static int lr_stage(const savsr_satu_weights* wt, const float* x, const float* s
     static_assert(lds <= 160 * 1024, "LR stage LDS budget");
     const bool diag = NB == 1 && g_satu_diag_host;
     dim3 grid((w + LR_TW - 1) / LR_TW, (h + LR_TH - 1) / LR_TH);
-#if LR_ROWS2
-    const void* fn = diag ? reinterpret_cast<const void*>(&satu_lr2_kernel<true, 1>) : reinterpret_cast<const void*>(&satu_lr2_kernel<false, NB>);
-    if (int rc = ensure_dynamic_lds(fn, (int)lds, "satu_lr_stage")) return rc;
-    if (diag) hipLaunchKernelGGL((satu_lr2_kernel<true, 1>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL((satu_lr2_kernel<false, NB>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
-#else
     const void* fn = diag ? reinterpret_cast<const void*>(&satu_lr_kernel<true, 1>) : reinterpret_cast<const void*>(&satu_lr_kernel<false, NB>);
     if (int rc = ensure_dynamic_lds(fn, (int)lds, "satu_lr_stage")) return rc;
     if (diag) hipLaunchKernelGGL((satu_lr_kernel<true, 1>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
     else hipLaunchKernelGGL((satu_lr_kernel<false, NB>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
-#endif
     return check_launch("satu_lr_kernel");
 }
 
