@@ -672,6 +672,27 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
     const f32x4* rs[4];
     recs(to, ro);
     recs(ts, rs);
+    // ---- gathers into a (rows acc_row(r, 0)) and b (rows acc_row(r, 1)) of the lane's own pixel, bias first ----
+    const f32x4* fb4 = reinterpret_cast<const f32x4*>(cst + hr_wimg_floats(1));     // LDS copy of the bias, packed [half][16]
+    f32x16 a, b;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ba = fb4[g], bb = fb4[4 + g];
+        a[4 * g] = ba[0]; a[4 * g + 1] = ba[1]; a[4 * g + 2] = ba[2]; a[4 * g + 3] = ba[3];
+        b[4 * g] = bb[0]; b[4 * g + 1] = bb[1]; b[4 * g + 2] = bb[2]; b[4 * g + 3] = bb[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                    // G(Wt27 Wb x, off): record quads 4 .. 7 (half 0), 12 .. 15 (half 1)
+        const float wk = to.wgt[k];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { fma_quad(a, g, wk, ro[k][4 + g]); fma_quad(b, g, wk, ro[k][12 + g]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                    // G(Wt27 Wa sta, soff): record quads 0 .. 3, 8 .. 11
+        const float wk = ts.wgt[k];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { fma_quad(a, g, wk, rs[k][g]); fma_quad(b, g, wk, rs[k][8 + g]); }
+    }
     // ---- t_j = sum_m r_m (C_m G(x, off))_j : the record's 32 compressed channels (quads 16 .. 23 = (m, j) at 8 m + j) ----
     f32x2 tq[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
@@ -711,27 +732,6 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
         }
         bh[0][ks] = __builtin_bit_cast(bf16x8, uxh); bl[0][ks] = __builtin_bit_cast(bf16x8, uxl);
         bh[1][ks] = __builtin_bit_cast(bf16x8, uyh); bl[1][ks] = __builtin_bit_cast(bf16x8, uyl);
-    }
-    // ---- gathers into a (rows acc_row(r, 0)) and b (rows acc_row(r, 1)) of the lane's own pixel, bias first ----
-    const f32x4* fb4 = reinterpret_cast<const f32x4*>(cst + hr_wimg_floats(1));     // LDS copy of the bias, packed [half][16]
-    f32x16 a, b;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 ba = fb4[g], bb = fb4[4 + g];
-        a[4 * g] = ba[0]; a[4 * g + 1] = ba[1]; a[4 * g + 2] = ba[2]; a[4 * g + 3] = ba[3];
-        b[4 * g] = bb[0]; b[4 * g + 1] = bb[1]; b[4 * g + 2] = bb[2]; b[4 * g + 3] = bb[3];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {                    // G(Wt27 Wb x, off): record quads 4 .. 7 (half 0), 12 .. 15 (half 1)
-        const float wk = to.wgt[k];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { fma_quad(a, g, wk, ro[k][4 + g]); fma_quad(b, g, wk, ro[k][12 + g]); }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {                    // G(Wt27 Wa sta, soff): record quads 0 .. 3, 8 .. 11
-        const float wk = ts.wgt[k];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { fma_quad(a, g, wk, rs[k][g]); fma_quad(b, g, wk, rs[k][8 + g]); }
     }
     // ---- to the MFMA's (pixel, row half) layout, then + (Wt27 Wb E) v on the bf16 matrix cores ----
 #pragma unroll
