@@ -2,7 +2,8 @@
 // kernel's regime (MI355X_MICROARCH.md, "DVFS give-back" item 7: 1.12-1.15x the FLOP/s at equal cycles with every operand
 // re-read from LDS)?  Both kernels: 8 waves per CU, each wave a 64 co x 64 px fp32 output tile (64 accumulator registers),
 // split-bf16 products (3 MFMAs per product), per K = 32 slice 16 fragment reads of 1 KiB from LDS (random bf16 data), one
-// barrier per 9 slices -- 24 MFMAs of 32 cycles vs 48 of 16 cycles per slice.
+// barrier per 9 slices -- 24 MFMAs of 32 cycles vs 48 of 16 cycles per slice.  Third variant: the 32x32x16 shape with ONE wave per
+// SIMD and a 2 x 4 register tile (64 co x 128 px, 128 accumulator registers): 12 fragment reads per 24 MFMAs.
 // Build: hipcc --offload-arch=gfx950 -O3 mfma_shape.hip -o mfma_shape
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -14,11 +15,11 @@ typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
 constexpr int LDS_UNITS = 8192;     // 128 KiB of fragments
 
 template <int SHAPE, int NVALU>
-__global__ __launch_bounds__(512) void k(const bf16x8* __restrict__ src, float* out, long long* cyc, int phases) {
+__global__ __launch_bounds__(SHAPE == 2 ? 256 : 512) void k(const bf16x8* __restrict__ src, float* out, long long* cyc, int phases) {
     extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
     bf16x8* lds = reinterpret_cast<bf16x8*>(raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < LDS_UNITS; i += 512) lds[i] = src[i];
+    for (int i = threadIdx.x; i < LDS_UNITS; i += blockDim.x) lds[i] = src[i];
     __syncthreads();
     float vx[4] = {1.f + lane, 2.f, 3.f, 4.f};
     const float vy = 1.0001f;
@@ -52,6 +53,36 @@ __global__ __launch_bounds__(512) void k(const bf16x8* __restrict__ src, float* 
         }
         t1 = __builtin_amdgcn_s_memtime();
         for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) sum += acc[a][r];
+    } else if (SHAPE == 2) {
+        // 4 waves (one per SIMD), each a 64 co x 128 px tile: 8 accumulators (128 registers), per K = 16 step 4 weight + 8 pixel
+        // fragment reads for 24 MFMAs (0.5 KiB of LDS reads per MFMA instead of 0.67); same MFMAs per CU and phase
+        f32x16 acc[8];
+        for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        bf16x8 f[2][12];
+        for (int i = 0; i < 12; ++i) { f[0][i] = lds[i * 64 + lane]; f[1][i] = lds[768 + i * 64 + lane]; }
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int ph = 0; ph < phases; ++ph) {
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {
+                if (s == 16) __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 12; ++i) f[(s + 1) & 1][i] = lds[(((s * 12 + i) * 5 + ph) & 63) * 64 + (i < 8 ? wave * 1024 + (i & 4) * 128 : 4096) % LDS_UNITS + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8* fr = f[s & 1];                      // [0..7]: B (4 px rows x hi, lo), [8..11]: A (2 co tiles x hi, lo)
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) {
+                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[8 + (a & 1) * 2 + (part & 1)], fr[(a >> 1) * 2 + (part >> 1)], acc[a], 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < NVALU; ++v) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(vx[v & 3]) : "v"(vy));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        t1 = __builtin_amdgcn_s_memtime();
+        for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) sum += acc[a][r];
     } else {
         f32x4 acc[16];
         for (int a = 0; a < 16; ++a) for (int r = 0; r < 4; ++r) acc[a][r] = 0.f;
@@ -83,7 +114,7 @@ __global__ __launch_bounds__(512) void k(const bf16x8* __restrict__ src, float* 
         t1 = __builtin_amdgcn_s_memtime();
         for (int a = 0; a < 16; ++a) for (int r = 0; r < 4; ++r) sum += acc[a][r];
     }
-    out[blockIdx.x * 512 + threadIdx.x] = sum + vx[0] + vx[1] + vx[2] + vx[3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sum + vx[0] + vx[1] + vx[2] + vx[3];
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -94,9 +125,9 @@ void run(const char* name, const bf16x8* src, int reps) {
     const int phases = 400;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k<SHAPE, NVALU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_UNITS * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<SHAPE, NVALU>), dim3(256), dim3(512), LDS_UNITS * 16, 0, src, out, cyc, phases);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<SHAPE, NVALU>), dim3(256), dim3(SHAPE == 2 ? 256 : 512), LDS_UNITS * 16, 0, src, out, cyc, phases);
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<SHAPE, NVALU>), dim3(256), dim3(512), LDS_UNITS * 16, 0, src, out, cyc, phases);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<SHAPE, NVALU>), dim3(256), dim3(SHAPE == 2 ? 256 : 512), LDS_UNITS * 16, 0, src, out, cyc, phases);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
@@ -124,6 +155,8 @@ int main() {
         run<1, 0>("16x16x32, fragment reads + barrier", src, 10);
         run<0, 3>("32x32x16, + 3 VALU per MFMA", src, 10);
         run<1, 3>("16x16x32, + 3 VALU per 2 MFMAs (same VALU per flop)", src, 10);
+        run<2, 0>("32x32x16, 4 waves x (2 x 4) tiles, 12 reads / 24 MFMAs", src, 10);
+        run<2, 3>("32x32x16, 4 waves x (2 x 4) tiles, + 3 VALU per MFMA", src, 10);
     }
     return 0;
 }
