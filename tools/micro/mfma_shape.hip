@@ -83,6 +83,48 @@ __global__ __launch_bounds__(SHAPE == 2 ? 256 : 512) void k(const bf16x8* __rest
         }
         t1 = __builtin_amdgcn_s_memtime();
         for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) sum += acc[a][r];
+    } else if (SHAPE == 3) {
+        // Winograd F(2x2, 3x3) costed as a loop skeleton: the same conv work as one phase above (a 16 x 32 px tile, 32 input
+        // channels, 64 co) = 4 Winograd phases (8 x 32 px tile = 64 Winograd tiles, 16 channels): per phase each wave owns 2 of
+        // the 16 transform positions: 2 x (4 accumulators x 3 split products) = 24 MFMAs with 8 fragment reads per 12, two
+        // barriers (the 128 KB of transformed operands do not double-buffer whole), and the input transform + (hi, lo) split of
+        // 32 values per thread = NVALU vector instructions and 16 LDS writes of 16 B per thread.
+        f32x16 acc[8];
+        for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        bf16x8 f[2][8];
+        for (int i = 0; i < 8; ++i) { f[0][i] = lds[i * 64 + lane]; f[1][i] = lds[512 + i * 64 + lane]; }
+        f32x4 wv = {vx[0], vx[1], vx[2], vx[3]};
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int ph = 0; ph < phases; ++ph) {
+#pragma unroll
+            for (int wp = 0; wp < 4; ++wp) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) f[(h + 1) & 1][i] = lds[((((wp * 2 + h) * 8 + i) * 5 + ph) & 63) * 64 + (i < 4 ? wave * 512 : 4096) % LDS_UNITS + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8* fr = f[h & 1];
+#pragma unroll
+                    for (int part = 0; part < 3; ++part) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            acc[h * 4 + a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(a & 1) * 2 + (part & 1)], fr[4 + (a >> 1) * 2 + (part >> 1)], acc[h * 4 + a], 0, 0, 0);
+#pragma unroll
+                            for (int v = 0; v < NVALU / 24; ++v) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(vx[v & 3]) : "v"(vy));
+                            if ((part * 4 + a) % 3 == 0) {          // 4 of the 16 LDS writes per half ... x 2 halves x 2: 16 per phase
+                                wv[0] = vx[0];
+                                *reinterpret_cast<f32x4*>(&lds[6144 + ((part * 4 + a) / 3 * 512 + threadIdx.x) % 2048]) = wv;
+                                *reinterpret_cast<f32x4*>(&lds[6144 + ((part * 4 + a) / 3 * 512 + 256 + threadIdx.x) % 2048]) = wv;
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        t1 = __builtin_amdgcn_s_memtime();
+        for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) sum += acc[a][r];
     } else {
         f32x4 acc[16];
         for (int a = 0; a < 16; ++a) for (int r = 0; r < 4; ++r) acc[a][r] = 0.f;
@@ -155,6 +197,9 @@ int main() {
         run<1, 0>("16x16x32, fragment reads + barrier", src, 10);
         run<0, 3>("32x32x16, + 3 VALU per MFMA", src, 10);
         run<1, 3>("16x16x32, + 3 VALU per 2 MFMAs (same VALU per flop)", src, 10);
+        run<3, 0>("Winograd F(2,3) skeleton, MFMAs + reads + LDS writes only", src, 10);
+        run<3, 120>("Winograd F(2,3) skeleton, + 120 VALU per thread and phase", src, 10);
+        run<3, 216>("Winograd F(2,3) skeleton, + 216 VALU per thread and phase", src, 10);
         run<2, 0>("32x32x16, 4 waves x (2 x 4) tiles, 12 reads / 24 MFMAs", src, 10);
         run<2, 3>("32x32x16, 4 waves x (2 x 4) tiles, + 3 VALU per MFMA", src, 10);
     }
