@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 17
+#define SAVSR_ABI_VERSION 18
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -89,7 +89,12 @@ typedef struct savsr_conv_desc {
                                           row t (t < savsr_conv_pool_blocks(h, w)) = channel sums of pixel tile t,
                                           written at pool[t * pool_stride + co]; consumers add rows in order */
     int32_t      pool_stride;
+    int32_t      algo;                 /* SAVSR_CONV_DIRECT: `wpacked` is the image of savsr_conv_pack_index();
+                                          SAVSR_CONV_WINOGRAD (3x3, cout % 64 == 0 only): the image of savsr_conv_wino_pack() */
 } savsr_conv_desc;
+
+#define SAVSR_CONV_DIRECT   0
+#define SAVSR_CONV_WINOGRAD 1
 
 /* Elements PER PART (hi or lo) of the weight image of a (cout, cin, ksize) conv; the bf16 image
  * holds 2x that many 2-byte elements.  -1 for unsupported shapes. */
@@ -100,6 +105,12 @@ int64_t savsr_conv_packed_elems(int cout, int cin, int ksize);
  * savsr_osconv_weights stores W at index p directly.  Unaddressed entries must be zero. */
 int64_t savsr_conv_pack_index(int cout, int cin, int ksize, int co, int ci, int tap);
 int savsr_conv_pool_blocks(int h, int w);
+/* Winograd F(2x2, 3x3) form of a 3x3 conv (csrc/conv_wino.hip): same arithmetic contract as above, 16 transformed
+ * [cout x cin] products per 2x2 outputs instead of 36.  The weight image (savsr_conv_wino_packed_elems() bf16 elements, 16-B
+ * aligned) is produced ON DEVICE by savsr_conv_wino_pack from the fp32 kernel laid out [cout][ky*3+kx][cin] (channel fastest):
+ * U = G g G^T per (co, ci), split to (hi, lo) bf16, in the kernel's lane order.  -1 for unsupported shapes (cout % 64, cin % 16). */
+int64_t savsr_conv_wino_packed_elems(int cout, int cin);
+int savsr_conv_wino_pack(const float* w_ohwi, int cout, int cin, void* image, void* stream);
 int savsr_conv2d(const savsr_conv_desc* d, void* stream);
 /* n (1..6) independent convs of identical geometry (ksize, nsrc, src_ch, h, w, cout) in ONE launch
  * (grid.z = n * output-channel blocks): e.g. the per-stream convs of a ResidualBlock (savsr_arch.py:402,413)

@@ -17,7 +17,8 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 17
+ABI_VERSION = 18
+CONV_DIRECT, CONV_WINOGRAD = 0, 1
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
 
@@ -39,6 +40,7 @@ class ConvDesc(C.Structure):
         ("res2_scale", C.c_float),
         ("out", fptr), ("out_pix", C.c_int32),
         ("pool", fptr), ("pool_stride", C.c_int32),
+        ("algo", C.c_int32),
     ]
 
 
@@ -79,6 +81,8 @@ SIGNATURES = {
     "savsr_conv_packed_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "savsr_conv_pack_index": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "savsr_conv_pool_blocks": (C.c_int, [C.c_int, C.c_int]),
+    "savsr_conv_wino_packed_elems": (C.c_int64, [C.c_int, C.c_int]),
+    "savsr_conv_wino_pack": (C.c_int, [fptr, C.c_int, C.c_int, fptr, C.c_void_p]),
     "savsr_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "savsr_conv2d_batch": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "savsr_channel_sums": (C.c_int, [C.POINTER(fptr), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int64, C.c_int, fptr, C.c_void_p]),

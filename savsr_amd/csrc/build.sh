@@ -28,7 +28,7 @@ sig_for() { printf '%s' "$HIPCC $(flags_for "$1")" | sha1sum | cut -d' ' -f1; }
 stale() {   # stale <src> <obj>
   local src=$1 obj=$2
   [ ! -f "$obj" ] || [ ! -f "$obj.flags" ] || [ "$(cat "$obj.flags")" != "$(sig_for "$src")" ] ||
-    [ "$src" -nt "$obj" ] || [ common.hpp -nt "$obj" ] || [ ../../include/savsr_hip.h -nt "$obj" ]
+    [ "$src" -nt "$obj" ] || [ common.hpp -nt "$obj" ] || [ conv_common.hpp -nt "$obj" ] || [ ../../include/savsr_hip.h -nt "$obj" ]
 }
 
 compile() { # compile <src> <obj> [extra hipcc args]
@@ -46,7 +46,7 @@ compile() { # compile <src> <obj> [extra hipcc args]
 
 OBJS=()
 PIDS=()
-for f in conv_mfma.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip; do
+for f in conv_mfma.hip conv_wino.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip; do
   o="$OBJDIR/${f%.hip}.o"
   if stale "$f" "$o"; then
     compile "$f" "$o" &

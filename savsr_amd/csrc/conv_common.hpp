@@ -1,0 +1,64 @@
+// Shared by the two conv kernels (conv_mfma.hip: direct implicit GEMM; conv_wino.hip: Winograd F(2x2, 3x3)): the launch
+// parameters savsr_conv2d_batch fills from the descriptors, and the global-memory access helpers.
+#pragma once
+#include "common.hpp"
+
+namespace savsr {
+
+struct ConvParams {
+    const float* src[SAVSR_MAX_SRC];
+    int src_pix[SAVSR_MAX_SRC];      // floats between pixels of source s
+    const unsigned short* wimg;
+    const float* bias;
+    int act;
+    float slope;
+    const float* mul_px;
+    const float* res1;
+    int res1_pix;
+    const float* res2;
+    int res2_pix;
+    float res2_scale;
+    float* out;
+    int out_pix;
+    float* pool;          // optional [tiles][pool_stride]: per-tile channel sums of the stored values
+    int pool_stride;
+};
+
+constexpr int CONV_MAX_BATCH = 6;
+constexpr int CONV_WIDE_MIN_TILES = 200;       // 16-row tiles are used when a launch has at least this many of them
+constexpr int CONV_PERSISTENT_BLOCKS = 256;   // one resident workgroup per CU (117-154 KB of LDS each)
+struct MultiConvParams {
+    ConvParams c[CONV_MAX_BATCH];     // convs of identical geometry:
+    int h, w, cout, nchunk, src_ch;   //   shared shape (fixed kernarg offsets: read once, not per tile)
+    int nconv, ncob, ntx, nty;        // tile id = ((conv * ncob + cob) * nty + ty) * ntx + tx
+};
+
+// global accesses as (uniform base, 32-bit byte offset): one VGPR per address instead of a 64-bit pair
+// (savsr_conv2d validates that every tensor of a launch spans < 2 GiB).  The explicit global address space matters: the
+// epilogue's pointers pass through an asm pin, after which hipcc no longer knows their address space and emits FLAT
+// loads / stores, which also count on lgkmcnt and so tie every LDS wait of the transpose to the outstanding stores.
+#define SAVSR_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ f32x4 ldg4(const float* base, unsigned byte_off) {
+    return *(const SAVSR_GLOBAL f32x4*)((const SAVSR_GLOBAL char*)base + byte_off);
+}
+__device__ __forceinline__ float ldg1(const float* base, unsigned idx) {
+    return *((const SAVSR_GLOBAL float*)base + idx);
+}
+__device__ __forceinline__ void stg4(float* base, unsigned byte_off, const f32x4& v) {
+    *(SAVSR_GLOBAL f32x4*)((SAVSR_GLOBAL char*)base + byte_off) = v;
+}
+// max without the NaN canonicalisation hipcc puts in front of fmaxf (one extra v_max_f32 per call); operands here are
+// results of fp32 arithmetic, never signalling NaNs
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void stg1(float* base, unsigned idx, float v) {
+    *((SAVSR_GLOBAL float*)base + idx) = v;
+}
+
+// conv_wino.hip: n convs of identical geometry (3x3, cout % 64 == 0) whose `wimg` are Winograd weight images
+int launch_conv_wino(const MultiConvParams& mp, hipStream_t st);
+
+}  // namespace savsr

@@ -35,7 +35,7 @@
 // partial sums; descriptor fields are pinned in scalars once per tile and every access names the global address space.
 //
 // Replaces: every nn.Conv2d / F.conv2d of savsr_arch.py (see include/savsr_hip.h).
-#include "common.hpp"
+#include "conv_common.hpp"
 
 #ifndef CONV_INTERLEAVE
 #define CONV_INTERLEAVE 1
@@ -54,34 +54,6 @@
 
 namespace savsr {
 
-struct ConvParams {
-    const float* src[SAVSR_MAX_SRC];
-    int src_pix[SAVSR_MAX_SRC];      // floats between pixels of source s
-    const unsigned short* wimg;
-    const float* bias;
-    int act;
-    float slope;
-    const float* mul_px;
-    const float* res1;
-    int res1_pix;
-    const float* res2;
-    int res2_pix;
-    float res2_scale;
-    float* out;
-    int out_pix;
-    float* pool;          // optional [tiles][pool_stride]: per-tile channel sums of the stored values
-    int pool_stride;
-};
-
-constexpr int CONV_MAX_BATCH = 6;
-constexpr int CONV_WIDE_MIN_TILES = 200;       // 16-row tiles are used when a launch has at least this many of them
-constexpr int CONV_PERSISTENT_BLOCKS = 256;   // one resident workgroup per CU (117-154 KB of LDS each)
-struct MultiConvParams {
-    ConvParams c[CONV_MAX_BATCH];     // convs of identical geometry:
-    int h, w, cout, nchunk, src_ch;   //   shared shape (fixed kernarg offsets: read once, not per tile)
-    int nconv, ncob, ntx, nty;        // tile id = ((conv * ncob + cob) * nty + ty) * ntx + tx
-};
-
 // Diagnostics (not used by the product path): per-workgroup s_memtime stamps, enabled by
 // savsr_debug_conv_stamps(1) and read back with savsr_debug_read_conv_stamps():
 // [blk][6] = entry, after the first staging, after the first K phase, after the first tile's K loop,
@@ -94,31 +66,6 @@ __device__ __attribute__((aligned(16))) const float g_conv_zero16[4] = {0.f, 0.f
 __device__ __forceinline__ void stamp(int on, int slot) {
     if (on == 1 && threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS)
         g_conv_stamps[blockIdx.x * STAMP_N + slot] = (slot == 5) ? (long long)__builtin_amdgcn_s_memrealtime() : (long long)__builtin_amdgcn_s_memtime();
-}
-
-// global accesses as (uniform base, 32-bit byte offset): one VGPR per address instead of a 64-bit pair
-// (savsr_conv2d validates that every tensor of a launch spans < 2 GiB).  The explicit global address space matters: the
-// epilogue's pointers pass through an asm pin, after which hipcc no longer knows their address space and emits FLAT
-// loads / stores, which also count on lgkmcnt and so tie every LDS wait of the transpose to the outstanding stores.
-#define SAVSR_GLOBAL __attribute__((address_space(1)))
-__device__ __forceinline__ f32x4 ldg4(const float* base, unsigned byte_off) {
-    return *(const SAVSR_GLOBAL f32x4*)((const SAVSR_GLOBAL char*)base + byte_off);
-}
-__device__ __forceinline__ float ldg1(const float* base, unsigned idx) {
-    return *((const SAVSR_GLOBAL float*)base + idx);
-}
-__device__ __forceinline__ void stg4(float* base, unsigned byte_off, const f32x4& v) {
-    *(SAVSR_GLOBAL f32x4*)((SAVSR_GLOBAL char*)base + byte_off) = v;
-}
-// max without the NaN canonicalisation hipcc puts in front of fmaxf (one extra v_max_f32 per call); operands here are
-// results of fp32 arithmetic, never signalling NaNs
-__device__ __forceinline__ float vmax_raw(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ void stg1(float* base, unsigned idx, float v) {
-    *((SAVSR_GLOBAL float*)base + idx) = v;
 }
 
 // DIAG: the instrumented build (section stamps, timing experiments), launched only while savsr_debug_conv_stamps is on;
@@ -864,8 +811,8 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
         if (rc) return rc;
         const savsr_conv_desc& a = descs[0];
         const savsr_conv_desc& b = descs[i];
-        if (b.ksize != a.ksize || b.nsrc != a.nsrc || b.src_ch != a.src_ch || b.h != a.h || b.w != a.w || b.cout != a.cout)
-            return fail_arg("conv: all convs of a batch must share ksize / nsrc / src_ch / h / w / cout");
+        if (b.ksize != a.ksize || b.nsrc != a.nsrc || b.src_ch != a.src_ch || b.h != a.h || b.w != a.w || b.cout != a.cout || b.algo != a.algo)
+            return fail_arg("conv: all convs of a batch must share ksize / nsrc / src_ch / h / w / cout / algo");
     }
     for (int i = n; i < CONV_MAX_BATCH; ++i) mp.c[i] = mp.c[0];
     const savsr_conv_desc* d = descs;
@@ -878,6 +825,12 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
     mp.ntx = (d->w + CONV_TW - 1) / CONV_TW;
     mp.nty = (d->h + CONV_TH - 1) / CONV_TH;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d->algo == SAVSR_CONV_WINOGRAD) {
+        if (d->ksize != 3 || d->cout % 64) return fail_arg("conv: the Winograd form needs ksize 3 and cout a multiple of 64");
+        mp.nty = (d->h + 7) / 8;                          // 8 x 32-pixel tiles (pool rows: the numbering of savsr_conv_pool_blocks)
+        return launch_conv_wino(mp, st);
+    }
+    if (d->algo != SAVSR_CONV_DIRECT) return fail_arg("conv: unknown algo");
     const bool wide = cot == 64;
     if (d->ksize == 3 && wide) {
         // 16-row tiles (each wave 64 channels x 2 rows: one weight-fragment read feeds two pixel rows, 2/3 of the LDS

@@ -452,8 +452,9 @@ class HipEngine:
                   mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None,
                   pool: Optional[Tuple[torch.Tensor, int, int]] = None) -> ConvDesc:
         """pool = (partial tensor, column offset, row stride): fused global-average-pool partials of the output."""
-        wpk, bias, cout, cin, ks = weights if weights is not None else self.pw[key]
+        wpk, bias, cout, cin, ks, *rest = weights if weights is not None else self.pw[key]
         d = ConvDesc()
+        d.algo = rest[0] if rest else _lib.CONV_DIRECT
         assert len(srcs) <= _lib.MAX_SRC and all(s.ch == srcs[0].ch for s in srcs)
         assert cin == len(srcs) * srcs[0].ch, (key, cin, len(srcs), srcs[0].ch)
         assert out.ch == cout, (key, out.ch, cout)
@@ -472,6 +473,25 @@ class HipEngine:
         if pool is not None:
             d.pool, d.pool_stride = pool[0].data_ptr() + 4 * pool[1], pool[2]
         return d
+
+    def wino_image(self, w_ohwi: torch.Tensor, cout: int, cin: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Winograd F(2x2, 3x3) weight image (savsr_conv_wino_pack, on the current stream) of an fp32 DEVICE kernel laid out
+        [cout][9][cin]."""
+        n = int(self.lib.savsr_conv_wino_packed_elems(cout, cin))
+        if n < 0:
+            raise ValueError(f"no Winograd form for a {cin} -> {cout} conv (cout % 64, cin % 16)")
+        img = out if out is not None else torch.empty(n, dtype=torch.int16, device=self.dev)
+        assert w_ohwi.is_cuda and w_ohwi.dtype == torch.float32 and w_ohwi.is_contiguous() and w_ohwi.numel() == cout * 9 * cin
+        _lib.check(self.lib.savsr_conv_wino_pack(w_ohwi.data_ptr(), cout, cin, img.data_ptr(), self._stream()), "savsr_conv_wino_pack")
+        return img
+
+    def wino_weights(self, w: torch.Tensor, bias: Optional[torch.Tensor]):
+        """[cout, cin, 3, 3] fp32 (any device) -> the `weights` tuple of a Winograd-form conv."""
+        cout, cin = w.shape[:2]
+        ohwi = w.detach().to(self.dev, torch.float32).permute(0, 2, 3, 1).contiguous().view(cout, 9, cin)
+        img = self.wino_image(ohwi, cout, cin)
+        torch.cuda.current_stream().synchronize()         # `ohwi` dies here
+        return (img, None if bias is None else bias.to(self.dev, torch.float32).contiguous(), cout, cin, 3, _lib.CONV_WINOGRAD)
 
     def conv_launch(self, descs: List[ConvDesc], label: str = "conv"):
         """Independent convs of identical geometry, up to 6 per launch (savsr_conv2d_batch)."""

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="conv: convs per launch (savsr_conv2d_batch)")
     ap.add_argument("--cycles", action="store_true", help="conv / satu, library built with -DCONV_EXP=8 / -DLR_EXP=8 (+ experiments): per-workgroup s_memtime totals")
     ap.add_argument("--stamps", action="store_true", help="conv / satu: print per-workgroup section timings (s_memtime)")
+    ap.add_argument("--wino", action="store_true", help="conv: the Winograd F(2x2, 3x3) form (3x3, cout % 64 == 0)")
+    ap.add_argument("--distinct", action="store_true", help="conv: every conv of the batch gets its own inputs and weights")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     eng = E.HipEngine(synth.synth_state_dict(), SAVSR().cfg, dev)
@@ -37,11 +39,15 @@ def main():
     if a.what == "conv":
         g = torch.Generator().manual_seed(0)
         wt = torch.randn(a.cout, a.cin, a.ks, a.ks, generator=g) / (a.cin * a.ks * a.ks) ** 0.5
-        weights = (E.pack_conv_weight(wt).to(dev), torch.randn(a.cout, generator=g).to(dev), a.cout, a.cin, a.ks)
+        bias = torch.randn(a.cout, generator=g).to(dev)
+        mk = lambda wt_: eng.wino_weights(wt_, bias) if a.wino else (E.pack_conv_weight(wt_).to(dev), bias, a.cout, a.cin, a.ks)
         nsrc = max(1, a.cin // 64)
-        xs = [torch.randn(h, w, a.cin // nsrc, generator=g).to(dev) for _ in range(nsrc)]
+        nset = a.batch if a.distinct else 1
+        wsets = [mk(wt if k == 0 else torch.randn(a.cout, a.cin, a.ks, a.ks, generator=g) / (a.cin * a.ks * a.ks) ** 0.5) for k in range(nset)]
+        xsets = [[torch.randn(h, w, a.cin // nsrc, generator=g).to(dev) for _ in range(nsrc)] for _ in range(nset)]
         outs = [torch.empty(h, w, a.cout, device=dev) for _ in range(a.batch)]
-        descs = [eng.conv_desc("bench", [eng.full(x) for x in xs], eng.full(o), h, w, ACT_LRELU, 0.2, weights=weights) for o in outs]
+        descs = [eng.conv_desc("bench", [eng.full(x) for x in xsets[k % nset]], eng.full(o), h, w, ACT_LRELU, 0.2, weights=wsets[k % nset])
+                 for k, o in enumerate(outs)]
         run = lambda: eng.conv_launch(descs)
         flop = 2.0 * a.batch * a.cin * a.cout * a.ks * a.ks * h * w
     elif a.what == "satu":
