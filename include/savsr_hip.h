@@ -89,12 +89,15 @@ typedef struct savsr_conv_desc {
                                           row t (t < savsr_conv_pool_blocks(h, w)) = channel sums of pixel tile t,
                                           written at pool[t * pool_stride + co]; consumers add rows in order */
     int32_t      pool_stride;
-    int32_t      algo;                 /* SAVSR_CONV_DIRECT: `wpacked` is the image of savsr_conv_pack_index();
+    int32_t      algo;                 /* SAVSR_CONV_DIRECT / _DIRECT_THROUGHPUT: `wpacked` is the image of savsr_conv_pack_index();
                                           SAVSR_CONV_WINOGRAD (3x3, cout % 64 == 0 only): the image of savsr_conv_wino_pack() */
 } savsr_conv_desc;
 
 #define SAVSR_CONV_DIRECT   0
 #define SAVSR_CONV_WINOGRAD 1
+#define SAVSR_CONV_DIRECT_THROUGHPUT 2   /* the direct kernel, tiled for several launches in flight on different streams: 16-row
+                                            tiles from 100 of them up (120 workgroups for a 64 -> 64 conv at 180x320: slower
+                                            alone, faster in aggregate -- DESIGN.md 4a); results are bit-identical to DIRECT */
 
 /* Elements PER PART (hi or lo) of the weight image of a (cout, cin, ksize) conv; the bf16 image
  * holds 2x that many 2-byte elements.  -1 for unsupported shapes. */

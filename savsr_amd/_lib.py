@@ -18,7 +18,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
 ABI_VERSION = 18
-CONV_DIRECT, CONV_WINOGRAD = 0, 1
+CONV_DIRECT, CONV_WINOGRAD, CONV_DIRECT_THROUGHPUT = 0, 1, 2
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
 

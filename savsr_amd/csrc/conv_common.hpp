@@ -25,7 +25,8 @@ struct ConvParams {
 };
 
 constexpr int CONV_MAX_BATCH = 6;
-constexpr int CONV_WIDE_MIN_TILES = 200;       // 16-row tiles are used when a launch has at least this many of them
+constexpr int CONV_WIDE_MIN_TILES = 200;       // 16-row tiles are used when a launch has at least this many of them ...
+constexpr int CONV_WIDE_MIN_TILES_TP = 100;    // ... or this many in throughput mode (SAVSR_CONV_DIRECT_THROUGHPUT)
 constexpr int CONV_PERSISTENT_BLOCKS = 256;   // one resident workgroup per CU (117-154 KB of LDS each)
 struct MultiConvParams {
     ConvParams c[CONV_MAX_BATCH];     // convs of identical geometry:

@@ -830,13 +830,15 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
         mp.nty = (d->h + 7) / 8;                          // 8 x 32-pixel tiles (pool rows: the numbering of savsr_conv_pool_blocks)
         return launch_conv_wino(mp, st);
     }
-    if (d->algo != SAVSR_CONV_DIRECT) return fail_arg("conv: unknown algo");
+    if (d->algo != SAVSR_CONV_DIRECT && d->algo != SAVSR_CONV_DIRECT_THROUGHPUT) return fail_arg("conv: unknown algo");
     const bool wide = cot == 64;
     if (d->ksize == 3 && wide) {
         // 16-row tiles (each wave 64 channels x 2 rows: one weight-fragment read feeds two pixel rows, 2/3 of the LDS
         // traffic per MFMA and half the barriers) once they still fill the chip; 8-row tiles for small launches
         const int nty2 = (d->h + 2 * CONV_TH - 1) / (2 * CONV_TH);
-        if (d->cout % 64 == 0 && n * mp.ncob * mp.ntx * nty2 >= CONV_WIDE_MIN_TILES) {
+        // A launch of 100 .. 199 such tiles (a single 64 -> 64 conv at 180x320: 120) fills half the chip: alone it is slower than
+        // 230 8-row tiles (26 vs 19-22 us), with other streams' launches beside it the aggregate is faster (bench +2.4 %)
+        if (d->cout % 64 == 0 && n * mp.ncob * mp.ntx * nty2 >= (d->algo == SAVSR_CONV_DIRECT_THROUGHPUT ? CONV_WIDE_MIN_TILES_TP : CONV_WIDE_MIN_TILES)) {
             mp.nty = nty2;
             return launch_conv<3, 2, 2>(mp, st);
         }

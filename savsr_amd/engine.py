@@ -142,6 +142,7 @@ class HipEngine:
         self._keep: List[torch.Tensor] = []
         self._init_caches()
         self.satu_events: Optional[list] = None     # bench.py: (start, end) HIP events around SATU
+        self.conv_algo = _lib.CONV_DIRECT           # CONV_DIRECT_THROUGHPUT while several clips are in flight (forward_many / batches)
         self.use_graphs = os.environ.get("SAVSR_GRAPHS", "1") != "0"
         self.n_streams = max(1, int(os.environ.get("SAVSR_STREAMS", "3")))   # clips of a batch in flight concurrently
         self._siblings: List["HipEngine"] = []
@@ -374,6 +375,7 @@ class HipEngine:
         e._init_caches()
         e.max_shapes, e.max_scales = self.max_shapes, self.max_scales
         e.satu_events, e.use_graphs = None, self.use_graphs
+        e.conv_algo = _lib.CONV_DIRECT
         e._siblings, e._streams = [], []
         return e
 
@@ -454,7 +456,7 @@ class HipEngine:
         """pool = (partial tensor, column offset, row stride): fused global-average-pool partials of the output."""
         wpk, bias, cout, cin, ks, *rest = weights if weights is not None else self.pw[key]
         d = ConvDesc()
-        d.algo = rest[0] if rest else _lib.CONV_DIRECT
+        d.algo = rest[0] if rest else self.conv_algo
         assert len(srcs) <= _lib.MAX_SRC and all(s.ch == srcs[0].ch for s in srcs)
         assert cin == len(srcs) * srcs[0].ch, (key, cin, len(srcs), srcs[0].ch)
         assert out.ch == cout, (key, out.ch, cout)
@@ -873,12 +875,17 @@ class HipEngine:
         self._stage_tail(c, lq, out)
         return out
 
-    def _forward_graphed(self, lq: torch.Tensor, scale, out: torch.Tensor):
+    def _forward_graphed(self, lq: torch.Tensor, scale, out: torch.Tensor, throughput: bool = False):
         """hipGraph replay of the same launch sequence (three graphs: body | SATU | tail, so the SATU
         stage can be bracketed by HIP events).  The ~1400 launches of a frame cost ~11 us of host time
-        each when issued from Python; captured once per (shape, scale) they replay in tens of us."""
+        each when issued from Python; captured once per (shape, scale) they replay in tens of us.
+        throughput=True (several clips in flight on different streams): the convs are launched as
+        SAVSR_CONV_DIRECT_THROUGHPUT -- same results bit for bit, its own captured graphs."""
         sc = self._select(lq.shape, scale)
-        g = sc["graphs"]
+        if sc["graphs"] is None:
+            sc["graphs"] = {}
+        self.conv_algo = _lib.CONV_DIRECT_THROUGHPUT if throughput else _lib.CONV_DIRECT
+        g = sc["graphs"].get(throughput)
         if g is None:
             s_in = torch.empty_like(lq)
             s_out = torch.empty_like(out)
@@ -898,7 +905,7 @@ class HipEngine:
             finally:
                 self.satu_events = ev
             g = (s_in, s_out, graphs)
-            sc["graphs"] = g
+            sc["graphs"][throughput] = g
         s_in, s_out, graphs = g
         s_in.copy_(lq)
         graphs[0].replay()
@@ -939,7 +946,7 @@ class HipEngine:
             self._streams[k].wait_stream(cur)
         for i, (lq, sc) in enumerate(items):
             with torch.cuda.stream(self._streams[i % ns]):
-                engines[i % ns]._forward_graphed(lq.to(torch.float32).contiguous(), sc, outs[i])
+                engines[i % ns]._forward_graphed(lq.to(torch.float32).contiguous(), sc, outs[i], throughput=True)
         for k in range(ns):
             cur.wait_stream(self._streams[k])
         return outs
@@ -963,10 +970,11 @@ class HipEngine:
                 engines[k].satu_events = self.satu_events
             for i in range(b):
                 with torch.cuda.stream(self._streams[i % ns]):
-                    engines[i % ns]._forward_graphed(lq[i], scale, out[i])
+                    engines[i % ns]._forward_graphed(lq[i], scale, out[i], throughput=True)
             for k in range(ns):
                 cur.wait_stream(self._streams[k])
             return out
+        self.conv_algo = _lib.CONV_DIRECT
         for i in range(b):      # samples are independent (OSConv groups=b, savsr_arch.py:166-167)
             if self.use_graphs and taps is None:
                 self._forward_graphed(lq[i], scale, out[i])
