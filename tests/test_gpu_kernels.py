@@ -125,6 +125,31 @@ def test_conv2d_rejects_bad_args(eng):
     assert eng.lib.savsr_conv2d(C.byref(d), None) < 0
 
 
+def test_conv2d_algo_field(eng):
+    """savsr_conv_desc.algo: DIRECT and DIRECT_THROUGHPUT (other tiling, same bits); an unknown value and a Winograd request the
+    kernel has no form for (cout % 64) are argument errors."""
+    from savsr_amd import engine as E
+    from savsr_amd import _lib
+    g = np.random.RandomState(9)
+    h, w = 100, 320                                          # 7 x 10 16-row tiles: >= 100 of them only with two output blocks
+    wt = torch.from_numpy((g.standard_normal((128, 64, 3, 3)) / 24.0).astype(np.float32))
+    x = cl(torch.from_numpy(g.standard_normal((64, h, w)).astype(np.float32)))
+    img = _dev(E.pack_conv_weight(wt))
+    outs = []
+    for algo in (_lib.CONV_DIRECT, _lib.CONV_DIRECT_THROUGHPUT):
+        o = torch.full((h, w, 128), float("nan"), device="cuda:0")
+        eng.conv("t", [eng.full(x)], eng.full(o), h, w, weights=(img, None, 128, 64, 3, algo))
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+    d = eng.conv_desc("t", [eng.full(x)], eng.full(outs[0]), h, w, weights=(img, None, 128, 64, 3, 7))
+    assert eng.lib.savsr_conv2d(C.byref(d), None) < 0 and b"algo" in eng.lib.savsr_last_error()
+    wt48 = _dev(E.pack_conv_weight(wt[:48]))
+    o48 = torch.empty(h, w, 48, device="cuda:0")
+    d = eng.conv_desc("t", [eng.full(x)], eng.full(o48), h, w, weights=(wt48, None, 48, 64, 3, _lib.CONV_WINOGRAD))
+    assert eng.lib.savsr_conv2d(C.byref(d), None) < 0 and b"Winograd" in eng.lib.savsr_last_error()
+
+
 @pytest.mark.parametrize("tag,pfx,cin", OSCONV_CASES)
 def test_osconv_vs_golden(eng, golden, synth_sd, tag, pfx, cin):
     """OSConv2d (savsr_arch.py:139-172): pool -> routing -> attention -> aggregate -> conv."""
