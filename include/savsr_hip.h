@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 18
+#define SAVSR_ABI_VERSION 19
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -229,12 +229,15 @@ typedef struct savsr_satu_tiling {
     float   off_min_x, off_min_y;
     int32_t table_entries;   /* n_uh * n_uw; informational */
     float   step_x, step_y;  /* LR pixels per HR pixel (1 / scale_w, 1 / scale_h) for the window origin; <= 0: w / W, h / H */
+    int32_t variant;         /* wave split of the workgroup, 0 .. savsr_satu_hr_variants() - 1 (0: 8 compute + 4 producer waves; 1, tail
+                                form only: 10 + 6).  Which one is faster depends on size and scale; the caller may time both. */
 } savsr_satu_tiling;
+int savsr_satu_hr_variants(void);
 int64_t savsr_satu_hr_lds_bytes(int tail_form, int n_table, int tile_rows, int tile_cols32, int lr_rows, int lr_cols);
 /* resident workgroups per CU the HR kernel is written for (plan tiles so that this many fit 160 KiB of LDS) */
 int savsr_satu_hr_occupancy_target(int tail_form);
 /* compute waves of an HR workgroup: a tile of tile_rows x tile_cols32 "wave tiles" (one row x 32 pixels) is dealt over them */
-int savsr_satu_hr_compute_waves(void);
+int savsr_satu_hr_compute_waves(int variant);
 int savsr_satu_hr_rows_per_wave_tile(int tail_form);   /* HR rows one wave tile covers (32 pixels wide) */
 
 /* Per-pixel expansion of the phase table, once per (size, scale, weights): ptab[Y][X][8] = table[idx_h[Y]][idx_w[X]] with the

@@ -17,7 +17,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 18
+ABI_VERSION = 19
 CONV_DIRECT, CONV_WINOGRAD, CONV_DIRECT_THROUGHPUT = 0, 1, 2
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
@@ -70,7 +70,7 @@ class SatuWeights(C.Structure):
 class SatuTiling(C.Structure):
     _fields_ = [("tile_rows", C.c_int32), ("tile_cols32", C.c_int32), ("lr_rows", C.c_int32), ("lr_cols", C.c_int32),
                 ("off_min_x", C.c_float), ("off_min_y", C.c_float), ("table_entries", C.c_int32),
-                ("step_x", C.c_float), ("step_y", C.c_float)]
+                ("step_x", C.c_float), ("step_y", C.c_float), ("variant", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/savsr_hip.h declares
@@ -106,7 +106,8 @@ SIGNATURES = {
     "savsr_satu_hr_tail": (C.c_int, [C.POINTER(SatuWeights), fptr, C.c_int, C.c_int, fptr, C.c_int, C.c_int, fptr, fptr, fptr, fptr, fptr,
                                      C.c_int, C.c_int, C.POINTER(SatuTiling), fptr, fptr, C.c_int64, C.c_void_p]),
     "savsr_satu_hr_occupancy_target": (C.c_int, [C.c_int]),
-    "savsr_satu_hr_compute_waves": (C.c_int, []),
+    "savsr_satu_hr_compute_waves": (C.c_int, [C.c_int]),
+    "savsr_satu_hr_variants": (C.c_int, []),
     "savsr_satu_hr_rows_per_wave_tile": (C.c_int, [C.c_int]),
     "savsr_satu_hr_lds_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "savsr_tail_gather": (C.c_int, [fptr, C.c_int64, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),

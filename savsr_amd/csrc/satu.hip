@@ -685,13 +685,13 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
     for (int k = 0; k < 4; ++k) {                    // G(Wt27 Wb x, off): record quads 4 .. 7 (half 0), 12 .. 15 (half 1)
         const float wk = to.wgt[k];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { fma_quad(a, g, wk, ro[k][4 + g]); fma_quad(b, g, wk, ro[k][12 + g]); }
+        for (int g = 0; g < 4; ++g) { fma_quad(a, g, wk, ro[k][4 + g]); if (g < 3) fma_quad(b, g, wk, ro[k][12 + g]); }   // (b's quad 3 = rows 28 .. 31: padding, never stored)
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                    // G(Wt27 Wa sta, soff): record quads 0 .. 3, 8 .. 11
         const float wk = ts.wgt[k];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { fma_quad(a, g, wk, rs[k][g]); fma_quad(b, g, wk, rs[k][8 + g]); }
+        for (int g = 0; g < 4; ++g) { fma_quad(a, g, wk, rs[k][g]); if (g < 3) fma_quad(b, g, wk, rs[k][8 + g]); }
     }
     // ---- t_j = sum_m r_m (C_m G(x, off))_j : the record's 32 compressed channels (quads 16 .. 23 = (m, j) at 8 m + j) ----
     f32x2 tq[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -778,21 +778,19 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
 // ONE workgroup per CU: HR_WAVES compute waves (wave tiles are dealt round-robin over them) + HR_PRODUCERS producer waves that
 // only issue the next tile's LDS-DMAs.  A wave's gather chain is latency-bound (LDS round trips): alone on its SIMD a wave
 // needs ~4.1 k cycles per 32-pixel tile, three waves sharing a SIMD finish one every ~1.3 k, so the kernel wants as many
-// compute waves per SIMD as the register file holds (HR_MINW waves per SIMD <-> the VGPR cap the kernel is compiled for).
+// compute waves per SIMD as the register file holds (the launch bounds give the VGPR cap the kernel is compiled for).
 // A producer wave gets ~4-5 LDS-DMAs in flight (one 1-KiB DMA per ~450 cycles, measured).
 #ifndef HR_LANE_PX
 #define HR_LANE_PX 1              // tail-projected form: lane = pixel wave tiles (hr_tile_px); 0 = two lanes per pixel (hr_tile)
 #endif
-#ifndef HR_WAVES
-#define HR_WAVES 8         // measured at 180x320 x4: 8 + 4 -> 42-44 us, 10 + 2 -> 43-46, 12 + 4 and 14 + 2 (128 VGPRs, spills) -> 47-58
-#endif
-#ifndef HR_PRODUCERS
-#define HR_PRODUCERS 4
-#endif
-#ifndef HR_MINW
-#define HR_MINW ((HR_WAVES + HR_PRODUCERS + 3) / 4)
-#endif
-constexpr int HR_THREADS = 64 * (HR_WAVES + HR_PRODUCERS);
+// Two wave splits are compiled (savsr_satu_tiling.variant; the caller picks per size / scale, results do not depend on it):
+//   variant 0 =  8 compute + 4 producer waves (3 waves per SIMD)
+//   variant 1 = 10 compute + 6 producer waves (4 per SIMD: the lane = pixel tile needs 126 VGPRs)
+// measured at 180x320, tail form (us; 8+4 -> 10+6): x4 40.4 -> 37.1, x3.7 37.3 -> 36.3, x3.9 37.2 -> 38.4, x3 28.0 -> 29.3, x2 22.0 -> 23.7,
+// (2.95, 3.75) 38.6 -> 43.9, 480x318 x(1.5, 4) 51.4 -> 60.0; other splits at x4: 12+4 38.6-39.1, 10+2 38.5-38.9, 8+8 37.9-39.3, 6+10 42-43, 14+2 50.
+constexpr int HR_VARIANTS = 2;
+__host__ __device__ constexpr int hr_compute_waves(int variant) { return variant == 1 ? 10 : 8; }
+__host__ __device__ constexpr int hr_producer_waves(int variant) { return variant == 1 ? 6 : 4; }
 // One LDS-DMA: the active lanes move 16 B each, global (uniform 64-bit base in SGPRs + a 32-bit byte offset per lane) ->
 // lds_base + 16 * lane (no registers, no ds_write).  The scalar-base form keeps the whole address computation of a staging
 // loop on the scalar unit: with a per-lane 64-bit address every DMA cost ~40 vector instructions (quarter-rate 64-bit
@@ -820,8 +818,10 @@ constexpr int HR_THREADS = 64 * (HR_WAVES + HR_PRODUCERS);
 //     (workgroups launched together stage together), and 52-55 us with the compute waves issuing the DMAs themselves -- the
 //     CU's memory pipe queues them behind the output stores, ~200 cycles of issue stall per DMA, 3.7 k cycles per tile.
 // DIAG = the instrumented build (section stamps, timing experiments); the product launch uses DIAG = false.
-template <bool DIAG, int NB>
-__global__ __launch_bounds__(HR_THREADS, HR_MINW) void satu_hr_kernel(const HrParams p) {
+template <bool DIAG, int NB, int VAR>
+__global__ __launch_bounds__(64 * (hr_compute_waves(VAR) + hr_producer_waves(VAR)), (hr_compute_waves(VAR) + hr_producer_waves(VAR) + 3) / 4)
+void satu_hr_kernel(const HrParams p) {
+    constexpr int HR_WAVES = hr_compute_waves(VAR), HR_PRODUCERS = hr_producer_waves(VAR);
     constexpr int REC = rec_floats(NB), LREC = hr_lds_rec(NB);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
@@ -1085,13 +1085,14 @@ extern "C" int savsr_debug_satu_stamps(int enable) {
 }
 
 extern "C" int savsr_satu_hr_occupancy_target(int tail_form) { (void)tail_form; return 1; }
-extern "C" int savsr_satu_hr_compute_waves(void) { return HR_WAVES; }
+extern "C" int savsr_satu_hr_variants(void) { return HR_VARIANTS; }
+extern "C" int savsr_satu_hr_compute_waves(int variant) { return variant < 0 || variant >= HR_VARIANTS ? -1 : hr_compute_waves(variant); }
 extern "C" int savsr_satu_hr_rows_per_wave_tile(int tail_form) { return tail_form && HR_LANE_PX ? 2 : 1; }
 
 // Diagnostics: resident workgroups per CU the runtime predicts for the HR / LR kernels (tail-projected form) with `lds_bytes` of dynamic LDS.
 extern "C" int savsr_debug_satu_occupancy(int which, int lds_bytes) {
     int n = -1;
-    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel<false, 1>, HR_THREADS, (size_t)lds_bytes)
+    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel<false, 1, 0>, 64 * (hr_compute_waves(0) + hr_producer_waves(0)), (size_t)lds_bytes)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_kernel<false, 1>, 512, (size_t)lds_bytes);
     return e == hipSuccess ? n : -(int)e;
 }
@@ -1171,6 +1172,16 @@ extern "C" int savsr_satu_expand_table(const float* table, int n_uw, const int32
     return check_launch("satu_expand_table_kernel");
 }
 
+template <int NB, int VAR>
+static int hr_launch(const HrParams& p, size_t lds, int grid, bool diag, hipStream_t st) {
+    constexpr int threads = 64 * (hr_compute_waves(VAR) + hr_producer_waves(VAR));
+    const void* fn = diag ? reinterpret_cast<const void*>(&satu_hr_kernel<true, 1, VAR>) : reinterpret_cast<const void*>(&satu_hr_kernel<false, NB, VAR>);
+    if (int rc = ensure_dynamic_lds(fn, 160 * 1024, "satu_hr")) return rc;
+    if (diag) hipLaunchKernelGGL((satu_hr_kernel<true, 1, VAR>), dim3(grid), dim3(threads), lds, st, p);
+    else hipLaunchKernelGGL((satu_hr_kernel<false, NB, VAR>), dim3(grid), dim3(threads), lds, st, p);
+    return check_launch("satu_hr_kernel");
+}
+
 template <int NB>
 static int hr_stage(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uh, int n_uw, const int32_t* idx_h,
                     const int32_t* idx_w, const float* ptab, const float* gyn, const float* gxn, int H, int W, const savsr_satu_tiling* tiling,
@@ -1192,7 +1203,11 @@ static int hr_stage(const savsr_satu_weights* wt, const float* lrcat, int h, int
     p.gyn = gyn; p.gxn = gxn; p.H = H; p.W = W; p.out = out; p.out_plane = out_plane; p.sched = sched;
     p.ty = 8; p.txw = 1; p.lrh = 0; p.lrw = 0; p.omin_x = 0.f; p.omin_y = 0.f;      // default: no window staging, gathers from global
     p.step_x = (float)w / (float)W; p.step_y = (float)h / (float)H;
+    int variant = 0;
     if (tiling) {
+        if (tiling->variant < 0 || tiling->variant >= HR_VARIANTS || (NB != 1 && tiling->variant != 0))
+            return fail_arg("satu_hr: tiling.variant (0 .. savsr_satu_hr_variants() - 1; the standalone form has variant 0 only)");
+        variant = tiling->variant;
         if (tiling->tile_rows < 4 || tiling->tile_rows > HR_MAX_ROWS || (tiling->tile_rows & 3) || tiling->tile_cols32 < 1 || tiling->tile_cols32 > 8 ||
             tiling->lr_rows < 0 || tiling->lr_cols < 0)
             return fail_arg("satu_hr: tiling (tile_rows a multiple of 4 in 4..64, tile_cols32 in 1..8)");
@@ -1207,17 +1222,17 @@ static int hr_stage(const savsr_satu_weights* wt, const float* lrcat, int h, int
     const size_t lds = ((size_t)hr_once_floats(NB, small) + 2 * (size_t)hr_buf_floats(NB, p.ty, p.txw, p.lrh, p.lrw, small)) * sizeof(float);
     if (lds > 160 * 1024) return fail_arg("satu_hr: staged windows + tile tables exceed 160 KiB of LDS");
     const bool diag = NB == 1 && g_satu_diag_host;
-    const void* fn = diag ? reinterpret_cast<const void*>(&satu_hr_kernel<true, 1>) : reinterpret_cast<const void*>(&satu_hr_kernel<false, NB>);
-    if (int rc = ensure_dynamic_lds(fn, 160 * 1024, "satu_hr")) return rc;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     long long ntile = (long long)p.ntx * p.nty;
     int grid = ncu;                                                    // one fat workgroup per CU
     if (grid > ntile) grid = (int)ntile;
     grid = (grid + 7) & ~7;                                            // the XCD split needs a multiple of 8
-    if (diag) hipLaunchKernelGGL((satu_hr_kernel<true, 1>), dim3(grid), dim3(HR_THREADS), lds, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL((satu_hr_kernel<false, NB>), dim3(grid), dim3(HR_THREADS), lds, static_cast<hipStream_t>(stream), p);
-    return check_launch("satu_hr_kernel");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if constexpr (NB == 1) {
+        if (variant == 1) return hr_launch<1, 1>(p, lds, grid, diag, st);
+    }
+    return hr_launch<NB, 0>(p, lds, grid, diag, st);
 }
 
 extern "C" int savsr_satu_hr_upsample(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uh, int n_uw,

@@ -697,14 +697,17 @@ class HipEngine:
         H, W = ent["H"], ent["W"]
         ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count
         forced = os.environ.get("SAVSR_HR_TILE")                                         # "rows,cols32": experiments only
-        for tail_form in (False, True):
+        nvar = int(self.lib.savsr_satu_hr_variants())
+        ent["tiling_tail_variants"] = []
+        for tail_form, variant in [(False, 0)] + [(True, v) for v in range(nvar)]:
             occ = int(self.lib.savsr_satu_hr_occupancy_target(int(tail_form)))
-            cw = int(self.lib.savsr_satu_hr_compute_waves())                             # compute waves of a workgroup
+            cw = int(self.lib.savsr_satu_hr_compute_waves(variant))                      # compute waves of a workgroup
             rpw = int(self.lib.savsr_satu_hr_rows_per_wave_tile(int(tail_form)))         # rows of a wave tile
             lds_cap = (160 * 1024) // occ - 1024                                         # `occ` workgroups per CU
             nslot = max(1, occ * ncu // 8)                                               # workgroups per XCD chunk of the tile sequence
             rec_bytes = 4 * (_lib.SATU_LRCAT_TAIL if tail_form else _lib.SATU_LRCAT)
             t = SatuTiling()
+            t.variant = variant
             t.table_entries = n_table
             t.step_x, t.step_y = 1.0 / float(scale[1]), 1.0 / float(scale[0])
             best = None
@@ -712,7 +715,7 @@ class HipEngine:
                 rx, ry = float(ox.max() - ox.min()), float(oy.max() - oy.min())
                 c_tile, c_byte, c_fix = self.HR_COST[tail_form]
                 cands = [(int(forced.split(",")[0]), int(forced.split(",")[1]))] if forced else \
-                    [(r, c) for c in (1, 2, 4) for r in (4, 8, 12, 16, 20, 24, 28, 32)]
+                    [(r, c) for c in (1, 2, 4) for r in sorted({4, 8, 12, 16, 20, 24, 28, 32, rpw * cw, 2 * rpw * cw}) if r % 4 == 0 and r <= 64]   # (+ whole rounds of the compute waves)
                 for trows, tcols in cands:
                     lr_c = min(max(int(np.ceil(32 * tcols / scale[1] + rx)) + 2, 2), w)
                     lr_r = min(int(np.ceil(trows / scale[0] + ry)) + 2, h)
@@ -730,7 +733,14 @@ class HipEngine:
             else:
                 t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = best[1], best[2], best[3], best[4]
                 t.off_min_x, t.off_min_y = float(ox.min()), float(oy.min())
-            ent["tiling_tail" if tail_form else "tiling"] = t
+            if tail_form:
+                ent["tiling_tail_variants"].append(t)
+            else:
+                ent["tiling"] = t
+        # which wave split of the HR kernel (8 + 4 or 10 + 6 waves) is faster depends on size and scale (x4: the second by 2-3 us,
+        # asymmetric scales: the first by up to 9): satu_hr() times the candidates once, on the first real frame of this size / scale
+        forced_v = os.environ.get("SAVSR_HR_VARIANT")
+        ent["tiling_tail"] = ent["tiling_tail_variants"][int(forced_v)] if forced_v else None
 
     @staticmethod
     def hr_plane(H: int, W: int) -> int:
@@ -756,13 +766,36 @@ class HipEngine:
         """HR stage of SATU (grid_sample x2, expert mixing, fusion, savsr_arch.py:262-295,353-374) -> out [64] planes of [H][W];
         tail_form: -> the 27 tail-projected planes P."""
         ax = self.satu_axes(h, w, scale)       # incl. the phase table: a function of (size, scale, weights) only, evaluated once
-        fn, wts, til = (self.lib.savsr_satu_hr_tail, self.satu_w_tail, ax["tiling_tail"]) if tail_form else \
-            (self.lib.savsr_satu_hr_upsample, self.satu_w, ax["tiling"])
-        _lib.check(fn(C.byref(wts), lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uh"], ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
-                      _ptr(ax["ptab"]), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"],
-                      C.byref(til), self.hr_sched.data_ptr() if os.environ.get("SAVSR_HR_STATIC") != "1" else None,
-                      out.data_ptr(), out_plane if out_plane is not None else ax["H"] * ax["W"], self._stream()),
-                   "savsr_satu_hr")
+        fn, wts = (self.lib.savsr_satu_hr_tail, self.satu_w_tail) if tail_form else (self.lib.savsr_satu_hr_upsample, self.satu_w)
+        sched = self.hr_sched.data_ptr() if os.environ.get("SAVSR_HR_STATIC") != "1" else None
+        plane = out_plane if out_plane is not None else ax["H"] * ax["W"]
+
+        def launch(til):
+            _lib.check(fn(C.byref(wts), lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uh"], ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
+                          _ptr(ax["ptab"]), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"],
+                          C.byref(til), sched, out.data_ptr(), plane, self._stream()), "savsr_satu_hr")
+        if not tail_form:
+            launch(ax["tiling"])
+            return out
+        if ax["tiling_tail"] is None:
+            cands = ax["tiling_tail_variants"]
+            if len(cands) == 1 or torch.cuda.is_current_stream_capturing():
+                ax["tiling_tail"] = cands[0]
+            else:                               # one-time choice: every candidate writes the same `out`, bit for bit
+                best = None
+                for til in cands:
+                    launch(til)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(4):
+                        launch(til)
+                    e1.record()
+                    e1.synchronize()
+                    t_us = e0.elapsed_time(e1)
+                    if best is None or t_us < best[0]:
+                        best = (t_us, til)
+                ax["tiling_tail"] = best[1]
+        launch(ax["tiling_tail"])
         return out
 
     def satu(self, x: Src, st: Src, row_px: int, h: int, w: int, scale, out: torch.Tensor, out_plane: Optional[int] = None):

@@ -353,16 +353,44 @@ def test_satu_tail_form_without_window_and_large_offsets(synth_sd):
         with torch.no_grad():
             ref = torch.einsum("pc,chw->phw", _wt27(sd), O.sta_upsample(sd, "upsample", x, sc, st)[0].double())
         lrcat = e2.satu_lr(e2.full(cl(x[0])), e2.full(cl(st[0])), 8, 9, 8, tail_form=True)
-        for drop_window in (False, True):
-            ax = e2.satu_axes(9, 8, sc)
-            keep = (ax["tiling_tail"].lr_rows, ax["tiling_tail"].lr_cols)
-            if drop_window:
-                ax["tiling_tail"].lr_rows, ax["tiling_tail"].lr_cols = 0, 0
-            p27 = torch.empty(27, H * W, device="cuda:0")
-            e2.satu_hr(lrcat, 9, 8, sc, p27, tail_form=True)
-            torch.cuda.synchronize()
-            ax["tiling_tail"].lr_rows, ax["tiling_tail"].lr_cols = keep
-            assert _maxerr(p27.view(27, H, W).double(), ref) < 5e-5
+        ax = e2.satu_axes(9, 8, sc)
+        for til in ax["tiling_tail_variants"]:                # both wave splits of the HR kernel, each with and without its window
+            for drop_window in (False, True):
+                ax["tiling_tail"] = til
+                keep = (til.lr_rows, til.lr_cols)
+                if drop_window:
+                    til.lr_rows, til.lr_cols = 0, 0
+                p27 = torch.empty(27, H * W, device="cuda:0")
+                e2.satu_hr(lrcat, 9, 8, sc, p27, tail_form=True)
+                torch.cuda.synchronize()
+                til.lr_rows, til.lr_cols = keep
+                assert _maxerr(p27.view(27, H, W).double(), ref) < 5e-5
+        ax["tiling_tail"] = None
+
+
+@pytest.mark.parametrize("h,w,sc", [(40, 52, (4, 4)), (33, 47, (3.5, 2)), (30, 40, (2.7, 2.7))])
+def test_satu_hr_variants_bit_identical(eng, h, w, sc):
+    """The HR kernel's wave splits (savsr_satu_tiling.variant) and tile plans are performance choices only: same planes, bit for
+    bit; the engine's one-time timing picks one of them."""
+    from savsr_amd.engine import get_hw
+    x, st = rnd((1, 64, h, w), 61, 1.0), rnd((1, 64, h, w), 62, 0.6)
+    H, W = get_hw(h, w, sc)
+    lrcat = eng.satu_lr(eng.full(cl(x[0])), eng.full(cl(st[0])), w, h, w, tail_form=True)
+    ax = eng.satu_axes(h, w, sc)
+    assert len(ax["tiling_tail_variants"]) == eng.lib.savsr_satu_hr_variants() >= 2
+    outs = []
+    for til in ax["tiling_tail_variants"]:
+        ax["tiling_tail"] = til
+        o = torch.full((27, H * W), float("nan"), device="cuda:0")
+        eng.satu_hr(lrcat, h, w, sc, o, tail_form=True)
+        outs.append(o)
+    ax["tiling_tail"] = None
+    o = torch.full((27, H * W), float("nan"), device="cuda:0")
+    eng.satu_hr(lrcat, h, w, sc, o, tail_form=True)           # the timed choice
+    torch.cuda.synchronize()
+    assert ax["tiling_tail"] is not None and bool(torch.isfinite(o).all())
+    for other in outs:
+        assert torch.equal(o, other)
 
 
 @pytest.mark.parametrize("h,w,sc", [(7, 9, (3.5, 2)), (8, 10, (2, 2.4)), (5, 16, (4, 4)), (6, 7, (1.5, 1.3))])
