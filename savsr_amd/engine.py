@@ -143,6 +143,7 @@ class HipEngine:
         self._init_caches()
         self.satu_events: Optional[list] = None     # bench.py: (start, end) HIP events around SATU
         self.conv_algo = _lib.CONV_DIRECT           # CONV_DIRECT_THROUGHPUT while several clips are in flight (forward_many / batches)
+        self._hr_choice: Dict[tuple, int] = {}      # (h, w, sh, sw) -> timed choice of the HR kernel's wave split; shared with the sibling engines
         self.use_graphs = os.environ.get("SAVSR_GRAPHS", "1") != "0"
         self.n_streams = max(1, int(os.environ.get("SAVSR_STREAMS", "3")))   # clips of a batch in flight concurrently
         self._siblings: List["HipEngine"] = []
@@ -376,6 +377,7 @@ class HipEngine:
         e.max_shapes, e.max_scales = self.max_shapes, self.max_scales
         e.satu_events, e.use_graphs = None, self.use_graphs
         e.conv_algo = _lib.CONV_DIRECT
+        e._hr_choice = self._hr_choice
         e._siblings, e._streams = [], []
         return e
 
@@ -779,7 +781,10 @@ class HipEngine:
             return out
         if ax["tiling_tail"] is None:
             cands = ax["tiling_tail_variants"]
-            if len(cands) == 1 or torch.cuda.is_current_stream_capturing():
+            ckey = (h, w, float(scale[0]), float(scale[1]))
+            if ckey in self._hr_choice:         # (a sibling engine has timed this size / scale already)
+                ax["tiling_tail"] = cands[self._hr_choice[ckey]]
+            elif len(cands) == 1 or torch.cuda.is_current_stream_capturing():
                 ax["tiling_tail"] = cands[0]
             else:                               # one-time choice: every candidate writes the same `out`, bit for bit
                 best = None
@@ -795,6 +800,7 @@ class HipEngine:
                     if best is None or t_us < best[0]:
                         best = (t_us, til)
                 ax["tiling_tail"] = best[1]
+                self._hr_choice[ckey] = best[1].variant
         launch(ax["tiling_tail"])
         return out
 
