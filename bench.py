@@ -13,6 +13,14 @@ every rank runs its own K steps (weak scaling, no data-path collective); the onl
 per-frame [PSNR-Y, SSIM-Y] rows, as the reference reduces its metric tensor once per dataset
 (video_base_model.py:108-113).  Rank 0 prints ONE JSON line.
 
+`--config run_test`: the YAML workflow (savsr_amd.test.run_test = lbasicsr/test.py:11-48) on a synthetic Vid4-shaped PNG tree
+(4 folders x `--frames-per-folder` frames, 6 datasets = 6 scales over ONE dataroot_gt, checkpoint through torch.save): frames/s of
+the whole job incl. PNG decode, upload, LR synthesis, network, metrics; GPU-busy fraction; the same frames through the network
+alone for comparison.
+
+`--gpus N` without a torch.distributed environment: this process starts the N ranks itself (fresh children through
+`python -m torch.distributed.run`, before anything here touches a GPU), relays rank 0's line and exits with the launcher's code.
+
 Config 3: the 30 symmetric Vid4 scales x1.1 ... x4.0 at LR 180x320 (batch 1, as the reference's test flow); config 4: the
 UDM10 asymmetric shapes (LR 480x318 x(1.5, 4), LR 204x636 x(3.5, 2)); config 5: a seeded stream of Vimeo90K training
 (shape, scale) pairs.  Their lines carry per-scale / per-shape figures (`per_case`) next to the aggregate `value`.
@@ -365,17 +373,182 @@ def run_config5(args, rank, world, dev, dist):
     print(json.dumps(line), flush=True)
 
 
+# --------------------------------------------------------------------------------------------- the YAML workflow
+VID4_SHAPES = [("calendar", 576, 720), ("city", 576, 704), ("foliage", 480, 720), ("walk", 480, 720)]     # GT sizes of Vid4
+RUN_TEST_SCALES = [(4, 4), (3.5, 3.5), (3, 3), (2.5, 2.5), (2, 2), (1.5, 4)]
+
+
+def make_png_tree(root, frames_per_folder):
+    """Synthetic Vid4-shaped ground truth: per folder one smooth base image, each frame a shifted crop of it (a panning
+    camera), written as PNG through the product's own writer."""
+    import numpy as np
+    from savsr_amd import io as sio
+    from savsr_amd.utils import synth
+    for k, (name, H, W) in enumerate(VID4_SHAPES):
+        base = (synth.synth_gt(3, H + 2 * frames_per_folder, W + 2 * frames_per_folder, seed=40 + k).numpy() * 255.0).round().astype(np.uint8)
+        for i in range(frames_per_folder):
+            img = base[:, 2 * i: 2 * i + H, i: i + W].transpose(1, 2, 0)[:, :, ::-1]          # HWC BGR, as cv2 / tensor2img hand it over
+            sio.imwrite(np.ascontiguousarray(img), os.path.join(root, "GT", name, f"{i:08d}.png"))
+
+
+def run_test_opt(root, ckpt, save_img):
+    ds = {}
+    for i, sc in enumerate(RUN_TEST_SCALES):
+        ds[f"test_{i + 1:02d}"] = dict(name=f"Vid4_x{sc[0]}_{sc[1]}", type="ASVideoTestDataset", dataroot_gt=os.path.join(root, "GT"),
+                                       dataroot_lq=os.path.join(root, "unused"), io_backend=dict(type="disk"), cache_data=False, num_frame=7,
+                                       padding="reflection", use_arbitrary_scale_downsampling=True, downsampling_scale=tuple(sc),
+                                       downsampling_mode="torch", phase="test")
+    return dict(name="bench_run_test", model_type="ASVSRModel", num_gpu=1, manual_seed=0, is_train=False, datasets=ds,
+                network_g=dict(type="SAVSR", num_in_ch=3, num_feat=64, num_frame=7, slid_win=3, fusion_win=5, interval=0, w1_num_block=4,
+                               w2_num_block=2, n_resgroups=4, n_resblocks=8, center_frame_idx=None),
+                path=dict(pretrain_network_g=ckpt, strict_load_g=True, resume_state=None, visualization=os.path.join(root, "results")),
+                val=dict(save_img=bool(save_img), suffix=None,
+                         metrics=dict(psnr_y=dict(type="calculate_psnr", crop_border=0, test_y_channel=True),
+                                      ssim_y=dict(type="calculate_ssim", crop_border=0, test_y_channel=True))),
+                profile_gpu_time=True)
+
+
+def run_run_test(args, rank, world, dev, dist):
+    """One pass = run_test(opt) over the 6 datasets (every rank its per-folder blocks; ONE all_gather per dataset).  Pass 1 is the
+    cold process (PNG decode + upload once, hipGraph capture per LR shape); pass 2 the steady state of a long YAML (the shipped
+    Vid4 YAML runs 42 datasets over the same files: decoded frames and captured graphs are reused).  `value` = HR Mpixel/s of
+    the steady-state pass; both passes' frames/s and GPU-busy fractions are in the line."""
+    import shutil
+    import tempfile
+    from savsr_amd import io as sio
+    from savsr_amd import models as M
+    from savsr_amd import test as T
+    from savsr_amd.utils import synth
+    root = tempfile.mkdtemp(prefix="savsr_bench_") if rank == 0 else None
+    if dist is not None:
+        box = [root]
+        dist.broadcast_object_list(box, src=0)
+        root = box[0]
+    try:
+        if rank == 0:
+            make_png_tree(root, args.frames_per_folder)
+            sd = synth.synth_state_dict(seed=0)
+            torch.save({"params": sd}, os.path.join(root, "net.pth"))
+        if dist is not None:
+            dist.barrier()
+        opt = run_test_opt(root, os.path.join(root, "net.pth"), args.save_img)
+        opt["rank"], opt["world_size"], opt["dist"] = rank, world, dist is not None
+        os.environ.setdefault("SAVSR_CACHE_SHAPES", str(4 * len(RUN_TEST_SCALES) + 1))      # every (folder, scale) LR shape stays captured
+        torch.cuda.set_device(dev)
+        model = M.build_model(opt)            # one model (= one engine, its graphs) across the passes, as in one long YAML
+        model_box = {"m": model}
+        passes = []
+        n_frames = len(VID4_SHAPES) * args.frames_per_folder * len(RUN_TEST_SCALES)
+        hr_px = sum(round_hw(H, W, sc) for _, H, W in VID4_SHAPES for sc in RUN_TEST_SCALES) * args.frames_per_folder
+        results = None
+        for p in range(2):
+            if "m" in model_box:
+                model_box["m"].gpu_ms = 0.0
+            st0 = dict(sio.frame_store().stats)
+            box = {}
+
+            def region():
+                box["res"] = T.run_test(dict(opt), model=model)
+            el = timed(dist, dev, region)
+            results = box["res"]
+            st1 = sio.frame_store().stats
+            passes.append({"wall_s": round(el, 3), "frames_per_s": round(n_frames / el, 2), "gpu_busy_frac": round(model_box["m"].gpu_ms / 1e3 / el, 4),
+                           "png_decoded_rank0": st1["decoded"] - st0["decoded"], "uploaded_rank0": st1["uploaded"] - st0["uploaded"]})
+        # the same frames through the network alone (inputs resident in HBM, groups of n_streams clips in flight, no metrics):
+        # what the workflow would run at if everything around the path were free
+        m = model_box["m"]
+        net = m.net_g
+        eng = net.engine()
+        t_net = 0.0
+        for dsname, dso in sorted(opt["datasets"].items()):
+            from savsr_amd.datasets import build_dataset
+            ds = build_dataset(dict(dso))
+            mine = ds.shard(rank, world)
+            items = [ds[i]["lq"] for i in mine]
+            net.set_scale(dso["downsampling_scale"])
+            g = eng.n_streams
+
+            def region2():
+                for k0 in range(0, len(items), g):
+                    net.forward_many(items[k0:k0 + g], [dso["downsampling_scale"]] * len(items[k0:k0 + g]))
+            t_net += timed(dist, dev, region2)
+        if rank != 0:
+            return
+        warm = passes[1]
+        line = base_line(args, world, hr_px / warm["wall_s"] / 1e6, warm["wall_s"],
+                         "YAML workflow run_test(opt): synthetic Vid4-shaped PNG tree (4 folders), 6 datasets = scales "
+                         + ", ".join(f"x{a}/{b}" for a, b in RUN_TEST_SCALES) + " over one dataroot_gt, ASVideoTestDataset + ASVSRModel, PSNR-Y / SSIM-Y",
+                         {"frames_per_folder": args.frames_per_folder, "frames": n_frames, "save_img": bool(args.save_img),
+                          "decode_threads": sio.frame_store().workers, "streams_per_gpu": eng.n_streams})
+        line["metric"] = "HR Mpixels/sec (YAML workflow, steady-state pass)"
+        line["steps"], line["warmup"], line["ms_per_step"] = 1, 1, round(1e3 * warm["wall_s"], 1)
+        line["bench_config"] = "run_test"
+        line["cold_pass"], line["steady_pass"] = passes[0], passes[1]
+        line["network_only_frames_per_s"] = round(n_frames / t_net, 2)
+        line["steady_vs_network_only"] = round(warm["frames_per_s"] / (n_frames / t_net), 4)
+        line["cold_vs_network_only"] = round(passes[0]["frames_per_s"] / (n_frames / t_net), 4)
+        line["metrics_x4"] = {k: round(v, 4) for k, v in results[0]["metrics"].items()}
+        line["roofline"] = None
+        print(json.dumps(line), flush=True)
+    finally:
+        if dist is not None:
+            dist.barrier()
+        if rank == 0 and root:
+            shutil.rmtree(root, ignore_errors=True)
+
+
+def round_hw(H, W, sc):
+    """HR pixels of one output frame of a (GT size, scale) dataset: the mod-cropped GT size."""
+    from savsr_amd.resize_gpu import as_mod_crop_hw
+    h, w = as_mod_crop_hw(H, W, (float(sc[0]), float(sc[1])))
+    return h * w
+
+
+def self_launch(args, argv):
+    """`--gpus N` outside a torch.distributed environment: start the N ranks as FRESH child processes -- nothing in this
+    process has touched a GPU (torch.cuda.device_count() does not initialise one) -- relay their output (rank 0 prints the one
+    JSON line) and exit with the launcher's return code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but this node shows {have} GPU(s); refusing to run a smaller job under that label",
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    rc = subprocess.call(cmd)
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json config (2 = the judged line)")
+    ap.add_argument("--config", type=str, default="2", choices=["2", "3", "4", "5", "run_test"],
+                    help="BASELINE.json config (2 = the judged line); run_test = the YAML workflow on a synthetic PNG tree")
+    ap.add_argument("--frames-per-folder", type=int, default=32, help="run_test: frames per synthetic folder (4 folders)")
+    ap.add_argument("--save-img", action="store_true", help="run_test: also write every output frame as PNG (val.save_img)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clips-per-step", type=int, default=18,
                     help="independent clips per step (3 in flight on separate HIP streams; 18 keeps a 20-step timed region at ~3 s)")
     ap.add_argument("--scales", type=str, default="", help="config 3: comma-separated subset, e.g. 1.1,2.5,4")
     args = ap.parse_args()
+    if args.config != "run_test":
+        args.config = int(args.config)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            self_launch(args, sys.argv[1:])            # never returns
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch one rank per GPU "
+              f"(--nproc-per-node {args.gpus}) or drop the launcher", file=sys.stderr, flush=True)
+        sys.exit(2)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -390,7 +563,9 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", device_id=dev)    # RCCL over xGMI
     try:
-        if args.config == 2:
+        if args.config == "run_test":
+            run_run_test(args, rank, world, dev, dist)
+        elif args.config == 2:
             run_config2(args, rank, world, dev, dist)
         elif args.config == 3:
             from savsr_amd.utils import workloads

@@ -1,6 +1,8 @@
 // Version / error plumbing of the C ABI.
 #include "common.hpp"
 
+#include <mutex>
+
 namespace savsr {
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -11,21 +13,27 @@ void set_error(const char* fmt, ...) {
 }
 
 int ensure_dynamic_lds(const void* fn, int bytes, const char* what) {
+    // (function, device) -> largest dynamic-LDS size the attribute has been set to.  The table is the only mutable state
+    // shared between calls, so it sits behind a mutex (one engine per device and thread in a DataParallel-style process);
+    // the attribute is set again whenever a caller asks for more than the recorded size.
     constexpr int MAX_DEV = 64, MAX_FN = 64;
-    struct Slot { const void* fn; unsigned long long devmask; };
+    struct Slot { const void* fn; int bytes[MAX_DEV]; };
     static Slot slots[MAX_FN] = {};
+    static std::mutex mu;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) { set_error("%s: hipGetDevice failed: %s", what, hipGetErrorString(e)); return (int)e; }
+    std::lock_guard<std::mutex> lock(mu);
     Slot* s = nullptr;
     for (int i = 0; i < MAX_FN; ++i) {
         if (slots[i].fn == fn) { s = &slots[i]; break; }
         if (!slots[i].fn) { slots[i].fn = fn; s = &slots[i]; break; }
     }
-    if (s && dev < MAX_DEV && (s->devmask >> dev & 1ull)) return 0;
+    const bool tracked = s && dev >= 0 && dev < MAX_DEV;
+    if (tracked && s->bytes[dev] >= bytes) return 0;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute(%d bytes LDS) failed: %s", what, bytes, hipGetErrorString(e)); return (int)e; }
-    if (s && dev < MAX_DEV) s->devmask |= 1ull << dev;
+    if (tracked) s->bytes[dev] = bytes;
     return 0;
 }
 }  // namespace savsr

@@ -17,8 +17,9 @@ inline int fail_arg(const char* what) {
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize for kernels that use more than 64 KiB of dynamic LDS.  The attribute is
-// per (function, DEVICE): the guard is keyed by the current device so that a process driving several GPUs (one engine
-// per device, or the reference's non-distributed DataParallel flow) sets it on each of them.  Benign race: idempotent.
+// per (function, DEVICE): the guard records the size set per (function, current device), so a process driving several GPUs
+// (one engine per device, or the reference's non-distributed DataParallel flow) sets it on each of them, and a later call
+// asking for more LDS sets it again.  Thread-safe (mutex around the table).
 int ensure_dynamic_lds(const void* fn, int bytes, const char* what);
 
 inline int check_launch(const char* kernel) {

@@ -7,10 +7,15 @@ Contract mirrored from lbasicsr/data/video_test_dataset.py:12-141 (VideoTestData
 crop of the ground truth (transforms.py:48-69) and the 'BI' LR synthesis (data_util.py:371-420).
 
 MI355X-first differences (results identical, work placed differently):
-  * PNG decode is host work (PIL); everything after it is on the GPU.  A folder's mod-cropped GT frames are
-    uploaded ONCE and stay in HBM (a 1280x720 frame is 11 MB; 288 GB holds any test folder), and each frame's LR
-    version is synthesised ONCE by csrc/resize.hip -- the reference re-reads and re-resizes the 7 frames of every
-    window on the CPU (7x the decode + resize work per output frame).
+  * PNG decode is host work (PIL); everything after it is on the GPU.  Files go through the process-wide `io.FrameStore`:
+    a file is decoded ONCE per process (on a small thread pool that runs a folder ahead of the GPU) and uploaded ONCE as
+    uint8, however many of the YAML's datasets (42 scales over one `dataroot_gt`) read it; the mod crop is a view and the
+    uint8 -> fp32 conversion a table lookup on the device, bit for bit `astype(float32) / 255`.  Each frame's LR version is
+    synthesised ONCE per dataset by csrc/resize.hip -- the reference re-reads and re-resizes the 7 frames of every window on
+    the CPU (7x the decode + resize work per output frame).
+  * Sharding (`shard(rank, world)`): every folder is cut into `world` contiguous blocks (harness.block_partition), so a
+    rank decodes / uploads / synthesises only its block plus the window reach (num_frame // 2 frames at each end) instead
+    of the whole folder (the reference's round-robin, video_base_model.py:50, makes every rank read every frame).
   * `__getitem__` returns DEVICE tensors ('lq' [t, c, h, w], 'gt' [c, h, w]); the DataLoader is not used (the
     reference's validation loop indexes the dataset directly too, video_base_model.py:51).
 There is no CPU path: constructing a dataset without a GPU raises.
@@ -25,9 +30,9 @@ from typing import Dict, List
 import torch
 
 from . import io as sio
-from .harness import window_indices
+from .harness import block_partition, needed_frames, window_indices
 from .registry import DATASET_REGISTRY
-from .resize_gpu import arbitrary_scale_downsample
+from .resize_gpu import arbitrary_scale_downsample, as_mod_crop_hw
 
 _SUPPORTED = ("vid4", "reds4", "redsofficial", "udm10")
 _MAX_CACHED_FOLDERS = 2      # folders whose GT / LR frames stay resident in HBM (the validation loop walks folder by folder)
@@ -92,12 +97,43 @@ class VideoTestDataset:
     def _synthesise(self) -> bool:
         return False
 
+    # ---- sharding ---------------------------------------------------------------------------------------------------
+    def folder_sizes(self) -> List[int]:
+        return [len(v) for v in self.imgs_gt.values()]               # insertion order = data_info order
+
+    def shard(self, rank: int = 0, world: int = 1) -> List[int]:
+        """Global frame indices owned by `rank` (contiguous per-folder blocks) -- and from here on this dataset object
+        only ever decodes / uploads / synthesises the frames those windows read."""
+        owned = block_partition(self.folder_sizes(), rank, world)
+        self._need = {}
+        base = 0
+        for name, paths in self.imgs_gt.items():
+            n = len(paths)
+            local = [g - base for g in owned if base <= g < base + n]
+            self._need[name] = needed_frames(local, n, self.opt["num_frame"], self.opt["padding"])
+            base += n
+        self._resident.clear()
+        return owned
+
+    def needed(self, folder: str) -> List[int]:
+        """Frames of `folder` this object loads (all of them until shard() narrows it)."""
+        need = getattr(self, "_need", None)
+        return list(range(len(self.imgs_gt[folder]))) if need is None else need[folder]
+
+    def prefetch(self, folder: str) -> None:
+        """Start decoding the needed files of `folder` in the background (the validation loop calls this one folder ahead)."""
+        store = sio.frame_store()
+        for paths in {id(self.imgs_gt[folder]): self.imgs_gt[folder], id(self.imgs_lq[folder]): self.imgs_lq[folder]}.values():
+            store.request([paths[i] for i in self.needed(folder)])
+
     # ---- per-folder residency -----------------------------------------------------------------------------------
     def _folder(self, folder: str) -> dict:
-        """GT frames (mod-cropped when the flow asks for it) and LR frames of one folder, resident on the GPU."""
+        """GT frames (mod-cropped when the flow asks for it) and LR frames of one folder, resident on the GPU:
+        {'gt': [k, 3, H, W], 'lq': [k, 3, h, w], 'pos': frame index -> row} for the k needed frames."""
         ent = self._resident.get(folder)
         if ent is None:
             ent = self._load_folder(folder)
+            ent["pos"] = {f: i for i, f in enumerate(self.needed(folder))}
             self._resident[folder] = ent
             while len(self._resident) > _MAX_CACHED_FOLDERS:
                 self._resident.popitem(last=False)
@@ -105,10 +141,25 @@ class VideoTestDataset:
             self._resident.move_to_end(folder)
         return ent
 
+    def _read(self, paths: List[str], folder: str, crop_scale) -> torch.Tensor:
+        """read_img_seq over the needed frames of a folder, through the frame store."""
+        store = sio.frame_store()
+        sel = [paths[i] for i in self.needed(folder)]
+        store.request(sel)
+        out = []
+        for p in sel:                                   # (frames of one folder may differ in size only in theory; crop per file)
+            crop = None
+            if crop_scale is not None:
+                h, w = store.host_shape(p)
+                crop = as_mod_crop_hw(h, w, crop_scale)
+            out.append(store.frames_chw_f32([p], self.device, crop)[0])
+        return torch.stack(out, 0)
+
     def _load_folder(self, folder: str) -> dict:
-        gt = sio.read_img_seq(self.imgs_gt[folder], require_as_mod_crop=self.as_down, scale=self.scale if self.as_down else None)
-        lq = sio.read_img_seq(self.imgs_lq[folder], require_as_mod_crop=self.as_down, scale=self.scale if self.as_down else None)
-        return {"gt": gt.to(self.device), "lq": lq.to(self.device)}
+        # video_test_dataset.py:101-119: only the cache_data branch mod-crops (LR and GT alike); the per-item branch (:133-137)
+        # reads both as they are
+        crop = self.scale if (self.cache_data and self.as_down) else None
+        return {"gt": self._read(self.imgs_gt[folder], folder, crop), "lq": self._read(self.imgs_lq[folder], folder, crop)}
 
     def __getitem__(self, index):
         folder = self.data_info["folder"][index]
@@ -117,7 +168,8 @@ class VideoTestDataset:
         sel = window_indices(idx, max_idx, self.opt["num_frame"], padding=self.opt["padding"])
         if max(sel) >= max_idx or min(sel) < 0:      # a folder shorter than the padding reach (the reference fails the same way, on the host)
             raise IndexError(f"folder '{folder}' has {max_idx} frames: too few for a {self.opt['num_frame']}-frame '{self.opt['padding']}' window")
-        out = {"lq": ent["lq"][sel], "gt": ent["gt"][idx], "folder": folder, "idx": self.data_info["idx"][index],
+        pos = ent["pos"]
+        out = {"lq": ent["lq"][[pos[j] for j in sel]], "gt": ent["gt"][pos[idx]], "folder": folder, "idx": self.data_info["idx"][index],
                "border": self.data_info["border"][index], "lq_path": self.data_info["lq_path"][index]}
         if "scale" in self.opt:
             out["scale"] = self.opt["scale"]
@@ -141,16 +193,20 @@ class ASVideoTestDataset(VideoTestDataset):
                                       "every shipped test YAML (data_util.py:405-412)")
 
     def _synthesise(self) -> bool:
-        # cache_data=True synthesises unconditionally (video_test_dataset.py:303-306); otherwise the YAML switch decides (:311-312)
-        return bool(self.opt.get("cache_data")) or bool(self.opt.get("use_arbitrary_scale_downsampling"))
+        # cache_data=True synthesises unconditionally (video_test_dataset.py:303-306); otherwise the YAML switch decides
+        # (:311-312: `self.opt['use_arbitrary_scale_downsampling']` -- a KeyError when the key is absent, mirrored here)
+        if self.opt.get("cache_data"):
+            return True
+        return bool(self.opt["use_arbitrary_scale_downsampling"])
 
     def _load_folder(self, folder: str) -> dict:
         scale = self.opt["scale"]
-        gt = sio.read_img_seq(self.imgs_gt[folder], require_as_mod_crop=True, scale=scale).to(self.device)
-        if self._synthesise():
-            lq = arbitrary_scale_downsample(gt, tuple(scale) if isinstance(scale, (tuple, list)) else scale)
-        else:
-            lq = gt              # :308-310 without the switch: the mod-cropped GT frames are the network input
+        scale = tuple(scale) if isinstance(scale, (tuple, list)) else scale
+        # GT: the per-item branch always mod-crops (:310,:313); the cache_data branch serves the parent's cache, which is
+        # cropped only when the YAML carries `use_arbitrary_scale_downsampling` (:101-110)
+        crop = scale if (not self.cache_data or self.as_down) else None
+        gt = self._read(self.imgs_gt[folder], folder, crop)
+        lq = arbitrary_scale_downsample(gt, scale) if self._synthesise() else gt     # :308-312
         return {"gt": gt, "lq": lq}
 
 

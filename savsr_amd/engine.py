@@ -943,9 +943,12 @@ class HipEngine:
                     self._stage_tail(c, s_in, s_out)
             finally:
                 self.satu_events = ev
-            g = (s_in, s_out, graphs)
+            # The captured launches bake in the raw device pointers of this (size, scale)'s SATU tables (phase table, per-pixel
+            # expansion, row / column index and coordinate arrays).  Replays never go through satu_axes(), so its LRU neither sees
+            # them nor may it free them: the graph tuple owns a reference and the tables live exactly as long as the graph does.
+            g = (s_in, s_out, graphs, self.satu_axes(lq.shape[-2], lq.shape[-1], scale))
             sc["graphs"][throughput] = g
-        s_in, s_out, graphs = g
+        s_in, s_out, graphs = g[:3]
         s_in.copy_(lq)
         graphs[0].replay()
         if self.satu_events is not None:

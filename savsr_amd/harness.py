@@ -47,13 +47,39 @@ def window_indices(crt_idx: int, max_frame_num: int, num_frames: int = 7, paddin
     return out
 
 
-def gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int) -> torch.Tensor:
-    """All ranks' per-frame rows in frame order.  local: [len(frame_indices(n_total, rank, world)), k].
-    One padded all_gather (RCCL all_gather_into_tensor on GPU tensors; list all_gather on gloo)."""
+def block_partition(folder_sizes: Sequence[int], rank: int, world: int) -> List[int]:
+    """Frames owned by `rank` when every folder is cut into `world` CONTIGUOUS blocks (global indices, folders laid out one
+    after the other as in `data_info`).  Same units and same independence as the reference's round-robin
+    (video_base_model.py:50; frames are independent: hidden state restarts per window), but a rank then needs only its block
+    plus the window reach at both ends (`needed_frames`) -- 1/world of a folder's decode / upload / LR-synthesis work instead
+    of all of it.  Block r of an n-frame folder is [r*n // world, (r+1)*n // world): sizes differ by at most one."""
+    out, base = [], 0
+    for n in folder_sizes:
+        out.extend(range(base + (rank * n) // world, base + ((rank + 1) * n) // world))
+        base += n
+    return out
+
+
+def needed_frames(owned_local: Sequence[int], n: int, num_frames: int = 7, padding: str = "reflection") -> List[int]:
+    """Frames of an n-frame folder that the windows of `owned_local` read (sorted): the block + a halo of num_frames // 2
+    on each side, folded back inside the folder by the padding rule."""
+    need = set()
+    for i in owned_local:
+        need.update(window_indices(i, n, num_frames, padding))
+    return sorted(need)
+
+
+def gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int, owners: Optional[Sequence[Sequence[int]]] = None) -> torch.Tensor:
+    """All ranks' per-frame rows in frame order.  local: [frames owned by `rank`, k], in the order of its index list.
+    owners[r] = global frame indices of rank r (every rank passes the same lists; default: the reference's round-robin
+    `frame_indices`).  One padded all_gather (RCCL all_gather_into_tensor on GPU tensors; list all_gather on gloo)."""
     import torch.distributed as dist
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return local                     # no process group: nothing to gather (a single-rank GROUP still runs the collective)
-    per = (n_total + world - 1) // world
+    if owners is None:
+        owners = [frame_indices(n_total, r, world) for r in range(world)]
+    assert len(owners) == world and sum(len(o) for o in owners) == n_total and local.shape[0] == len(owners[rank])
+    per = max(1, max(len(o) for o in owners))
     k = local.shape[1]
     padded = torch.zeros(per, k, dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
@@ -67,9 +93,33 @@ def gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int) -> tor
         parts = torch.stack(lst, 0)
     out = torch.empty(n_total, k, dtype=local.dtype, device=local.device)
     for r in range(world):
-        idx = frame_indices(n_total, r, world)
-        out[idx] = parts[r, : len(idx)]
+        idx = list(owners[r])
+        if idx:
+            out[torch.as_tensor(idx, device=local.device)] = parts[r, : len(idx)]
     return out
+
+
+def aggregate_rows(allrows: torch.Tensor, metric_cols: Sequence[Tuple[str, int]], folders: Sequence[str], dataset_name: str = "",
+                   scale=None) -> dict:
+    """What the reference does with the reduced metric tensor (video_base_model.py:108-113, 125-167), device-free:
+    allrows [n_frames, k] in frame order -> float32 table of the requested metrics (the reference accumulates in float32
+    tensors, :36-37) -> per-folder frame tables -> per-folder means -> the mean over FOLDERS (not over frames).
+    metric_cols: (metric name, column of allrows); folders[i] = folder of frame i."""
+    names = [m for m, _ in metric_cols]
+    table = allrows[:, [c for _, c in metric_cols]].to(torch.float32).cpu()
+    frames = {}
+    for f in dict.fromkeys(folders):
+        frames[f] = table[[i for i, g in enumerate(folders) if g == f]]
+    avg = {f: torch.mean(t, dim=0) for f, t in frames.items()}
+    total = {m: 0.0 for m in names}
+    for t in avg.values():
+        for i, m in enumerate(names):
+            total[m] += t[i].item()
+    for m in names:
+        total[m] /= max(1, len(avg))
+    return {"dataset": dataset_name, "scale": scale, "metrics": total,
+            "folders": {f: {m: t[i].item() for i, m in enumerate(names)} for f, t in avg.items()},
+            "frames": {f: frames[f].clone() for f in avg}}
 
 
 def validate_folder(net: Callable, lq_frames: torch.Tensor, gt_frames: Sequence[torch.Tensor], scale: Tuple[float, float],

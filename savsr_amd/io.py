@@ -102,3 +102,178 @@ def result_img_path(visualization_root: str, dataset_name: str, folder: str, lq_
     else:
         img_name = osp.splitext(osp.basename(lq_path))[0]
     return osp.join(visualization_root, dataset_name, folder, f"{img_name}_{suffix if suffix else name}.png")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Decoded-frame store: one per process, shared by every dataset.  The shipped test YAMLs define up to 42 datasets over ONE
+# `dataroot_gt` (options/test/SAVSR/test_SAVSR_Vid4_asBI.yml:8-517: the same frames at 42 scales); the reference re-reads
+# and re-decodes every window's 7 PNGs per output frame and per dataset (video_test_dataset.py:297-328).  Here a file is
+# decoded ONCE (host, PIL, on a small thread pool that runs ahead of the GPU), uploaded ONCE as uint8 (1/4 of the fp32
+# bytes over PCIe) and stays in HBM (a 1280x720 frame is 2.8 MB: 288 GB holds any test set); every dataset then takes its
+# mod crop as a view and converts to fp32 on the device.
+# ----------------------------------------------------------------------------------------------------------------------
+import threading                                      # noqa: E402
+from concurrent.futures import Future, ThreadPoolExecutor  # noqa: E402
+from typing import Dict, Iterable                     # noqa: E402
+
+
+def decode_rgb_u8(path: str) -> np.ndarray:
+    """One image file -> HWC RGB uint8 (what cv2.imread returns, channel order reversed)."""
+    return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB")))
+
+
+class FrameStore:
+    def __init__(self, host_bytes: Optional[int] = None, device_bytes: Optional[int] = None, workers: Optional[int] = None):
+        gib = 1 << 30
+        self.host_cap = int(float(os.environ.get("SAVSR_DECODE_CACHE_GB", "8")) * gib) if host_bytes is None else host_bytes
+        self.dev_cap = int(float(os.environ.get("SAVSR_GT_CACHE_GB", "32")) * gib) if device_bytes is None else device_bytes
+        n = workers if workers is not None else int(os.environ.get("SAVSR_DECODE_THREADS", "0"))
+        if n <= 0:
+            n = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+        self.workers = n
+        self._pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="savsr-decode")
+        self._lock = threading.Lock()
+        self._host: "OrderedDict[tuple, object]" = OrderedDict()      # key -> ndarray | Future
+        self._host_bytes = 0
+        self._dev: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()
+        self._dev_bytes = 0
+        self._dev_files: Dict[tuple, int] = {}                        # file key -> devices holding it
+        self._shape: Dict[tuple, Tuple[int, int]] = {}                # file key -> (H, W)
+        self._lut: Dict[str, torch.Tensor] = {}
+        self.stats = {"decoded": 0, "host_hits": 0, "uploaded": 0, "device_hits": 0}
+
+    @staticmethod
+    def _key(path: str) -> tuple:
+        st = os.stat(path)
+        return (osp.abspath(path), st.st_mtime_ns, st.st_size)
+
+    def _decode(self, path: str) -> np.ndarray:
+        img = decode_rgb_u8(path)
+        with self._lock:
+            self.stats["decoded"] += 1
+        return img
+
+    def request(self, paths: Iterable[str]) -> None:
+        """Start decoding `paths` in the background (no-op for files already decoded or in flight)."""
+        for p in paths:
+            k = self._key(p)
+            with self._lock:
+                if k in self._host or self._dev_files.get(k, 0) > 0:
+                    continue
+                self._host[k] = self._pool.submit(self._decode, p)
+
+    def host(self, path: str) -> np.ndarray:
+        """HWC RGB uint8 of one file (blocks until its decode is done; decodes here when nobody requested it)."""
+        k = self._key(path)
+        with self._lock:
+            ent = self._host.get(k)
+            if ent is None:
+                ent = self._pool.submit(self._decode, path)
+                self._host[k] = ent
+            elif not isinstance(ent, Future):
+                self.stats["host_hits"] += 1
+                self._host.move_to_end(k)
+                self._shape[k] = (int(ent.shape[0]), int(ent.shape[1]))
+                return ent
+        img = ent.result()
+        self._shape[k] = (int(img.shape[0]), int(img.shape[1]))
+        with self._lock:
+            if isinstance(self._host.get(k), Future):
+                self._host[k] = img
+                self._host_bytes += img.nbytes
+                while self._host_bytes > self.host_cap and len(self._host) > 1:
+                    ok, ov = next(iter(self._host.items()))
+                    if ok == k or isinstance(ov, Future):
+                        break
+                    self._host.pop(ok)
+                    self._host_bytes -= ov.nbytes
+        return img
+
+    def host_shape(self, path: str) -> Tuple[int, int]:
+        """(H, W) of a file that is resident on a device or decoded (decodes it otherwise)."""
+        k = self._key(path)
+        hw = self._shape.get(k)
+        if hw is None:
+            a = self.host(path)
+            hw = (int(a.shape[0]), int(a.shape[1]))
+        return hw
+
+    def device(self, path: str, device: torch.device) -> torch.Tensor:
+        """[H, W, 3] RGB uint8 on `device` (uploaded once per file and device)."""
+        k = (self._key(path), str(device))
+        t = self._dev.get(k)
+        if t is not None:
+            self.stats["device_hits"] += 1
+            self._dev.move_to_end(k)
+            return t
+        t = torch.from_numpy(self.host(path)).to(device, non_blocking=False)
+        self.stats["uploaded"] += 1
+        self._dev[k] = t
+        self._dev_bytes += t.numel()
+        self._dev_files[k[0]] = self._dev_files.get(k[0], 0) + 1
+        while self._dev_bytes > self.dev_cap and len(self._dev) > 1:
+            ok, ov = self._dev.popitem(last=False)
+            self._dev_bytes -= ov.numel()
+            self._dev_files[ok[0]] -= 1
+        with self._lock:                          # the host copy has served its purpose once the frame is resident in HBM
+            ent = self._host.pop(k[0], None)
+            if ent is not None and not isinstance(ent, Future):
+                self._host_bytes -= ent.nbytes
+        return t
+
+    def frames_chw_f32(self, paths: Sequence[str], device: torch.device, crop_hw: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+        """read_img_seq (data_util.py:29-60) for files through the store: [t, 3, h, w] RGB fp32 in [0, 1] on `device`, bit for bit
+        the host path's `uint8.astype(float32) / 255` (a 256-entry table built with that very numpy expression is indexed on the
+        device), optionally cropped to the top-left crop_hw (the arbitrary-scale mod crop, transforms.py:48-69)."""
+        dk = str(device)
+        lut = self._lut.get(dk)
+        if lut is None:
+            lut = torch.from_numpy(np.arange(256, dtype=np.uint8).astype(np.float32) / 255.0).to(device)
+            self._lut[dk] = lut
+        out = []
+        for p in paths:
+            u8 = self.device(p, device)
+            if crop_hw is not None:
+                u8 = u8[: crop_hw[0], : crop_hw[1]]
+            idx = u8.permute(2, 0, 1).reshape(-1).to(torch.int64)
+            out.append(torch.index_select(lut, 0, idx).view(3, u8.shape[0], u8.shape[1]))
+        return torch.stack(out, 0)
+
+    def clear(self):
+        with self._lock:
+            self._host.clear()
+            self._host_bytes = 0
+        self._dev.clear()
+        self._dev_files.clear()
+        self._dev_bytes = 0
+
+
+_STORE: Optional[FrameStore] = None
+
+
+def frame_store() -> FrameStore:
+    """The process-wide store (created on first use)."""
+    global _STORE
+    if _STORE is None:
+        _STORE = FrameStore()
+    return _STORE
+
+
+_WRITER: Optional[ThreadPoolExecutor] = None
+_PENDING: List[Future] = []
+
+
+def imwrite_async(img: np.ndarray, file_path: str) -> None:
+    """imwrite on a small thread pool (PNG encode is zlib work that releases the GIL): the validation loop hands the uint8
+    frame over and goes on launching; flush_writes() at the end of a dataset waits for the files and re-raises a failure."""
+    global _WRITER
+    if _WRITER is None:
+        _WRITER = ThreadPoolExecutor(max_workers=max(1, min(4, frame_store().workers)), thread_name_prefix="savsr-png")
+    _PENDING.append(_WRITER.submit(imwrite, img, file_path))
+    if len(_PENDING) >= 64:                           # bound the queue (a 720p frame is 2.8 MB)
+        _PENDING.pop(0).result()
+
+
+def flush_writes() -> None:
+    while _PENDING:
+        _PENDING.pop(0).result()

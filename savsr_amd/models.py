@@ -25,7 +25,7 @@ import torch
 
 from . import io as sio
 from .archs import build_network
-from .harness import frame_indices, gather_rows
+from .harness import aggregate_rows, block_partition, frame_indices, gather_rows
 from .metrics import tensor2img
 from .registry import METRIC_REGISTRY, MODEL_REGISTRY
 from .resize_gpu import resize_bicubic_aa
@@ -103,6 +103,11 @@ class VideoBaseModel(BaseModel):
         return out
 
     # ---- one dataset -----------------------------------------------------------------------------------------------
+    def _group_scale(self, net):
+        """Scale the grouped (forward_many) path runs with: what `test()` would use for the same frame.  VideoBaseModel.test
+        does not touch the network's scale (video_base_model.py / sr_model.py:200-212): whatever was set last stays."""
+        return tuple(net.scale)
+
     def dist_validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
         from .metrics_gpu import psnr_ssim_y
         dataset = getattr(dataloader, "dataset", dataloader)
@@ -113,7 +118,14 @@ class VideoBaseModel(BaseModel):
         with_metrics = metrics_opt is not None
         rank, world = self.opt.get("rank", 0), self.opt.get("world_size", 1)
         n = len(dataset)
-        mine = frame_indices(n, rank, world)                          # :50
+        # Frame partition (:50).  The reference deals frames round-robin, which makes every rank read every file; a dataset
+        # that can shard itself hands out contiguous per-folder blocks instead and then loads only its block + window reach.
+        if hasattr(dataset, "shard"):
+            mine = dataset.shard(rank, world)
+            owners = [block_partition(dataset.folder_sizes(), r, world) for r in range(world)]
+        else:
+            mine = frame_indices(n, rank, world)
+            owners = None
         names = list(metrics_opt.keys()) if with_metrics else []
         crop = _gpu_metric_plan(metrics_opt) if with_metrics else None
         rows = torch.zeros(len(mine), 2, dtype=torch.float64, device=self.device)
@@ -123,12 +135,27 @@ class VideoBaseModel(BaseModel):
         # (+12 % frames/s at 180x320 x4).  Per-frame results are bitwise those of the one-at-a-time flow (`test()`).
         net = self.net_g.module if hasattr(self.net_g, "module") else self.net_g
         group = max(1, int(getattr(net.engine(), "n_streams", 1))) if hasattr(net, "forward_many") else 1
+        folders_all = dataset.data_info["folder"]
+        my_folders = list(dict.fromkeys(folders_all[i] for i in mine))
+        if hasattr(dataset, "prefetch") and my_folders:
+            dataset.prefetch(my_folders[0])
+        cur_folder = None
+        ev = []                                                        # (start, end) HIP events around the device work of a group
+        timing = bool(self.opt.get("profile_gpu_time"))
         for k0 in range(0, len(mine), group):
+            f0 = folders_all[mine[k0]]
+            if f0 != cur_folder:                                      # entering a folder: the pool decodes the NEXT one meanwhile
+                cur_folder = f0
+                nxt = my_folders.index(f0) + 1
+                if hasattr(dataset, "prefetch") and nxt < len(my_folders):
+                    dataset.prefetch(my_folders[nxt])
             vals = [dataset[idx] for idx in mine[k0:k0 + group]]
-            scale = self.opt["scale"]
+            if timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             if group > 1 and len(vals) > 1:
                 net.eval()
-                outs = net.forward_many([v["lq"] for v in vals], [scale] * len(vals))
+                outs = net.forward_many([v["lq"] for v in vals], [self._group_scale(net)] * len(vals))
             else:
                 outs = None
             for j, val in enumerate(vals):
@@ -143,38 +170,28 @@ class VideoBaseModel(BaseModel):
                 if save_img:
                     path = sio.result_img_path(self.opt["path"]["visualization"], dataset_name, val["folder"], val["lq_path"],
                                                self.opt["name"], self.opt["val"].get("suffix"))
-                    sio.imwrite(tensor2img(vis["result"]), path)
+                    sio.imwrite_async(tensor2img(vis["result"]), path)
                 if with_metrics:
                     psnr_ssim_y(vis["result"][0], vis["gt"][0], crop, out=rows[k0 + j])
                 del self.lq, self.output, self.gt
+            if timing:
+                e1.record()
+                ev.append((e0, e1))
+        if save_img:
+            sio.flush_writes()
+        if timing:
+            torch.cuda.synchronize()
+            self.gpu_ms = getattr(self, "gpu_ms", 0.0) + sum(a.elapsed_time(b) for a, b in ev)
         if not with_metrics:
             return None
-        allrows = gather_rows(rows, n, rank, world)                   # the one collective of the dataset (:108-113)
-        cols = [0 if metrics_opt[m]["type"] == "calculate_psnr" else 1 for m in names]
-        table = allrows[:, cols].to(torch.float32).cpu()              # the reference accumulates in float32 tensors (:36-37)
-        self.metric_results = {}
-        folders = dataset.data_info["folder"]
-        for f in dict.fromkeys(folders):
-            sel = [i for i, g in enumerate(folders) if g == f]
-            self.metric_results[f] = table[sel]
-        self.last_validation = self._log_validation_metric_values(current_iter, dataset_name, tb_logger, names)
+        allrows = gather_rows(rows, n, rank, world, owners)           # the one collective of the dataset (:108-113)
+        cols = [(m, 0 if metrics_opt[m]["type"] == "calculate_psnr" else 1) for m in names]
+        self.last_validation = aggregate_rows(allrows, cols, folders_all, dataset_name, self.opt.get("scale"))   # :125-167
+        self.metric_results = self.last_validation["frames"]
         return self.last_validation
 
     def nondist_validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
         return self.dist_validation(dataloader, current_iter, tb_logger, save_img)       # :120-123
-
-    def _log_validation_metric_values(self, current_iter, dataset_name, tb_logger, names):
-        """:125-167 -- per-folder means, then the mean over folders; returned instead of logged."""
-        avg = {f: torch.mean(t, dim=0) for f, t in self.metric_results.items()}
-        total = {m: 0.0 for m in names}
-        for f, t in avg.items():
-            for i, m in enumerate(names):
-                total[m] += t[i].item()
-        for m in names:
-            total[m] /= len(avg)
-        return {"dataset": dataset_name, "scale": self.opt.get("scale"), "metrics": total,
-                "folders": {f: {m: t[i].item() for i, m in enumerate(names)} for f, t in avg.items()},
-                "frames": {f: self.metric_results[f].clone() for f in avg}}
 
 
 @MODEL_REGISTRY.register()
@@ -187,6 +204,10 @@ class ASVSRModel(VideoBaseModel):
         net.eval()
         with torch.no_grad():
             self.output = self.net_g(self.lq)
+
+    def _group_scale(self, net):
+        net.set_scale(self.opt["scale"])          # asvsr_model.py:54-57: the dataset's scale, set before every forward
+        return tuple(net.scale)
 
 
 def build_model(opt):

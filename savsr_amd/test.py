@@ -21,7 +21,9 @@ from .models import build_model
 from .options import parse_test_options
 
 
-def run_test(opt: Union[str, dict], root_path: str = ".") -> List[dict]:
+def run_test(opt: Union[str, dict], root_path: str = ".", model=None) -> List[dict]:
+    """model: an already built model (build_model(opt)) to run the datasets through -- several YAMLs / passes over one set of
+    weights then share its engine (captured graphs, packed weights); None builds one from `opt` as test.py:35 does."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if isinstance(opt, str):
@@ -40,7 +42,10 @@ def run_test(opt: Union[str, dict], root_path: str = ".") -> List[dict]:
             own_group = True
     try:
         test_sets = [build_dataset(d) for _, d in sorted(opt["datasets"].items())]       # test.py:26-32
-        model = build_model(opt)                                                          # :35
+        if model is None:
+            model = build_model(opt)                                                      # :35
+        else:
+            model.opt["rank"], model.opt["world_size"], model.opt["dist"] = opt["rank"], opt["world_size"], opt["dist"]
         results = []
         for ds in test_sets:                                                              # :37-48
             results.append(model.validation(ds, current_iter=opt["name"], tb_logger=None, save_img=opt["val"].get("save_img", False)))

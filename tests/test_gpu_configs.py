@@ -102,3 +102,43 @@ def test_mixed_scale_stream_reuses_engine(net):
         if key in first:
             assert torch.equal(first[key], out)
         first[key] = out
+
+
+def test_live_graphs_keep_their_satu_tables(synth_sd, monkeypatch):
+    """A captured hipGraph bakes in the device pointers of its (size, scale)'s SATU tables.  More live (shape, scale) graphs
+    than the table LRU holds (here 3 shapes x 2 scales = 6 graphs, table cap max(shapes, scales) = 4) must not let a table
+    be freed under a graph that can still be replayed: revisiting the oldest pairs replays their graphs bitwise."""
+    import savsr_amd
+    monkeypatch.setenv("SAVSR_CACHE_SHAPES", "4")
+    monkeypatch.setenv("SAVSR_CACHE_SCALES", "2")
+    n = savsr_amd.build_network(dict(type="SAVSR")).eval()
+    n.load_state_dict(synth_sd, strict=True)
+    n = n.to("cuda:0")
+    shapes = [(24, 40), (32, 48), (40, 56)]
+    scales = [(2.5, 2.5), (3.7, 3.7)]             # one small-table and one expanded-table regime
+    first = {}
+    for h, w in shapes:
+        lq = synth.synth_clip(7, 3, h, w, seed=h)
+        for sc in scales:
+            n.set_scale(sc)
+            first[(h, w, sc)] = n(lq.to("cuda:0")).cpu()
+    eng = n.engine()
+    assert eng.cache_stats()["scales"] == 6 and eng.cache_stats()["axes"] <= 4
+    lq4 = synth.synth_clip(7, 3, 48, 64, seed=9)  # a fourth shape: its tables land in whatever the evicted ones freed
+    for sc in [(1.7, 1.7), (3.3, 3.3)]:
+        n.set_scale(sc)
+        n(lq4.to("cuda:0"))
+    for h, w in shapes:
+        lq = synth.synth_clip(7, 3, h, w, seed=h)
+        for sc in scales:
+            n.set_scale(sc)
+            assert torch.equal(n(lq.to("cuda:0")).cpu(), first[(h, w, sc)]), (h, w, sc)
+
+
+def test_config3_all_30_scales_shape_finite_bitwise(net):
+    """Every one of the 30 symmetric Vid4 scales (x1.1 ... x4.0, Vid4.yml) at the working LR size: output shape per the
+    reference's get_HW, finite, bitwise identical rerun (the oracle comparison runs on the regime-covering subset above)."""
+    lq = synth.synth_clip(7, 3, 180, 320, seed=0)
+    assert len(workloads.CONFIG3_SCALES) == 30
+    for sc in workloads.CONFIG3_SCALES:
+        _run(net, lq, sc)

@@ -216,3 +216,48 @@ def test_rccl_single_rank_gather(workdir):
                 assert torch.equal(a["frames"][f], b["frames"][f])
     finally:
         dist.destroy_process_group()
+
+
+def test_frame_store_device_path_matches_read_img_seq(workdir):
+    """io.FrameStore.frames_chw_f32 (uint8 upload + 256-entry table on the device) is bit for bit read_img_seq
+    (data_util.py:29-60: float32 / 255 on the host), with and without the arbitrary-scale mod crop."""
+    store = sio.FrameStore()
+    name, (n, H, W) = "calendar", FOLDERS["calendar"]
+    paths = sorted(sio.scandir(os.path.join(workdir, "GT", name), full_path=True))
+    dev = torch.device("cuda", 0)
+    assert torch.equal(store.frames_chw_f32(paths, dev).cpu(), sio.read_img_seq(paths))
+    sc = (1.5, 2.5)
+    crop = as_mod_crop_hw(H, W, sc)
+    assert torch.equal(store.frames_chw_f32(paths, dev, crop).cpu(), sio.read_img_seq(paths, require_as_mod_crop=True, scale=sc))
+    assert store.stats["decoded"] == n and store.stats["uploaded"] == n and store.stats["device_hits"] == n
+
+
+def test_sharded_datasets_read_their_block_only(workdir, monkeypatch):
+    """Two ranks of one dataset (contiguous per-folder blocks + window reach): every owned item is bitwise the unsharded
+    dataset's, each rank decodes / uploads fewer files than the folder holds, and a second dataset over the same
+    dataroot_gt decodes nothing."""
+    from savsr_amd import harness
+    from savsr_amd.datasets import build_dataset
+    root = os.path.join(workdir, "GT7")
+    for i in range(12):                                   # one 12-frame folder: blocks of 6 + a 3-frame reach = 9 of 12 files
+        sio.imwrite(M.tensor2img(synth.synth_gt(3, 40, 48, seed=90 + i)), os.path.join(root, "walk", f"{i:08d}.png"))
+    dopt = dict(_opt(workdir)["datasets"]["test_02"])
+    dopt["dataroot_gt"] = root
+    monkeypatch.setattr(sio, "_STORE", sio.FrameStore())
+    full = build_dataset(dict(dopt))
+    ref = [full[i] for i in range(len(full))]
+    assert sio.frame_store().stats["decoded"] == 12
+    for rank in range(2):
+        monkeypatch.setattr(sio, "_STORE", sio.FrameStore())
+        ds = build_dataset(dict(dopt))
+        mine = ds.shard(rank, 2)
+        assert mine == harness.block_partition([12], rank, 2) == list(range(6 * rank, 6 * rank + 6))
+        for i in mine:
+            it = ds[i]
+            assert torch.equal(it["lq"], ref[i]["lq"]) and torch.equal(it["gt"], ref[i]["gt"]) and it["idx"] == ref[i]["idx"]
+        st = sio.frame_store().stats
+        assert st["decoded"] == st["uploaded"] == 9, st
+        ds2 = build_dataset(dict(dopt, downsampling_scale=(2, 2), name="Vid4_x2"))      # another scale, same files
+        ds2.shard(rank, 2)
+        ds2[mine[0]]
+        assert sio.frame_store().stats["decoded"] == 9 and sio.frame_store().stats["uploaded"] == 9

@@ -69,3 +69,31 @@ def test_result_img_path():
     assert io.result_img_path("results/x/visualization", "Vid4", "calendar", "datasets/Vid4/BIx4/calendar/00000003.png", "SAVSR_x4") == \
         os.path.join("results/x/visualization", "Vid4", "calendar", "00000003_SAVSR_x4.png")
     assert io.result_img_path("v", "Vimeo90K", "f", "a/00001/0266/im4.png", "n", suffix="s") == os.path.join("v", "Vimeo90K", "f", "00001_0266_im4_s.png")
+
+
+def test_frame_store_decodes_each_file_once(tmp_path):
+    """io.FrameStore (host side; the device side is covered by tests/test_gpu_run_test.py): files requested ahead are decoded
+    on the pool, every later reader -- another dataset over the same dataroot_gt -- gets the cached array."""
+    import numpy as np
+    from savsr_amd import io as sio
+    rng = np.random.RandomState(0)
+    paths = []
+    for i in range(6):
+        p = str(tmp_path / f"{i:03d}.png")
+        sio.imwrite(rng.randint(0, 256, (9 + i, 12, 3)).astype(np.uint8), p)
+        paths.append(p)
+    st = sio.FrameStore(host_bytes=1 << 20, device_bytes=1 << 20, workers=3)
+    st.request(paths[:4])
+    st.request(paths[:4])                                                     # already in flight: nothing new
+    for p in paths:
+        a = st.host(p)
+        assert a.dtype == np.uint8 and np.array_equal(a[:, :, ::-1], sio.imread(p))
+        assert st.host_shape(p) == a.shape[:2]
+    assert st.stats["decoded"] == 6
+    for p in paths:                                                           # a second dataset over the same files
+        st.host(p)
+    assert st.stats["decoded"] == 6 and st.stats["host_hits"] >= 6
+    small = sio.FrameStore(host_bytes=700, device_bytes=0, workers=1)         # byte cap: old frames are dropped, never the one in hand
+    for p in paths:
+        small.host(p)
+    assert small._host_bytes <= 700 + 14 * 12 * 3
