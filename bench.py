@@ -166,8 +166,17 @@ def satu_roofline(eng, clip, h, w, scale, in_flight_ms=None):
          "traffic": traffic if (h, w, tuple(scale)) == (LR_H, LR_W, SCALE) else None, "traffic_source": src,
          "algorithmic_bytes": alg, "avg_ms": round(1e3 * t, 4), "lr_us": round(parts["satu_lr_us"], 1), "hr_us": round(parts["satu_hr_us"], 1),
          "tail_gather_us": round(parts["tail_us"], 1),
-         "note": "frac = launches alone on the GPU (algorithmic bytes of SURVEY 8(d): x + st read once, the [64,H,W] output written once; the kernels "
-                 "themselves write the 27 tail-projected planes instead, DESIGN.md section 4b)"}
+         "satu_plus_tail_us": round(parts["satu_lr_us"] + parts["satu_hr_us"] + parts["tail_us"], 1),
+         "frac_definition": "frac = frac_algorithmic = SURVEY 8(d)'s CONTRACT bytes (x + st read once, the [64,H,W] output written once) / time / peak: a "
+                            "figure of merit per HR pixel, NOT achieved bandwidth -- the tail-projected kernels write 27 planes instead of 64 and move "
+                            "fewer bytes; moved_frac = PMC-measured HBM bytes of these launches (`traffic`) / time / peak is the bandwidth actually "
+                            "achieved (DESIGN.md section 4b)",
+         "note": "launches alone on the GPU, each looped on the tensors of a real frame (inputs of 22-29 MB may be served by the 256 MB Infinity "
+                 "Cache, as they are in the frame itself, where the previous kernels have just written them)"}
+    r["frac_algorithmic"] = r["frac"]
+    if r["traffic"]:
+        r["moved_gbs"] = round(r["traffic"] / t / 1e9, 1)
+        r["moved_frac"] = round(r["traffic"] / t / 1e9 / HBM_PEAK_GBS, 4)
     if in_flight_ms:
         avg = sum(in_flight_ms) / len(in_flight_ms) / 1e3
         r["in_flight_avg_ms"] = round(1e3 * avg, 4)

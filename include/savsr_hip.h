@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 19
+#define SAVSR_ABI_VERSION 20
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -89,12 +89,11 @@ typedef struct savsr_conv_desc {
                                           row t (t < savsr_conv_pool_blocks(h, w)) = channel sums of pixel tile t,
                                           written at pool[t * pool_stride + co]; consumers add rows in order */
     int32_t      pool_stride;
-    int32_t      algo;                 /* SAVSR_CONV_DIRECT / _DIRECT_THROUGHPUT: `wpacked` is the image of savsr_conv_pack_index();
-                                          SAVSR_CONV_WINOGRAD (3x3, cout % 64 == 0 only): the image of savsr_conv_wino_pack() */
+    int32_t      algo;                 /* SAVSR_CONV_DIRECT or SAVSR_CONV_DIRECT_THROUGHPUT (tiling only; same results) */
 } savsr_conv_desc;
 
 #define SAVSR_CONV_DIRECT   0
-#define SAVSR_CONV_WINOGRAD 1
+/* (1 was the Winograd F(2x2, 3x3) experiment of round 2: measured slower, archived under tools/experiments/) */
 #define SAVSR_CONV_DIRECT_THROUGHPUT 2   /* the direct kernel, tiled for several launches in flight on different streams: 16-row
                                             tiles from 100 of them up (120 workgroups for a 64 -> 64 conv at 180x320: slower
                                             alone, faster in aggregate -- DESIGN.md 4a); results are bit-identical to DIRECT */
@@ -108,12 +107,6 @@ int64_t savsr_conv_packed_elems(int cout, int cin, int ksize);
  * savsr_osconv_weights stores W at index p directly.  Unaddressed entries must be zero. */
 int64_t savsr_conv_pack_index(int cout, int cin, int ksize, int co, int ci, int tap);
 int savsr_conv_pool_blocks(int h, int w);
-/* Winograd F(2x2, 3x3) form of a 3x3 conv (csrc/conv_wino.hip): same arithmetic contract as above, 16 transformed
- * [cout x cin] products per 2x2 outputs instead of 36.  The weight image (savsr_conv_wino_packed_elems() bf16 elements, 16-B
- * aligned) is produced ON DEVICE by savsr_conv_wino_pack from the fp32 kernel laid out [cout][ky*3+kx][cin] (channel fastest):
- * U = G g G^T per (co, ci), split to (hi, lo) bf16, in the kernel's lane order.  -1 for unsupported shapes (cout % 64, cin % 16). */
-int64_t savsr_conv_wino_packed_elems(int cout, int cin);
-int savsr_conv_wino_pack(const float* w_ohwi, int cout, int cin, void* image, void* stream);
 int savsr_conv2d(const savsr_conv_desc* d, void* stream);
 /* n (1..6) independent convs of identical geometry (ksize, nsrc, src_ch, h, w, cout) in ONE launch
  * (grid.z = n * output-channel blocks): e.g. the per-stream convs of a ResidualBlock (savsr_arch.py:402,413)
@@ -305,8 +298,10 @@ int savsr_metrics_psnr_ssim_y(const float* sr, int64_t sr_plane, const float* gt
 int savsr_resize_aa_axis(const float* in, int planes, int h, int w, int axis, int out_size, const int32_t* xmin,
                          const int32_t* xsize, const float* weights, int max_taps, float* out, void* stream);
 
-/* ---- diagnostics (synchronous, never called by the product path) ----------------------------
- * While a stamps mode is on, the conv / SATU launches run INSTRUMENTED builds of their kernels (template parameter
+/* ---- diagnostics: compiled ONLY into the instrumented library (SAVSR_DIAG=1 savsr_amd/csrc/build.sh ->
+ * libsavsr_hip_diag.so, loaded by the tools through SAVSR_LIB_PATH).  The product library libsavsr_hip.so carries neither
+ * these entry points nor the DIAG kernel instantiations nor any process-global switch: every product call is a pure
+ * function of its arguments.  Synchronous; while a stamps mode is on, the conv / SATU launches run INSTRUMENTED builds of their kernels (template parameter
  * DIAG); with the mode off (the default) the product kernels carry no diagnostic code at all.
  * Conv kernel, savsr_debug_conv_stamps(mode): 0 off; 1 per-workgroup s_memtime stamps [blk][6] = entry, after
  * the prologue, after the first K phase, after the first tile's K loop, after the stores drained,
@@ -314,6 +309,7 @@ int savsr_resize_aa_axis(const float* in, int planes, int h, int w, int axis, in
  * steps before it, wait, barrier, epilogue); + 16 / + 32 / + 64 / + 128 / + 256 / + 512: timing experiments that skip
  * the staging / the fragment reads / the epilogue's stores / its LDS transpose / its whole body / its bias load
  * (results invalid). */
+#ifdef SAVSR_DIAG
 int savsr_debug_conv_stamps(int enable);
 int savsr_debug_read_conv_stamps(long long* host, int nblocks);
 /* SATU LR / HR kernels: [blk][8] accumulated section times of wave 0 (see satu.hip), last = total. */
@@ -322,6 +318,7 @@ int savsr_debug_read_satu_stamps(long long* host, int nblocks);
 /* Resident workgroups per CU predicted by the runtime for the SATU HR (which = 0) / LR (1) kernel with
  * lds_bytes of dynamic LDS; < 0 = -hipError_t. */
 int savsr_debug_satu_occupancy(int which, int lds_bytes);
+#endif /* SAVSR_DIAG */
 
 #ifdef __cplusplus
 }

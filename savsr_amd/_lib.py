@@ -9,16 +9,17 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SAVSR_LIB_PATH: diagnostics only (tools/conv_experiments.sh loads an experiment build under its own name so that the
-# product library is never overwritten); unset, the in-tree product library is the only one ever loaded.
+# SAVSR_LIB_PATH: diagnostics only (the instrumented build libsavsr_hip_diag.so of `SAVSR_DIAG=1 build.sh`, or an experiment
+# build of tools/conv_experiments.sh under its own name: the product library is never overwritten); unset, the in-tree
+# product library is the only one ever loaded.
 LIB_PATH = os.environ.get("SAVSR_LIB_PATH") or os.path.join(_HERE, "csrc", "libsavsr_hip.so")
 
 MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 19
-CONV_DIRECT, CONV_WINOGRAD, CONV_DIRECT_THROUGHPUT = 0, 1, 2
+ABI_VERSION = 20
+CONV_DIRECT, CONV_DIRECT_THROUGHPUT = 0, 2
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
 
@@ -81,8 +82,6 @@ SIGNATURES = {
     "savsr_conv_packed_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "savsr_conv_pack_index": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "savsr_conv_pool_blocks": (C.c_int, [C.c_int, C.c_int]),
-    "savsr_conv_wino_packed_elems": (C.c_int64, [C.c_int, C.c_int]),
-    "savsr_conv_wino_pack": (C.c_int, [fptr, C.c_int, C.c_int, fptr, C.c_void_p]),
     "savsr_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "savsr_conv2d_batch": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "savsr_channel_sums": (C.c_int, [C.POINTER(fptr), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int64, C.c_int, fptr, C.c_void_p]),
@@ -111,15 +110,19 @@ SIGNATURES = {
     "savsr_satu_hr_rows_per_wave_tile": (C.c_int, [C.c_int]),
     "savsr_satu_hr_lds_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "savsr_tail_gather": (C.c_int, [fptr, C.c_int64, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
-    "savsr_debug_conv_stamps": (C.c_int, [C.c_int]),
-    "savsr_debug_satu_stamps": (C.c_int, [C.c_int]),
-    "savsr_debug_read_satu_stamps": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
-    "savsr_debug_satu_occupancy": (C.c_int, [C.c_int, C.c_int]),
     "savsr_resize_aa_axis": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int, fptr, C.c_void_p]),
     "savsr_metrics_blocks": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "savsr_metrics_psnr_ssim_y": (C.c_int, [fptr, C.c_int64, fptr, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "savsr_debug_read_conv_stamps": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
     "savsr_tail_residual": (C.c_int, [fptr, C.c_int64, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
+}
+
+# the instrumented library only (header section under SAVSR_DIAG; tools load it through SAVSR_LIB_PATH)
+DIAG_SIGNATURES = {
+    "savsr_debug_conv_stamps": (C.c_int, [C.c_int]),
+    "savsr_debug_read_conv_stamps": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
+    "savsr_debug_satu_stamps": (C.c_int, [C.c_int]),
+    "savsr_debug_read_satu_stamps": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
+    "savsr_debug_satu_occupancy": (C.c_int, [C.c_int, C.c_int]),
 }
 
 _lib = None
@@ -149,6 +152,11 @@ def load() -> C.CDLL:
             raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in DIAG_SIGNATURES.items():      # present in libsavsr_hip_diag.so only
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     if lib.savsr_abi_version() != ABI_VERSION:
         raise HipLibraryError("libsavsr_hip.so ABI version mismatch")
     _lib = lib

@@ -12,6 +12,13 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 BASE_FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
+# SAVSR_DIAG=1: the INSTRUMENTED library (DIAG kernel instantiations + the savsr_debug_* entry points of the header's
+# SAVSR_DIAG section) as libsavsr_hip_diag.so with its own object directory; tools load it through SAVSR_LIB_PATH.
+if [ "${SAVSR_DIAG:-0}" = "1" ]; then
+  EXTRA_FLAGS="${EXTRA_FLAGS:-} -DSAVSR_DIAG"
+  OUT=${OUT:-libsavsr_hip_diag.so}
+  OBJDIR=${OBJDIR:-diag_obj}
+fi
 OUT=${OUT:-libsavsr_hip.so}
 OBJDIR=${OBJDIR:-.}
 mkdir -p "$OBJDIR"
@@ -46,7 +53,7 @@ compile() { # compile <src> <obj> [extra hipcc args]
 
 OBJS=()
 PIDS=()
-for f in conv_mfma.hip conv_wino.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip; do
+for f in conv_mfma.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip; do
   o="$OBJDIR/${f%.hip}.o"
   if stale "$f" "$o"; then
     compile "$f" "$o" &

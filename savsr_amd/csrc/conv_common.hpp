@@ -1,5 +1,5 @@
-// Shared by the two conv kernels (conv_mfma.hip: direct implicit GEMM; conv_wino.hip: Winograd F(2x2, 3x3)): the launch
-// parameters savsr_conv2d_batch fills from the descriptors, and the global-memory access helpers.
+// Launch parameters savsr_conv2d_batch fills from the descriptors, and the global-memory access helpers of the conv kernel
+// (conv_mfma.hip; the archived Winograd experiment tools/experiments/conv_wino.hip included this header too).
 #pragma once
 #include "common.hpp"
 
@@ -58,8 +58,5 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {
 __device__ __forceinline__ void stg1(float* base, unsigned idx, float v) {
     *((SAVSR_GLOBAL float*)base + idx) = v;
 }
-
-// conv_wino.hip: n convs of identical geometry (3x3, cout % 64 == 0) whose `wimg` are Winograd weight images
-int launch_conv_wino(const MultiConvParams& mp, hipStream_t st);
 
 }  // namespace savsr

@@ -58,14 +58,21 @@ namespace savsr {
 // savsr_debug_conv_stamps(1) and read back with savsr_debug_read_conv_stamps():
 // [blk][6] = entry, after the first staging, after the first K phase, after the first tile's K loop,
 // kernel end (stores drained), s_memrealtime at entry.
-constexpr int STAMP_BLOCKS = 1024, STAMP_N = 6;
+[[maybe_unused]] constexpr int STAMP_BLOCKS = 1024, STAMP_N = 6;
+#if defined(SAVSR_DIAG) || (CONV_EXP & 8)
+#define CONV_HAS_STAMPS 1
 __device__ long long g_conv_stamps[STAMP_BLOCKS * STAMP_N];
 __device__ int g_conv_stamps_on = 0;
+#else
+#define CONV_HAS_STAMPS 0      // the product library: no diagnostic state at all
+#endif
 __device__ __attribute__((aligned(16))) const float g_conv_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // what padding lanes load
 
 __device__ __forceinline__ void stamp(int on, int slot) {
+#if CONV_HAS_STAMPS
     if (on == 1 && threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS)
         g_conv_stamps[blockIdx.x * STAMP_N + slot] = (slot == 5) ? (long long)__builtin_amdgcn_s_memrealtime() : (long long)__builtin_amdgcn_s_memtime();
+#endif
 }
 
 // DIAG: the instrumented build (section stamps, timing experiments), launched only while savsr_debug_conv_stamps is on;
@@ -98,7 +105,12 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     const int prio_group = __builtin_amdgcn_readfirstlane(wave >> 2);      // wave-uniform by construction: a scalar for the s_setprio branch
     const int tiles_per_cob = mp.ntx * mp.nty;
     const int total = mp.nconv * mp.ncob * tiles_per_cob;
+#if CONV_HAS_STAMPS
     const int dbg_all = DIAG ? __builtin_amdgcn_readfirstlane(g_conv_stamps_on) : 0;
+#else
+    static_assert(!DIAG, "DIAG kernels exist in the instrumented library only");
+    const int dbg_all = 0;
+#endif
     const int stamps_on = dbg_all & 15;
     const bool dbg_nostage = dbg_all & 16, dbg_nofrag = dbg_all & 32;   // timing experiments only (results are wrong)
     const bool dbg_nost = dbg_all & 64, dbg_nolds = dbg_all & 128;      // epilogue without its global stores / without the LDS transpose
@@ -221,8 +233,10 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #define CV_MARK(i) do { if (stamps_on >= 3) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); sec[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     stamp(stamps_on, 0);
-    if ((CONV_EXP & 8) && !DIAG && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && blockIdx.x < STAMP_BLOCKS)   // (scalar branch: all of wave 0 stores)
+#if CONV_EXP & 8
+    if (!DIAG && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && blockIdx.x < STAMP_BLOCKS)   // (scalar branch: all of wave 0 stores)
         g_conv_stamps[blockIdx.x * STAMP_N + 0] = (long long)__builtin_amdgcn_s_memtime();
+#endif
     stamp(stamps_on, 5);
 
     // ---- software pipeline over the block's phases (tiles x chunks, walked linearly by the staging cursor) ----
@@ -689,17 +703,23 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     // The last phases re-stage unconditionally (straight-line steps): no LDS-DMA of this wave may still be in flight when
     // its LDS is released.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((CONV_EXP & 8) && !DIAG && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && blockIdx.x < STAMP_BLOCKS)
+#if CONV_EXP & 8
+    if (!DIAG && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && blockIdx.x < STAMP_BLOCKS)
         g_conv_stamps[blockIdx.x * STAMP_N + 4] = (long long)__builtin_amdgcn_s_memtime();
+#endif
     if (stamps_on == 1) {
         __builtin_amdgcn_s_waitcnt(0);              // diagnostics: include the store drain in the last stamp
         stamp(stamps_on, 4);
     }
+#if CONV_HAS_STAMPS
     if (stamps_on >= 3 && tid == (stamps_on - 3) * 64 && blockIdx.x < STAMP_BLOCKS)   // mode 3 + w: sections of wave w
         for (int i = 0; i < 5; ++i) g_conv_stamps[blockIdx.x * STAMP_N + i] = sec[i];
+#endif
 }
 
-static int g_conv_diag_host = 0;      // != 0: launch the instrumented kernels
+#ifdef SAVSR_DIAG
+static int g_conv_diag_host = 0;      // != 0: launch the instrumented kernels (instrumented library only)
+#endif
 
 template <int KS, int NT, int PXT, bool DIAG>
 static int launch_conv_impl(const MultiConvParams& mp, hipStream_t st) {
@@ -716,24 +736,31 @@ static int launch_conv_impl(const MultiConvParams& mp, hipStream_t st) {
 
 template <int KS, int NT, int PXT>
 static int launch_conv(const MultiConvParams& mp, hipStream_t st) {
-    return g_conv_diag_host ? launch_conv_impl<KS, NT, PXT, true>(mp, st) : launch_conv_impl<KS, NT, PXT, false>(mp, st);
+#ifdef SAVSR_DIAG
+    if (g_conv_diag_host) return launch_conv_impl<KS, NT, PXT, true>(mp, st);
+#endif
+    return launch_conv_impl<KS, NT, PXT, false>(mp, st);
 }
 
 }  // namespace savsr
 
 using namespace savsr;
 
+#if CONV_HAS_STAMPS
+extern "C" int savsr_debug_read_conv_stamps(long long* host, int nblocks) {
+    if (!host || nblocks < 1 || nblocks > STAMP_BLOCKS) return fail_arg("debug_read_conv_stamps");
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), sizeof(long long) * STAMP_N * nblocks);
+    return e == hipSuccess ? 0 : (int)e;
+}
+#endif
+#ifdef SAVSR_DIAG
 extern "C" int savsr_debug_conv_stamps(int enable) {
     g_conv_diag_host = enable;
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps_on), &enable, sizeof(int));
     return e == hipSuccess ? 0 : (int)e;
 }
 
-extern "C" int savsr_debug_read_conv_stamps(long long* host, int nblocks) {
-    if (!host || nblocks < 1 || nblocks > STAMP_BLOCKS) return fail_arg("debug_read_conv_stamps");
-    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), sizeof(long long) * STAMP_N * nblocks);
-    return e == hipSuccess ? 0 : (int)e;
-}
+#endif
 
 // Rows of a conv's `pool` output = pixel tiles of its launch.
 extern "C" int savsr_conv_pool_blocks(int h, int w) {
@@ -825,11 +852,6 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
     mp.ntx = (d->w + CONV_TW - 1) / CONV_TW;
     mp.nty = (d->h + CONV_TH - 1) / CONV_TH;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (d->algo == SAVSR_CONV_WINOGRAD) {
-        if (d->ksize != 3 || d->cout % 64) return fail_arg("conv: the Winograd form needs ksize 3 and cout a multiple of 64");
-        mp.nty = (d->h + 7) / 8;                          // 8 x 32-pixel tiles (pool rows: the numbering of savsr_conv_pool_blocks)
-        return launch_conv_wino(mp, st);
-    }
     if (d->algo != SAVSR_CONV_DIRECT && d->algo != SAVSR_CONV_DIRECT_THROUGHPUT) return fail_arg("conv: unknown algo");
     const bool wide = cot == 64;
     if (d->ksize == 3 && wide) {

@@ -48,9 +48,14 @@ static_assert(rec_floats(2) == SAVSR_SATU_LRCAT && rec_floats(1) == SAVSR_SATU_L
 
 // Diagnostics (never used by the product path): accumulated s_memtime deltas of kernel sections, written by
 // wave 0 of each workgroup when enabled with savsr_debug_satu_stamps(1).
-constexpr int SSTAMP_BLOCKS = 2048, SSTAMP_N = 8;
+[[maybe_unused]] constexpr int SSTAMP_BLOCKS = 2048, SSTAMP_N = 8;
+#if defined(SAVSR_DIAG) || (LR_EXP & 8)
+#define SATU_HAS_STAMPS 1
 __device__ long long g_satu_stamps[SSTAMP_BLOCKS * SSTAMP_N];
 __device__ int g_satu_stamps_on = 0;
+#else
+#define SATU_HAS_STAMPS 0         // the product library: no diagnostic state at all (DIAG kernels are never instantiated)
+#endif
 #define SATU_T() ((long long)__builtin_amdgcn_s_memtime())
 
 // ------------------------------------------------------------------------------------------
@@ -149,11 +154,16 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
     const int cy = gy < p.h ? gy : p.h - 1, cx = gx < p.w ? gx : p.w - 1;
     const long long cpix = ((long long)cy * p.row_px + cx) * p.pix + 8 * half;
 
+#if SATU_HAS_STAMPS
     const int stamps_on = DIAG ? __builtin_amdgcn_readfirstlane(g_satu_stamps_on) & 1 : 0;
+#else
+    static_assert(!DIAG, "DIAG kernels exist in the instrumented library only");
+    const int stamps_on = 0;
+#endif
     long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t_prev = stamps_on ? SATU_T() : 0;
-    const long long t_begin = t_prev;
-    const long long t_lr0 = (LR_EXP & 8) ? SATU_T() : 0;
+    [[maybe_unused]] const long long t_begin = t_prev;
+    [[maybe_unused]] const long long t_lr0 = (LR_EXP & 8) ? SATU_T() : 0;
 #define LR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     const bf16x8* kw = reinterpret_cast<const bf16x8*>(p.wt.kconv_w);
@@ -375,6 +385,7 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
         accC = mma3(pc[(ks * 2 + 0) * 64], pc[(ks * 2 + 1) * 64], xh, xl, accC);
     }
     LR_MARK(4);                                        // projections
+#if SATU_HAS_STAMPS
     if ((LR_EXP & 8) && !DIAG && __builtin_amdgcn_readfirstlane(tid) == 0) {      // (scalar branch: all of wave 0 stores)
         const int b = blockIdx.x + gridDim.x * blockIdx.y;
         if (b < SSTAMP_BLOCKS) g_satu_stamps[b * SSTAMP_N + 7] = SATU_T() - t_lr0;
@@ -386,6 +397,7 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
             g_satu_stamps[b * SSTAMP_N + 7] = SATU_T() - t_begin;
         }
     }
+#endif
     if (!valid) return;
     float* recf = p.lrcat + ((long long)gy * p.w + gx) * REC;
     f32x4* rec = reinterpret_cast<f32x4*>(recf + half * 32 * NB);
@@ -829,7 +841,7 @@ void satu_hr_kernel(const HrParams p) {
     const int ncol = 32 * p.txw;
     const bool small = p.n_table <= HR_TABLE_LDS;                 // (uniform) whole table in LDS vs per-pixel slices
     const long long t_entry = DIAG ? SATU_T() : 0;
-    const long long rt_entry = DIAG ? (long long)__builtin_amdgcn_s_memrealtime() : 0;     // 100 MHz wall clock
+    [[maybe_unused]] const long long rt_entry = DIAG ? (long long)__builtin_amdgcn_s_memrealtime() : 0;     // 100 MHz wall clock
 
     // ---- this workgroup's tiles --------------------------------------------------------------------------------
     const int ntile_img = p.ntx * p.nty;
@@ -856,7 +868,12 @@ void satu_hr_kernel(const HrParams p) {
     const int once = hr_once_floats(NB, small), bufsz = hr_buf_floats(NB, p.ty, p.txw, p.lrh, p.lrw, small);
     const int win_floats = p.lrh * p.lrw * LREC, slice_floats = small ? 0 : p.ty * ncol * SAVSR_SATU_TABLE;
 
+#if SATU_HAS_STAMPS
     const int dbg_all = DIAG ? __builtin_amdgcn_readfirstlane(g_satu_stamps_on) : 0;
+#else
+    static_assert(!DIAG, "DIAG kernels exist in the instrumented library only");
+    const int dbg_all = 0;
+#endif
     const int stamps_on = dbg_all & 1;
     const bool dbg_nostore = dbg_all & 2, dbg_stage_only = dbg_all & 4, dbg_nostage = dbg_all & 8;     // timing experiments (results invalid)
 
@@ -1043,6 +1060,7 @@ void satu_hr_kernel(const HrParams p) {
         idx_n = p.sched ? ring[(it + 2) & 3] : idx + nslot;
     }
     leave();
+#if SATU_HAS_STAMPS
     if (stamps_on) {
         __builtin_amdgcn_s_waitcnt(0);
         if (tid == 0 && blockIdx.x < SSTAMP_BLOCKS) {
@@ -1052,6 +1070,7 @@ void satu_hr_kernel(const HrParams p) {
             g_satu_stamps[blockIdx.x * SSTAMP_N + 7] = SATU_T() - t_entry;
         }
     }
+#endif
 }
 
 // Per-pixel expansion of the phase table, once per (size, scale, weights): ptab[Y][X] = table[idx_h[Y]][idx_w[X]] with the two
@@ -1076,19 +1095,22 @@ __global__ __launch_bounds__(256) void satu_expand_table_kernel(const float* __r
 
 using namespace savsr;
 
-static int g_satu_diag_host = 0;      // != 0: launch the instrumented kernels (tail-projected form only)
+#ifdef SAVSR_DIAG
+static int g_satu_diag_host = 0;      // != 0: launch the instrumented kernels (tail-projected form only; instrumented library only)
 
 extern "C" int savsr_debug_satu_stamps(int enable) {
     g_satu_diag_host = enable;
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_satu_stamps_on), &enable, sizeof(int));
     return e == hipSuccess ? 0 : (int)e;
 }
+#endif
 
 extern "C" int savsr_satu_hr_occupancy_target(int tail_form) { (void)tail_form; return 1; }
 extern "C" int savsr_satu_hr_variants(void) { return HR_VARIANTS; }
 extern "C" int savsr_satu_hr_compute_waves(int variant) { return variant < 0 || variant >= HR_VARIANTS ? -1 : hr_compute_waves(variant); }
 extern "C" int savsr_satu_hr_rows_per_wave_tile(int tail_form) { return tail_form && HR_LANE_PX ? 2 : 1; }
 
+#ifdef SAVSR_DIAG
 // Diagnostics: resident workgroups per CU the runtime predicts for the HR / LR kernels (tail-projected form) with `lds_bytes` of dynamic LDS.
 extern "C" int savsr_debug_satu_occupancy(int which, int lds_bytes) {
     int n = -1;
@@ -1097,11 +1119,14 @@ extern "C" int savsr_debug_satu_occupancy(int which, int lds_bytes) {
     return e == hipSuccess ? n : -(int)e;
 }
 
+#endif
+#if SATU_HAS_STAMPS
 extern "C" int savsr_debug_read_satu_stamps(long long* host, int nblocks) {
     if (!host || nblocks < 1 || nblocks > SSTAMP_BLOCKS) return fail_arg("debug_read_satu_stamps");
     hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_satu_stamps), sizeof(long long) * SSTAMP_N * nblocks);
     return e == hipSuccess ? 0 : (int)e;
 }
+#endif
 
 static bool satu_weights_ok(const savsr_satu_weights* w) {
     return w && w->body0_w && w->body0_b && w->body2_w && w->body2_b && w->head_w && w->head_b && w->kconv_w && w->kconv_b &&
@@ -1132,12 +1157,16 @@ static int lr_stage(const savsr_satu_weights* wt, const float* x, const float* s
     p.wt = *wt; p.x = x; p.st = st; p.pix = pix; p.row_px = row_px; p.h = h; p.w = w; p.lrcat = lrcat;
     constexpr size_t lds = LR_NPX * LR_XS * sizeof(float) + 2 * LR_PHASE * 16 + 25 * 64 * sizeof(float);     // 150.5 KB
     static_assert(lds <= 160 * 1024, "LR stage LDS budget");
-    const bool diag = NB == 1 && g_satu_diag_host;
     dim3 grid((w + LR_TW - 1) / LR_TW, (h + LR_TH - 1) / LR_TH);
-    const void* fn = diag ? reinterpret_cast<const void*>(&satu_lr_kernel<true, 1>) : reinterpret_cast<const void*>(&satu_lr_kernel<false, NB>);
-    if (int rc = ensure_dynamic_lds(fn, (int)lds, "satu_lr_stage")) return rc;
-    if (diag) hipLaunchKernelGGL((satu_lr_kernel<true, 1>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL((satu_lr_kernel<false, NB>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
+#ifdef SAVSR_DIAG
+    if (NB == 1 && g_satu_diag_host) {
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_kernel<true, 1>), (int)lds, "satu_lr_stage")) return rc;
+        hipLaunchKernelGGL((satu_lr_kernel<true, 1>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
+        return check_launch("satu_lr_kernel");
+    }
+#endif
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_kernel<false, NB>), (int)lds, "satu_lr_stage")) return rc;
+    hipLaunchKernelGGL((satu_lr_kernel<false, NB>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_lr_kernel");
 }
 
@@ -1175,10 +1204,16 @@ extern "C" int savsr_satu_expand_table(const float* table, int n_uw, const int32
 template <int NB, int VAR>
 static int hr_launch(const HrParams& p, size_t lds, int grid, bool diag, hipStream_t st) {
     constexpr int threads = 64 * (hr_compute_waves(VAR) + hr_producer_waves(VAR));
-    const void* fn = diag ? reinterpret_cast<const void*>(&satu_hr_kernel<true, 1, VAR>) : reinterpret_cast<const void*>(&satu_hr_kernel<false, NB, VAR>);
-    if (int rc = ensure_dynamic_lds(fn, 160 * 1024, "satu_hr")) return rc;
-    if (diag) hipLaunchKernelGGL((satu_hr_kernel<true, 1, VAR>), dim3(grid), dim3(threads), lds, st, p);
-    else hipLaunchKernelGGL((satu_hr_kernel<false, NB, VAR>), dim3(grid), dim3(threads), lds, st, p);
+#ifdef SAVSR_DIAG
+    if (diag) {
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<true, 1, VAR>), 160 * 1024, "satu_hr")) return rc;
+        hipLaunchKernelGGL((satu_hr_kernel<true, 1, VAR>), dim3(grid), dim3(threads), lds, st, p);
+        return check_launch("satu_hr_kernel");
+    }
+#endif
+    (void)diag;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, NB, VAR>), 160 * 1024, "satu_hr")) return rc;
+    hipLaunchKernelGGL((satu_hr_kernel<false, NB, VAR>), dim3(grid), dim3(threads), lds, st, p);
     return check_launch("satu_hr_kernel");
 }
 
@@ -1221,7 +1256,11 @@ static int hr_stage(const savsr_satu_weights* wt, const float* lrcat, int h, int
     p.nty = (H + p.ty - 1) / p.ty;
     const size_t lds = ((size_t)hr_once_floats(NB, small) + 2 * (size_t)hr_buf_floats(NB, p.ty, p.txw, p.lrh, p.lrw, small)) * sizeof(float);
     if (lds > 160 * 1024) return fail_arg("satu_hr: staged windows + tile tables exceed 160 KiB of LDS");
+#ifdef SAVSR_DIAG
     const bool diag = NB == 1 && g_satu_diag_host;
+#else
+    const bool diag = false;
+#endif
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     long long ntile = (long long)p.ntx * p.nty;

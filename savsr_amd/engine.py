@@ -478,25 +478,6 @@ class HipEngine:
             d.pool, d.pool_stride = pool[0].data_ptr() + 4 * pool[1], pool[2]
         return d
 
-    def wino_image(self, w_ohwi: torch.Tensor, cout: int, cin: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Winograd F(2x2, 3x3) weight image (savsr_conv_wino_pack, on the current stream) of an fp32 DEVICE kernel laid out
-        [cout][9][cin]."""
-        n = int(self.lib.savsr_conv_wino_packed_elems(cout, cin))
-        if n < 0:
-            raise ValueError(f"no Winograd form for a {cin} -> {cout} conv (cout % 64, cin % 16)")
-        img = out if out is not None else torch.empty(n, dtype=torch.int16, device=self.dev)
-        assert w_ohwi.is_cuda and w_ohwi.dtype == torch.float32 and w_ohwi.is_contiguous() and w_ohwi.numel() == cout * 9 * cin
-        _lib.check(self.lib.savsr_conv_wino_pack(w_ohwi.data_ptr(), cout, cin, img.data_ptr(), self._stream()), "savsr_conv_wino_pack")
-        return img
-
-    def wino_weights(self, w: torch.Tensor, bias: Optional[torch.Tensor]):
-        """[cout, cin, 3, 3] fp32 (any device) -> the `weights` tuple of a Winograd-form conv."""
-        cout, cin = w.shape[:2]
-        ohwi = w.detach().to(self.dev, torch.float32).permute(0, 2, 3, 1).contiguous().view(cout, 9, cin)
-        img = self.wino_image(ohwi, cout, cin)
-        torch.cuda.current_stream().synchronize()         # `ohwi` dies here
-        return (img, None if bias is None else bias.to(self.dev, torch.float32).contiguous(), cout, cin, 3, _lib.CONV_WINOGRAD)
-
     def conv_launch(self, descs: List[ConvDesc], label: str = "conv"):
         """Independent convs of identical geometry, up to 6 per launch (savsr_conv2d_batch)."""
         st = self._stream()
@@ -670,18 +651,15 @@ class HipEngine:
             self._axes.move_to_end(key)
         return ent
 
-    # cost model of one HR tile in cycles (tools/bench_kernels.py satu --stamps and the staging / compute ablation in DESIGN.md):
-    # per 32-pixel tile of a wave (4 waves per workgroup), per staged byte (LDS-DMA runs at ~5.6 TB/s chip-wide = ~6 B/cycle for
-    # each of a CU's two workgroups), fixed per tile (barrier, DMA issue) -- [standalone 64-channel form, tail-projected form]
-    HR_COST = {False: (6900, 1.0 / 12.0, 1500), True: (3600, 1.0 / 12.0, 1500)}
     HR_TABLE_LDS = 256          # phase tables up to this size live whole in LDS (mirrors satu.hip)
 
     def _plan_hr_tiling(self, ent: dict, h: int, w: int, scale):
-        """One-time (per size/scale) choice of the HR stage's tiles and LDS windows: evaluate the phase table (and, for tables
-        too large for LDS, its per-pixel expansion), read the range of the sampling offsets back and pick the HR tile whose
-        double-buffered LRcat window (tile footprint + offset range + bilinear tap) fits two workgroups per CU at the lowest
-        modelled cost = tile rounds of the busiest workgroup x max(gather time, staging time).  Purely a performance plan:
-        waves whose taps leave the window gather from global memory."""
+        """One-time (per size / scale) preparation of the HR stage: evaluate the phase table (and, for tables too large for
+        LDS, its per-pixel expansion), read the range of the sampling offsets back and list every FEASIBLE launch plan -- wave
+        split x HR tile whose double-buffered LRcat window (tile footprint + offset range + bilinear tap) fits the LDS.  Which
+        plan runs is decided by measurement only: satu_hr() times the candidates once on the first real frame of this size /
+        scale (there is no cost model).  Purely a performance plan: waves whose taps leave the window gather from global
+        memory, so results never depend on it."""
         sw = C.byref(self.satu_w)
         _lib.check(self.lib.savsr_satu_phase_table(sw, ent["uh"].data_ptr(), ent["n_uh"], ent["uw"].data_ptr(), ent["n_uw"],
                                                    1.0 / scale[1], 1.0 / scale[0], ent["table"].data_ptr(), self._stream()),
@@ -696,53 +674,41 @@ class HipEngine:
         ox = np.concatenate([tab[:, 4], tab[:, 6]])
         oy = np.concatenate([tab[:, 5], tab[:, 7]])
         finite = bool(np.isfinite(ox).all() and np.isfinite(oy).all())
-        H, W = ent["H"], ent["W"]
-        ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count
         forced = os.environ.get("SAVSR_HR_TILE")                                         # "rows,cols32": experiments only
+        forced_v = os.environ.get("SAVSR_HR_VARIANT")
         nvar = int(self.lib.savsr_satu_hr_variants())
-        ent["tiling_tail_variants"] = []
-        for tail_form, variant in [(False, 0)] + [(True, v) for v in range(nvar)]:
-            occ = int(self.lib.savsr_satu_hr_occupancy_target(int(tail_form)))
+
+        def plans(tail_form: bool, variant: int) -> List[SatuTiling]:
             cw = int(self.lib.savsr_satu_hr_compute_waves(variant))                      # compute waves of a workgroup
             rpw = int(self.lib.savsr_satu_hr_rows_per_wave_tile(int(tail_form)))         # rows of a wave tile
-            lds_cap = (160 * 1024) // occ - 1024                                         # `occ` workgroups per CU
-            nslot = max(1, occ * ncu // 8)                                               # workgroups per XCD chunk of the tile sequence
-            rec_bytes = 4 * (_lib.SATU_LRCAT_TAIL if tail_form else _lib.SATU_LRCAT)
-            t = SatuTiling()
-            t.variant = variant
-            t.table_entries = n_table
-            t.step_x, t.step_y = 1.0 / float(scale[1]), 1.0 / float(scale[0])
-            best = None
+            out = []
             if finite:
                 rx, ry = float(ox.max() - ox.min()), float(oy.max() - oy.min())
-                c_tile, c_byte, c_fix = self.HR_COST[tail_form]
                 cands = [(int(forced.split(",")[0]), int(forced.split(",")[1]))] if forced else \
                     [(r, c) for c in (1, 2, 4) for r in sorted({4, 8, 12, 16, 20, 24, 28, 32, rpw * cw, 2 * rpw * cw}) if r % 4 == 0 and r <= 64]   # (+ whole rounds of the compute waves)
                 for trows, tcols in cands:
                     lr_c = min(max(int(np.ceil(32 * tcols / scale[1] + rx)) + 2, 2), w)
                     lr_r = min(int(np.ceil(trows / scale[0] + ry)) + 2, h)
-                    if self.lib.savsr_satu_hr_lds_bytes(int(tail_form), n_table, trows, tcols, lr_r, lr_c) > lds_cap:
+                    if self.lib.savsr_satu_hr_lds_bytes(int(tail_form), n_table, trows, tcols, lr_r, lr_c) > 160 * 1024 - 1024:
                         continue
-                    ntile = -(-H // trows) * -(-W // (32 * tcols))
-                    rounds = -(-(-(-ntile // 8)) // nslot)                               # tiles of the busiest workgroup
-                    staged = lr_r * lr_c * rec_bytes + (0 if n_table <= self.HR_TABLE_LDS else trows * tcols * 32 * 32)
-                    cost = rounds * (max(c_tile * rpw * -(-((trows // rpw) * tcols) // cw), c_byte * staged) + c_fix)
-                    if best is None or cost < best[0]:
-                        best = (cost, trows, tcols, lr_r, lr_c)
-            if best is None:                                           # no window fits (or non-finite offsets): gathers go to global memory
+                    t = SatuTiling()
+                    t.variant, t.table_entries = variant, n_table
+                    t.step_x, t.step_y = 1.0 / float(scale[1]), 1.0 / float(scale[0])
+                    t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = trows, tcols, lr_r, lr_c
+                    t.off_min_x, t.off_min_y = float(ox.min()), float(oy.min())
+                    out.append(t)
+            if not out:                                                    # no window fits (or non-finite offsets): gathers go to global memory
+                t = SatuTiling()
+                t.variant, t.table_entries = variant, n_table
+                t.step_x, t.step_y = 1.0 / float(scale[1]), 1.0 / float(scale[0])
                 t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = 8, 1, 0, 0
                 t.off_min_x, t.off_min_y = 0.0, 0.0
-            else:
-                t.tile_rows, t.tile_cols32, t.lr_rows, t.lr_cols = best[1], best[2], best[3], best[4]
-                t.off_min_x, t.off_min_y = float(ox.min()), float(oy.min())
-            if tail_form:
-                ent["tiling_tail_variants"].append(t)
-            else:
-                ent["tiling"] = t
-        # which wave split of the HR kernel (8 + 4 or 10 + 6 waves) is faster depends on size and scale (x4: the second by 2-3 us,
-        # asymmetric scales: the first by up to 9): satu_hr() times the candidates once, on the first real frame of this size / scale
-        forced_v = os.environ.get("SAVSR_HR_VARIANT")
-        ent["tiling_tail"] = ent["tiling_tail_variants"][int(forced_v)] if forced_v else None
+                out.append(t)
+            return out
+        # the standalone 64-channel form (tests / taps only, never timed): the feasible plan with the fewest staged bytes per HR pixel
+        ent["tiling"] = min(plans(False, 0), key=lambda t: (t.lr_rows * t.lr_cols) / float(t.tile_rows * t.tile_cols32 * 32))
+        ent["tail_plans"] = [t for v in (range(nvar) if not forced_v else [int(forced_v)]) for t in plans(True, v)]
+        ent["tiling_tail"] = ent["tail_plans"][0] if len(ent["tail_plans"]) == 1 else None
 
     @staticmethod
     def hr_plane(H: int, W: int) -> int:
@@ -780,13 +746,14 @@ class HipEngine:
             launch(ax["tiling"])
             return out
         if ax["tiling_tail"] is None:
-            cands = ax["tiling_tail_variants"]
+            cands = ax["tail_plans"]
             ckey = (h, w, float(scale[0]), float(scale[1]))
+            pick = lambda k: next((t for t in cands if (t.variant, t.tile_rows, t.tile_cols32) == k), cands[0])
             if ckey in self._hr_choice:         # (a sibling engine has timed this size / scale already)
-                ax["tiling_tail"] = cands[self._hr_choice[ckey]]
-            elif len(cands) == 1 or torch.cuda.is_current_stream_capturing():
+                ax["tiling_tail"] = pick(self._hr_choice[ckey])
+            elif torch.cuda.is_current_stream_capturing():
                 ax["tiling_tail"] = cands[0]
-            else:                               # one-time choice: every candidate writes the same `out`, bit for bit
+            else:                               # one-time choice by measurement: every plan writes the same `out`, bit for bit
                 best = None
                 for til in cands:
                     launch(til)
@@ -800,7 +767,7 @@ class HipEngine:
                     if best is None or t_us < best[0]:
                         best = (t_us, til)
                 ax["tiling_tail"] = best[1]
-                self._hr_choice[ckey] = best[1].variant
+                self._hr_choice[ckey] = (best[1].variant, best[1].tile_rows, best[1].tile_cols32)
         launch(ax["tiling_tail"])
         return out
 

@@ -126,8 +126,8 @@ def test_conv2d_rejects_bad_args(eng):
 
 
 def test_conv2d_algo_field(eng):
-    """savsr_conv_desc.algo: DIRECT and DIRECT_THROUGHPUT (other tiling, same bits); an unknown value and a Winograd request the
-    kernel has no form for (cout % 64) are argument errors."""
+    """savsr_conv_desc.algo: DIRECT and DIRECT_THROUGHPUT (other tiling, same bits); an unknown value (incl. 1, the retired
+    Winograd experiment's code) is an argument error."""
     from savsr_amd import engine as E
     from savsr_amd import _lib
     g = np.random.RandomState(9)
@@ -144,10 +144,8 @@ def test_conv2d_algo_field(eng):
     assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
     d = eng.conv_desc("t", [eng.full(x)], eng.full(outs[0]), h, w, weights=(img, None, 128, 64, 3, 7))
     assert eng.lib.savsr_conv2d(C.byref(d), None) < 0 and b"algo" in eng.lib.savsr_last_error()
-    wt48 = _dev(E.pack_conv_weight(wt[:48]))
-    o48 = torch.empty(h, w, 48, device="cuda:0")
-    d = eng.conv_desc("t", [eng.full(x)], eng.full(o48), h, w, weights=(wt48, None, 48, 64, 3, _lib.CONV_WINOGRAD))
-    assert eng.lib.savsr_conv2d(C.byref(d), None) < 0 and b"Winograd" in eng.lib.savsr_last_error()
+    d = eng.conv_desc("t", [eng.full(x)], eng.full(outs[0]), h, w, weights=(img, None, 128, 64, 3, 1))
+    assert eng.lib.savsr_conv2d(C.byref(d), None) < 0 and b"algo" in eng.lib.savsr_last_error()
 
 
 @pytest.mark.parametrize("tag,pfx,cin", OSCONV_CASES)
@@ -354,7 +352,7 @@ def test_satu_tail_form_without_window_and_large_offsets(synth_sd):
             ref = torch.einsum("pc,chw->phw", _wt27(sd), O.sta_upsample(sd, "upsample", x, sc, st)[0].double())
         lrcat = e2.satu_lr(e2.full(cl(x[0])), e2.full(cl(st[0])), 8, 9, 8, tail_form=True)
         ax = e2.satu_axes(9, 8, sc)
-        for til in ax["tiling_tail_variants"]:                # both wave splits of the HR kernel, each with and without its window
+        for til in ax["tail_plans"]:                          # every feasible plan (both wave splits of the HR kernel), each with and without its window
             for drop_window in (False, True):
                 ax["tiling_tail"] = til
                 keep = (til.lr_rows, til.lr_cols)
@@ -377,9 +375,10 @@ def test_satu_hr_variants_bit_identical(eng, h, w, sc):
     H, W = get_hw(h, w, sc)
     lrcat = eng.satu_lr(eng.full(cl(x[0])), eng.full(cl(st[0])), w, h, w, tail_form=True)
     ax = eng.satu_axes(h, w, sc)
-    assert len(ax["tiling_tail_variants"]) == eng.lib.savsr_satu_hr_variants() >= 2
+    assert len({t.variant for t in ax["tail_plans"]}) == eng.lib.savsr_satu_hr_variants() >= 2
+    assert len({(t.tile_rows, t.tile_cols32) for t in ax["tail_plans"]}) >= 3
     outs = []
-    for til in ax["tiling_tail_variants"]:
+    for til in ax["tail_plans"]:
         ax["tiling_tail"] = til
         o = torch.full((27, H * W), float("nan"), device="cuda:0")
         eng.satu_hr(lrcat, h, w, sc, o, tail_form=True)

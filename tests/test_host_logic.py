@@ -19,11 +19,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "savsr_hip.h")).read()
-    declared = set(re.findall(r"\b(savsr_[a-z0-9_]+)\s*\(", hdr))
+    # the section under SAVSR_DIAG is compiled into the instrumented library only (libsavsr_hip_diag.so)
+    diag_sec = re.search(r"#ifdef SAVSR_DIAG\n(.*?)#endif /\* SAVSR_DIAG \*/", hdr, flags=re.S)
+    assert diag_sec, "diagnostics section not found"
+    diag = set(re.findall(r"\b(savsr_[a-z0-9_]+)\s*\(", diag_sec.group(1)))
+    product_hdr = hdr.replace(diag_sec.group(0), "")
+    product_hdr = re.sub(r"/\*.*?\*/", "", product_hdr, flags=re.S)                      # comments may mention retired names
+    declared = set(re.findall(r"\b(savsr_[a-z0-9_]+)\s*\(", product_hdr))
     assert declared, "header parse failed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert diag == set(_lib.DIAG_SIGNATURES), diag ^ set(_lib.DIAG_SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
+    if not os.environ.get("SAVSR_LIB_PATH"):
+        for name in diag:                                   # no diagnostic entry point (and no global switch) in the product library
+            assert not hasattr(lib, name), name
     assert lib.savsr_abi_version() == _lib.ABI_VERSION
     assert b"gfx950" in lib.savsr_version()
 

@@ -28,8 +28,7 @@ def main():
     ap.add_argument("--w", type=int, default=320)
     ap.add_argument("--batch", type=int, default=1, help="conv: convs per launch (savsr_conv2d_batch)")
     ap.add_argument("--cycles", action="store_true", help="conv / satu, library built with -DCONV_EXP=8 / -DLR_EXP=8 (+ experiments): per-workgroup s_memtime totals")
-    ap.add_argument("--stamps", action="store_true", help="conv / satu: print per-workgroup section timings (s_memtime)")
-    ap.add_argument("--wino", action="store_true", help="conv: the Winograd F(2x2, 3x3) form (3x3, cout % 64 == 0)")
+    ap.add_argument("--stamps", action="store_true", help="conv / satu: print per-workgroup section timings (s_memtime); needs the instrumented library: SAVSR_DIAG=1 bash savsr_amd/csrc/build.sh, SAVSR_LIB_PATH=savsr_amd/csrc/libsavsr_hip_diag.so")
     ap.add_argument("--distinct", action="store_true", help="conv: every conv of the batch gets its own inputs and weights")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -40,7 +39,7 @@ def main():
         g = torch.Generator().manual_seed(0)
         wt = torch.randn(a.cout, a.cin, a.ks, a.ks, generator=g) / (a.cin * a.ks * a.ks) ** 0.5
         bias = torch.randn(a.cout, generator=g).to(dev)
-        mk = lambda wt_: eng.wino_weights(wt_, bias) if a.wino else (E.pack_conv_weight(wt_).to(dev), bias, a.cout, a.cin, a.ks)
+        mk = lambda wt_: (E.pack_conv_weight(wt_).to(dev), bias, a.cout, a.cin, a.ks)
         nsrc = max(1, a.cin // 64)
         nset = a.batch if a.distinct else 1
         wsets = [mk(wt if k == 0 else torch.randn(a.cout, a.cin, a.ks, a.ks, generator=g) / (a.cin * a.ks * a.ks) ** 0.5) for k in range(nset)]

@@ -28,6 +28,15 @@ def _load(modname, relpath):
     return mod
 
 
+def have_real_cv2() -> bool:
+    """True when a REAL OpenCV is importable (not the empty import placeholder below)."""
+    try:
+        import cv2
+        return hasattr(cv2, "filter2D") and hasattr(cv2, "getGaussianKernel") and hasattr(cv2, "cvtColor")
+    except ImportError:
+        return False
+
+
 def load_reference_metrics():
     sys.dont_write_bytecode = True
     for name in ("lbasicsr", "lbasicsr.utils", "lbasicsr.metrics"):
@@ -35,7 +44,7 @@ def load_reference_metrics():
             pkg = types.ModuleType(name)
             pkg.__path__ = []
             sys.modules[name] = pkg
-    if "cv2" not in sys.modules:
+    if "cv2" not in sys.modules and not have_real_cv2():
         sys.modules["cv2"] = types.ModuleType("cv2")          # import-only placeholder, see the module docstring
     _load("lbasicsr.utils.registry", "lbasicsr/utils/registry.py")
     cu = _load("lbasicsr.utils.color_util", "lbasicsr/utils/color_util.py")
@@ -63,7 +72,18 @@ def main():
             for ych in (True, False):
                 out[f"psnr/{i}/{crop}/{int(ych)}"] = np.float64(ps.calculate_psnr(a, b, crop, input_order="HWC", test_y_channel=ych))
         out[f"psnr_chw/{i}"] = np.float64(ps.calculate_psnr(a.transpose(2, 0, 1), b.transpose(2, 0, 1), 1, input_order="CHW", test_y_channel=True))
+        if have_real_cv2():
+            # a box with OpenCV: the SSIM half and tensor2img get pinned too (tests/test_metrics_pinned.py picks the keys up)
+            for crop in (0, 2):
+                out[f"ssim/{i}/{crop}"] = np.float64(ps.calculate_ssim(a, b, crop, input_order="HWC", test_y_channel=True))
         cases.append(i)
+    if have_real_cv2():
+        import torch
+        iu = _load("lbasicsr.utils.img_util", "lbasicsr/utils/img_util.py")
+        t = torch.from_numpy(rs.uniform(-0.2, 1.2, (3, 19, 23)).astype(np.float32))
+        out["tensor2img/in"] = t.numpy()
+        out["tensor2img/out"] = iu.tensor2img(t)
+    out["pinned_ssim"] = np.array(bool(have_real_cv2()))
     out["cases"] = np.array(cases)
     path = os.path.join(ROOT, "tests", "golden", "psnr_y.npz")
     np.savez_compressed(path, **out)
