@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 20
+#define SAVSR_ABI_VERSION 21
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -44,6 +44,10 @@ extern "C" {
 const char* savsr_version(void);
 const char* savsr_last_error(void);
 int savsr_abi_version(void);
+/* One-time, per DEVICE (the current one), not a stream operation: sets the > 64 KiB dynamic-LDS attribute of every kernel of
+ * the library, which the launch entry points otherwise do lazily on a kernel's first use.  Optional -- a caller that records
+ * the launches into a hipGraph calls it before the capture so that no attribute call falls inside it.  Idempotent, thread-safe. */
+int savsr_prepare_device(void);
 
 /* ------------------------------------------------------------------------------------------
  * Feature-map layout: every LR-resolution feature map is CHANNEL-LAST fp32, [h][w][C], addressed

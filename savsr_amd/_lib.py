@@ -18,7 +18,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 20
+ABI_VERSION = 21
 CONV_DIRECT, CONV_DIRECT_THROUGHPUT = 0, 2
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
@@ -79,6 +79,7 @@ SIGNATURES = {
     "savsr_version": (C.c_char_p, []),
     "savsr_last_error": (C.c_char_p, []),
     "savsr_abi_version": (C.c_int, []),
+    "savsr_prepare_device": (C.c_int, []),
     "savsr_conv_packed_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "savsr_conv_pack_index": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "savsr_conv_pool_blocks": (C.c_int, [C.c_int, C.c_int]),

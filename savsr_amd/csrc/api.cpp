@@ -42,4 +42,8 @@ extern "C" {
 const char* savsr_version(void) { return "savsr_hip 0.3 (gfx950, split-bf16 MFMA, channel-last)"; }
 const char* savsr_last_error(void) { return savsr::g_err; }
 int savsr_abi_version(void) { return SAVSR_ABI_VERSION; }
+int savsr_prepare_device(void) {
+    if (int rc = savsr::conv_prepare_device()) return rc;
+    return savsr::satu_prepare_device();
+}
 }

@@ -22,6 +22,9 @@ inline int fail_arg(const char* what) {
 // asking for more LDS sets it again.  Thread-safe (mutex around the table).
 int ensure_dynamic_lds(const void* fn, int bytes, const char* what);
 
+int conv_prepare_device();     // conv_mfma.hip
+int satu_prepare_device();     // satu.hip
+
 inline int check_launch(const char* kernel) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -37,6 +37,8 @@
 // Replaces: every nn.Conv2d / F.conv2d of savsr_arch.py (see include/savsr_hip.h).
 #include "conv_common.hpp"
 
+#include <type_traits>
+
 #ifndef CONV_INTERLEAVE
 #define CONV_INTERLEAVE 1
 #endif
@@ -50,6 +52,10 @@
 // its straight-line steps and read s_memtime (an lgkmcnt(0) wait) in every section, so small effects drown there.
 #ifndef CONV_EXP
 #define CONV_EXP 0
+#endif
+#ifndef ROWS_SKIP
+#define ROWS_SKIP 1               // 0: one phase body, MFMAs on zeros below the image; 1: a wave with NO row inside the image runs a body without MFMAs;
+                                  // 2: also a one-row body for waves with one row of two inside (three bodies: 69 spilled VGPRs in the 16-row kernel)
 #endif
 
 namespace savsr {
@@ -335,13 +341,22 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
 
+        // Pixel rows of this wave that lie inside the image (wave-uniform, fixed per tile): in the image's last band (180 rows =
+        // 11 x 16 + 4) a wave owns one row or none, and MFMAs on all-zero operands cost the same time and energy as useful ones
+        // -- 6 % of the MFMA work of a 16-row-tile launch at 180 rows.  The phase body is instantiated per row count (ROWS_SKIP):
+        // every variant stages, reads its fragments (the ring feeds the NEXT tile too) and meets the barriers alike; only the MFMA
+        // groups of absent rows are left out.
+        const int rows_valid = __builtin_amdgcn_readfirstlane((y0 + wave < H ? 1 : 0) + (PXT > 1 && y0 + wave + CONV_TH < H ? 1 : 0));
         for (int chunk = 0; chunk < mp.nchunk; ++chunk) {
+          bool pend2 = false;                               // phase c+2 exists (decided at the barrier)
+          auto phase = [&](auto rows_tag) {
+            constexpr int R = decltype(rows_tag)::value;    // rows of this wave that get MFMAs
             // per accumulator: lo*hi, hi*lo, hi*hi (the order is part of the numerics), as three MFMA groups so that the
             // staging work of a step can be issued BETWEEN them and run under matrix-pipe time (both waves of a SIMD leave
             // the barrier in lockstep: work placed after the whole MFMA burst is serial to it)
             auto mma_part = [&](const Frag& fr, int part) {
 #pragma unroll
-                for (int r = 0; r < PXT; ++r)
+                for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         if (part == 0) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.al[t], fr.bh[r], acc[r][t], 0, 0, 0);
@@ -349,7 +364,6 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                         if (part == 2) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.ah[t], fr.bh[r], acc[r][t], 0, 0, 0);
                     }
             };
-            bool pend2 = false;                               // phase c+2 exists (decided at the barrier)
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 if (FINE && s == LB0) pend2 = pend && stage_next();
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                     }
                     mma_part(f[s % RING], 2);
 #pragma unroll
-                    for (int i = 0; i < 3 * PXT * NT; ++i) {
+                    for (int i = 0; i < 3 * R * NT; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
 #if CONV_INTERLEAVE >= 2
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // up to one DS read (next step's fragments)
@@ -428,6 +442,10 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 mma_part(f[s % RING], 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
+          };
+          if (ROWS_SKIP == 0 || rows_valid == PXT || (ROWS_SKIP == 1 && rows_valid > 0)) phase(std::integral_constant<int, PXT>{});
+          else if (PXT > 1 && rows_valid == 1) phase(std::integral_constant<int, 1>{});
+          else phase(std::integral_constant<int, 0>{});
             if (STEPS % RING != 0) {                          // keep the ring aligned: the next phase starts at slots 0 ..
                 const Frag n0 = f[STEPS % RING], n1 = f[(STEPS + 1) % RING];
                 f[0] = n0;
@@ -721,11 +739,16 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 static int g_conv_diag_host = 0;      // != 0: launch the instrumented kernels (instrumented library only)
 #endif
 
-template <int KS, int NT, int PXT, bool DIAG>
-static int launch_conv_impl(const MultiConvParams& mp, hipStream_t st) {
+template <int KS, int NT, int PXT>
+constexpr size_t conv_lds_bytes() {
     constexpr int TAPS = KS * KS, HALO = KS / 2, KC = conv_kc(KS), KSTEPS = KC / 16;
     constexpr int NPX = (CONV_TH * PXT + 2 * HALO) * (CONV_TW + 2 * HALO);
-    constexpr size_t lds = 16ull * 2 * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64) + (PXT > 1 ? 0ull : 4ull * CONV_TH * 32 * 36);
+    return 16ull * 2 * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64) + (PXT > 1 ? 0ull : 4ull * CONV_TH * 32 * 36);
+}
+
+template <int KS, int NT, int PXT, bool DIAG>
+static int launch_conv_impl(const MultiConvParams& mp, hipStream_t st) {
+    constexpr size_t lds = conv_lds_bytes<KS, NT, PXT>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT, DIAG>), (int)lds, "conv")) return rc;
     const int total = mp.nconv * mp.ncob * mp.ntx * mp.nty;
@@ -740,6 +763,19 @@ static int launch_conv(const MultiConvParams& mp, hipStream_t st) {
     if (g_conv_diag_host) return launch_conv_impl<KS, NT, PXT, true>(mp, st);
 #endif
     return launch_conv_impl<KS, NT, PXT, false>(mp, st);
+}
+
+template <int KS, int NT, int PXT>
+static int conv_attr() {
+    return ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT, false>), (int)conv_lds_bytes<KS, NT, PXT>(), "conv");
+}
+// every product instantiation's dynamic-LDS attribute on the current device (savsr_prepare_device)
+int conv_prepare_device() {
+    if (int rc = conv_attr<3, 2, 2>()) return rc;
+    if (int rc = conv_attr<3, 2, 1>()) return rc;
+    if (int rc = conv_attr<3, 1, 1>()) return rc;
+    if (int rc = conv_attr<1, 2, 1>()) return rc;
+    return conv_attr<1, 1, 1>();
 }
 
 }  // namespace savsr

@@ -34,6 +34,21 @@
 #ifndef LR_PRIO
 #define LR_PRIO 0                 // s_setprio experiments in the 8-wave LR kernel: 1 static for waves 4-7, 2 alternating per tap, 3 per group
 #endif
+#ifndef LR_STREAM
+#define LR_STREAM 1               // product launch: satu_lr_stream_kernel (barrier inside the phase, MFMA stream across phase boundaries); 0: satu_lr_kernel
+#endif
+#ifndef LR_ST
+#define LR_ST 0                   // LRcat stores of satu_lr_stream_kernel: 0 plain, 1 nt, 2 sc1 (write-through), 3 sc0 sc1
+#endif
+#ifndef HR_ST
+#define HR_ST 2                   // plane stores of the lane = pixel HR tile: 0 plain, 1 nt, 2 sc1 (write-through)
+#endif
+#ifndef LRS_LRELU
+#define LRS_LRELU 1               // LeakyReLU * x accumulation of satu_lr_stream_kernel: 0 = mul, max, fmac per element; 1 = two independent FMAs
+#endif                            // (0.55 sum x k + 0.45 sum x |k|); 2 = form 0 batched per quad (4 mul | 4 max | 4 fmac)
+#ifndef LRS_EXP
+#define LRS_EXP 0                 // timing experiments on satu_lr_stream_kernel (results invalid; never set in a shipped build): 1 no fragment
+#endif                            // re-reads, 2 no x / bias reads, 4 no LeakyReLU * x arithmetic, 16 no slab DMAs inside the loop
 #ifndef LR_PACKED
 #define LR_PACKED 0               // LeakyReLU * x accumulation with v_pk_mul / v_pk_fma (1) or plain v_mul / v_max / v_fmac (0)
 #endif
@@ -418,6 +433,359 @@ __global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// LR stage, STREAMING form (round 3; the product launch when LR_STREAM is 1).  Same arithmetic, same tile, same LDS image as
+// satu_lr_kernel above -- what changes is where the per-phase barrier sits.  There, a phase is [5 DMAs | first fragment
+// reads | 20 MFMA groups | last tap's LeakyReLU * x | vmcnt(0) | barrier]: both waves of a SIMD leave the barrier in
+// lockstep, so every phase boundary drains the matrix pipe for ~1 k cycles (MFMA latency + 48 vector instructions + barrier
+// skew + DMA issue + fragment latency) of a ~5.8 k-cycle phase.  Here the MFMA stream never stops inside a channel group:
+//   * fragment reads run one tap (4 groups) ahead ACROSS the phase boundary: tap 4 of phase ph is read during tap 3, tap 0 of
+//     phase ph + 1 during tap 4 of phase ph;
+//   * so the one barrier B(ph) of a phase sits between tap 3 and tap 4 (group 16): in front of it every wave has issued its
+//     last fragment read of buffer ph & 1 (and __syncthreads drains its LDS queue), behind it every read goes to the other
+//     buffer, which is complete (its DMAs were issued right behind B(ph - 1), a whole phase earlier, and every wave waited for
+//     its own pieces in front of B(ph));
+//   * the slabs of phase ph + 2 are DMA'd into the buffer B(ph) has just freed, one piece per group of tap 4;
+//   * tap 4 accumulates into a third accumulator whose LeakyReLU * x runs under tap 0 of the next phase (its first reader is a
+//     compiler-generated instruction as in the other taps); it is drained once per channel group, where the x tile changes.
+// ------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p) {
+    constexpr int REC = rec_floats(NB);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xt = smem;                                                   // [432][36]: replicate-padded x tile of one channel group
+    bf16x8* wbuf = reinterpret_cast<bf16x8*>(smem + LR_NPX * LR_XS);    // [2][LR_PHASE]: weight slabs of a kernel row, double buffered
+    float* kbl = smem + LR_NPX * LR_XS + 2 * LR_PHASE * 4;              // [25][64] kernel_conv bias (+ 64 floats of slack: the bias of "phase 10")
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
+    const int x0 = blockIdx.x * LR_TW, y0 = blockIdx.y * LR_TH;
+    const int gy = y0 + wave, gx = x0 + px;
+    const bool valid = gy < p.h && gx < p.w;
+    const int cy = gy < p.h ? gy : p.h - 1, cx = gx < p.w ? gx : p.w - 1;
+    const long long cpix = ((long long)cy * p.row_px + cx) * p.pix + 8 * half;
+
+#if SATU_HAS_STAMPS
+    const long long ts0 = SATU_T(), rt0 = (long long)__builtin_amdgcn_s_memrealtime();
+    long long tsk[5] = {0, 0, 0, 0, 0};
+#define LRS_MARK(i) do { tsk[i] = SATU_T() - ts0; } while (0)
+#else
+#define LRS_MARK(i) do { } while (0)
+#endif
+    const bf16x8* kw = reinterpret_cast<const bf16x8*>(p.wt.kconv_w);
+    // piece i (of 5 per wave) of the slabs of linear phase q (= channel group q / 5, kernel row q % 5) -> LDS buffer b;
+    // q == 10: the projection image ((2 NB + 1) x 8 KB, consumed after the last phase).  BRANCH-FREE (a branch here cuts the
+    // straight-line MFMA groups of tap 4 into basic blocks the scheduler cannot interleave): the LDS destination has the same
+    // form for slabs and projection pieces (LR_SLAB = 8 x 64 units), and where there is nothing to fetch (q == 10 beyond the
+    // image, q == 11) the piece re-fetches slab bytes of phase 9 into a buffer nobody reads any more.
+    auto dma_piece = [&](int q, int b, int i) {
+        const int qs = q < 10 ? q : 9;
+        const int cg = qs >= 5 ? 1 : 0, ky = qs - 5 * cg;
+        const bf16x8* src = kw + (long long)((ky * 5 + i) * 2 + cg) * LR_SLAB + wave * 64 + lane;
+        const bf16x8* prj = reinterpret_cast<const bf16x8*>(p.wt.proj_w) + (i * 8 + wave) * 64 + lane;
+        if (i < 2 * NB + 1) src = q == 10 ? prj : src;               // (a select; i is a compile-time constant at every call site)
+        glds16(src, wbuf + b * LR_PHASE + i * LR_SLAB + wave * 64);
+    };
+    constexpr int XT_IT = (LR_NPX * 8 + 511) / 512;                    // 7 float4 per thread
+    f32x4 xv[XT_IT];
+    auto xt_load = [&](int cg) {
+#pragma unroll
+        for (int i = 0; i < XT_IT; ++i) {
+            const int e = tid + i * 512;
+            const int pl = (e < LR_NPX * 8 ? e : 0) >> 3, c4 = e & 7;
+            const int r = pl / LR_XC, c = pl - r * LR_XC;
+            int sy = y0 - LR_HALO + r, sx = x0 - LR_HALO + c;
+            sy = sy < 0 ? 0 : (sy > p.h - 1 ? p.h - 1 : sy);
+            sx = sx < 0 ? 0 : (sx > p.w - 1 ? p.w - 1 : sx);
+            xv[i] = *reinterpret_cast<const f32x4*>(p.x + ((long long)sy * p.row_px + sx) * p.pix + 32 * cg + 4 * c4);
+        }
+    };
+    auto xt_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < XT_IT; ++i) {
+            const int e = tid + i * 512;
+            if (e < LR_NPX * 8) *reinterpret_cast<f32x4*>(xt + (e >> 3) * LR_XS + 4 * (e & 7)) = xv[i];
+        }
+    };
+
+    // ---- prologue: what the first MFMAs need -- the slabs of phase 0, the st fragments, the bias -- is waited for here; the
+    // x tile (a third of the prologue's bytes) is only read by the LeakyReLU * x work, one tap behind the MFMAs: its loads fly
+    // under tap 0 of phase 0 and it is published by an extra barrier in front of that phase's group 3.
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma_piece(0, 0, i);
+    bf16x8 sth[4], stl[4];
+    {
+        f32x4 sv[8];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4* g = reinterpret_cast<const f32x4*>(p.st + cpix + 16 * ks);
+            sv[2 * ks] = g[0];
+            sv[2 * ks + 1] = g[1];
+        }
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (tid < 25 * 64 / 4) bv = reinterpret_cast<const f32x4*>(p.wt.kconv_b)[tid];
+        xt_load(0);                                                   // (younger than everything the first barrier waits for)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) split8v(sv[2 * ks], sv[2 * ks + 1], sth[ks], stl[ks]);
+        if (tid < 25 * 64 / 4) reinterpret_cast<f32x4*>(kbl)[tid] = bv;
+        if (tid < 16) reinterpret_cast<f32x4*>(kbl + 25 * 64)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XT_IT) : "memory");     // all but the x tile's loads: this wave's pieces of phase 0 have landed
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma_piece(1, 1, i);                   // lands under phase 0 (waited for in front of B(0))
+    LRS_MARK(0);
+
+    struct AFrag { bf16x8 ah[4], al[4]; };
+    auto bias_ptr = [&](int q, int kx) -> const float* {            // kernel_conv bias of tap (q % 5, kx), channel group q / 5, this lane half
+        const int cg = q >= 10 ? 2 : (q >= 5 ? 1 : 0), ky = q - 5 * cg;   // q == 10 (behind the last phase): rows 0 .. 4 at column 64+ = the next rows / the zero slack; never kept
+        return kbl + (ky * 5 + kx) * 64 + cg * 32 + 4 * half;
+    };
+    f32x16 sta[2];
+    f32x4 xc[8];                                                     // the centre pixel's x (loaded at the top of the last phase)
+    f32x16 acc[2], acc2;                                             // taps 0 / 2 | 1 / 3 | 4 (consumed under tap 0 of the next phase)
+    AFrag fr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    {
+        const bf16x8* wl0 = wbuf + lane;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { fr.ah[ks] = wl0[(ks * 2 + 0) * 64]; fr.al[ks] = wl0[(ks * 2 + 1) * 64]; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_ptr(0, 0) + 8 * g);
+            acc[0][4 * g] = b4[0]; acc[0][4 * g + 1] = b4[1]; acc[0][4 * g + 2] = b4[2]; acc[0][4 * g + 3] = b4[3];
+        }
+    }
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg) {                  // unrolled: sta[cg] must stay in registers
+        f32x16 sacc;
+        [[maybe_unused]] f32x16 sabs;                                // LRS_LRELU == 1: sum x |k| (sacc then holds sum x k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; sabs[r] = 0.f; }
+        auto x_read = [&](int ky, int kx, int g) -> f32x4 {          // x_pad at tap (ky, kx), channel quad g of this half
+            return *reinterpret_cast<const f32x4*>(xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half + 8 * g);
+        };
+        auto lrelu_x = [&](int g, const f32x16& a, const f32x4 xq) {   // sacc += LeakyReLU_0.1(K) * x_pad   (:228, :297-313); see satu_lr_kernel
+#if LRS_LRELU == 1
+            // LeakyReLU_0.1(k) = 0.55 k + 0.45 |k|: two INDEPENDENT accumulations per element (sum x k, sum x |k|; combined once per
+            // channel group) instead of the dependent mul -> max -> fmac chain.  The first reader of the MFMA result is the
+            // compiler's fma (it inserts the wait states an accumulator read needs); the |k| source modifier needs the VOP3 form.
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float k = a[4 * g + q];
+                sacc[4 * g + q] = __builtin_fmaf(k, xq[q], sacc[4 * g + q]);
+                float sv = sabs[4 * g + q];
+                asm volatile("v_fma_f32 %0, |%1|, %2, %0" : "+v"(sv) : "v"(k), "v"(xq[q]));
+                sabs[4 * g + q] = sv;
+            }
+#elif LRS_LRELU == 2
+            // same arithmetic as below, batched: 4 mul | 4 max | 4 fmac, so that no instruction follows its producer directly
+            float m[4], sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { m[q] = 0.1f * a[4 * g + q]; sv[q] = sacc[4 * g + q]; }
+            asm volatile("v_max_f32 %0, %8, %0\n\tv_max_f32 %1, %9, %1\n\tv_max_f32 %2, %10, %2\n\tv_max_f32 %3, %11, %3\n\t"
+                         "v_fmac_f32 %4, %0, %12\n\tv_fmac_f32 %5, %1, %13\n\tv_fmac_f32 %6, %2, %14\n\tv_fmac_f32 %7, %3, %15"
+                         : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3])
+                         : "v"(a[4 * g]), "v"(a[4 * g + 1]), "v"(a[4 * g + 2]), "v"(a[4 * g + 3]), "v"(xq[0]), "v"(xq[1]), "v"(xq[2]), "v"(xq[3]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sacc[4 * g + q] = sv[q];
+#else
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float sv = sacc[4 * g + q], m_tmp = 0.1f * a[4 * g + q];
+                asm volatile("v_max_f32 %0, %2, %0\n\tv_fmac_f32 %1, %0, %3" : "+v"(m_tmp), "+v"(sv) : "v"(a[4 * g + q]), "v"(xq[q]));
+                sacc[4 * g + q] = sv;
+            }
+#endif
+        };
+        // carried across the phases: the LDS operands of the NEXT group's vector work (read one group ahead of their use)
+        f32x4 x_pf = {0.f, 0.f, 0.f, 0.f};                            // (multiplies the zero accumulator in the first phase of a channel group)
+        f32x4 b_pf = *reinterpret_cast<const f32x4*>(bias_ptr(cg * 5, 1));
+#pragma unroll 1
+        for (int ky = 0; ky < 5; ++ky) {
+            const int ph = cg * 5 + ky, buf = ph & 1;
+            if (LR_XPREFETCH && ph == 4) xt_load(1);   // the second channel group's x tile: its loads fly under this phase (28 registers; written to LDS at the group boundary)
+            const bf16x8* wl = wbuf + buf * LR_PHASE + lane;
+            const bf16x8* wn = wbuf + (buf ^ 1) * LR_PHASE + lane;
+            // x operand of the deferred tap (ky - 1, 4); in the first phase of a channel group the accumulator it multiplies is zero
+            // and the operand comes from the zero slack row behind the bias (in phase 0 the x tile is not in LDS yet)
+            const float* xdef = ky > 0 ? xt + ((wave + ky - 1) * LR_XC + px + 4) * LR_XS + 4 * half : kbl + 25 * 64;
+            if (cg == 1 && ky == 4) {                  // the centre pixel's x (B operand of the Wb / C projections): loaded a phase ahead of its use
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const f32x4* g = reinterpret_cast<const f32x4*>(p.x + cpix + 16 * ks);
+                    xc[2 * ks] = g[0];
+                    xc[2 * ks + 1] = g[1];
+                }
+            }
+#pragma unroll
+            for (int G = 0; G < 20; ++G) {
+                const int kx = G / 4, ks = G % 4;
+                __builtin_amdgcn_sched_barrier(0);
+                if (cg == 0 && G == 3 && ky == 0) {     // phase 0 only: the x tile (its loads flew under the first groups) -> LDS, published
+                    xt_store();
+                    __syncthreads();
+                }
+                if (G == 16) {
+                    // B(ph): this wave's pieces of phase ph + 1 have landed; behind the barrier everybody's have, and nobody reads
+                    // buffer `buf` any more (tap 4's fragments were read during tap 3)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+                if (G >= 16 && !(LRS_EXP & 16)) {       // the slabs of phase ph + 2 into the freed buffer, one piece per group (two with the last)
+                    dma_piece(ph + 2, buf, G - 16);
+                    if (G == 19) dma_piece(ph + 2, buf, 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kx == 4) acc2 = mma3(fr.ah[ks], fr.al[ks], sth[ks], stl[ks], acc2);
+                else acc[kx & 1] = mma3(fr.ah[ks], fr.al[ks], sth[ks], stl[ks], acc[kx & 1]);
+                // this k-step's fragments of the NEXT tap (tap 0 of the next phase from the other buffer: complete since B(ph))
+                if (LRS_EXP & 1) {
+                } else if (kx < 4) { fr.ah[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 0) * 64]; fr.al[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 1) * 64]; }
+                else { fr.ah[ks] = wn[(ks * 2 + 0) * 64]; fr.al[ks] = wn[(ks * 2 + 1) * 64]; }
+                // LeakyReLU * x of the PREVIOUS tap (tap 4 of the previous phase under tap 0)
+                if (LRS_EXP & 4) {                      // (the accumulators stay live: the MFMAs are not dead code)
+                    const f32x16& a_ = kx == 0 ? acc2 : acc[(kx - 1) & 1];
+                    asm volatile("" :: "v"(a_[4 * ks]), "v"(a_[4 * ks + 1]), "v"(a_[4 * ks + 2]), "v"(a_[4 * ks + 3]), "v"(x_pf[0]));
+                } else if (kx == 0) lrelu_x(ks, acc2, x_pf);
+                else lrelu_x(ks, acc[(kx - 1) & 1], x_pf);
+                // the bias (initial accumulator) of the NEXT tap, quad ks: its previous contents were consumed a tap ago
+                {
+                    f32x16& an = kx == 3 ? acc2 : (kx == 4 ? acc[0] : acc[(kx + 1) & 1]);       // (tap 0 of the next phase: acc[0])
+                    an[4 * ks] = b_pf[0]; an[4 * ks + 1] = b_pf[1]; an[4 * ks + 2] = b_pf[2]; an[4 * ks + 3] = b_pf[3];
+                }
+                // LDS operands of the next group's vector work
+                {
+                    const int G1 = G + 1, kx1 = (G1 % 20) / 4, ks1 = G1 % 4;
+                    if (LRS_EXP & 2) {
+                    } else if (G1 < 20) {
+                        x_pf = kx1 > 0 ? x_read(ky, kx1 - 1, ks1) : *reinterpret_cast<const f32x4*>(xdef + 8 * ks1);
+                        b_pf = *reinterpret_cast<const f32x4*>((kx1 < 4 ? bias_ptr(ph, kx1 + 1) : bias_ptr(ph + 1, 0)) + 8 * ks1);
+                    } else {                                // group 0 of the next phase: the deferred tap (ky, 4) and the bias of its tap 1
+                        x_pf = x_read(ky, 4, 0);
+                        b_pf = *reinterpret_cast<const f32x4*>(bias_ptr(ph + 1, 1));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                }
+            }
+        }
+        LRS_MARK(cg == 0 ? 1 : 3);
+        // ---- end of the channel group: drain the deferred tap (4, 4); the x tile changes here ----
+        {
+            f32x4 xq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xq[g] = x_read(4, 4, g);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lrelu_x(g, acc2, xq[g]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        }
+#if LRS_LRELU == 1
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.55f * sacc[r] + 0.45f * sabs[r];
+#endif
+        sta[cg] = sacc;
+        if (cg == 0) {
+            if (!LR_XPREFETCH) xt_load(1);
+            // (the x loads are older than the five pieces of phase 6 issued behind B(4): VMEM returns in order)
+            if (LR_XPREFETCH) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            __syncthreads();                           // every wave is done with the old x tile
+            xt_store();
+            __syncthreads();
+            LRS_MARK(2);
+        }
+    }
+
+    // ---- LR-side projections (bf16x3): image in LDS buffer 0 (DMA'd behind B(8), published by B(9)) ----
+    const bf16x8* pa = wbuf + lane;
+    const bf16x8* pb = pa + NB * 4 * 2 * 64;
+    const bf16x8* pc = pb + NB * 4 * 2 * 64;
+    f32x16 accA[NB], accB[NB], accC;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int t = 0; t < NB; ++t) { accA[t][r] = 0.f; accB[t][r] = 0.f; }
+        accC[r] = 0.f;
+    }
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 lo4 = {sta[cg][8 * s], sta[cg][8 * s + 1], sta[cg][8 * s + 2], sta[cg][8 * s + 3]};
+            const f32x4 hi4 = {sta[cg][8 * s + 4], sta[cg][8 * s + 5], sta[cg][8 * s + 6], sta[cg][8 * s + 7]};
+            bf16x8 bh, bl;
+            split8v(lo4, hi4, bh, bl);
+            const int kidx = cg * 2 + s;
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+                accA[t] = mma3(pa[((t * 4 + kidx) * 2 + 0) * 64], pa[((t * 4 + kidx) * 2 + 1) * 64], bh, bl, accA[t]);
+        }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 xh, xl;
+        split8v(xc[2 * ks], xc[2 * ks + 1], xh, xl);
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+            accB[t] = mma3(pb[((t * 4 + ks) * 2 + 0) * 64], pb[((t * 4 + ks) * 2 + 1) * 64], xh, xl, accB[t]);
+        accC = mma3(pc[(ks * 2 + 0) * 64], pc[(ks * 2 + 1) * 64], xh, xl, accC);
+    }
+#if SATU_HAS_STAMPS
+    asm volatile("" :: "v"(accC[0]), "v"(accA[0][0]), "v"(accB[0][0]));
+    LRS_MARK(4);
+    if ((tid & 63) == 0 && (wave == 0 || wave == 4) && __builtin_amdgcn_readfirstlane(g_satu_stamps_on)) {    // waves 0 and 4 of every workgroup: [blk][2][8]
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        if (2 * b + 1 < SSTAMP_BLOCKS) {
+            long long* o = g_satu_stamps + (2 * b + (wave >> 2)) * SSTAMP_N;
+            for (int i = 0; i < 5; ++i) o[i] = tsk[i];
+            o[5] = rt0;
+            o[6] = (long long)__builtin_amdgcn_s_memrealtime();
+            o[7] = SATU_T() - ts0;
+        }
+    }
+#endif
+    if (!valid) return;
+    float* recf = p.lrcat + ((long long)gy * p.w + gx) * REC;
+    f32x4* rec = reinterpret_cast<f32x4*>(recf + half * 32 * NB);
+    // LRcat stores.  LR_ST 2 / 3: write-through (`sc1` / `sc0 sc1`): the 22 MB of records leave the XCD's L2 while the kernel
+    // still computes instead of in the end-of-kernel write-back that the dependent HR launch waits behind (a kernel boundary
+    // costs ~1.5 us + dirty bytes / 6 TB/s, MI355X_MICROARCH.md "boundary"); the readers are other CUs anyway.  The stores are
+    // inline asm, and the first reader of an MFMA result must otherwise be a compiler-generated instruction (hipcc inserts the
+    // wait states): the s_nops in front of them cover the 16-pass MFMA's write-back.
+    auto st16 = [&](f32x4* dst, const f32x4& v) {
+#if LR_ST == 1
+        __builtin_nontemporal_store(v, dst);
+#elif LR_ST == 2
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+#elif LR_ST == 3
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory");
+#else
+        *dst = v;
+#endif
+    };
+#if LR_ST >= 2
+    asm volatile("s_nop 15\n\ts_nop 15" :: "v"(accC[15]), "v"(accA[NB - 1][15]), "v"(accB[NB - 1][15]));
+#endif
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 a = {accA[t][4 * g], accA[t][4 * g + 1], accA[t][4 * g + 2], accA[t][4 * g + 3]};
+            f32x4 b = {accB[t][4 * g], accB[t][4 * g + 1], accB[t][4 * g + 2], accB[t][4 * g + 3]};
+            st16(rec + t * 4 + g, a);
+            st16(rec + 4 * NB + t * 4 + g, b);
+        }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 c = {accC[4 * g], accC[4 * g + 1], accC[4 * g + 2], accC[4 * g + 3]};
+        st16(reinterpret_cast<f32x4*>(recf + 64 * NB + 8 * g + 4 * half), c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // HR stage.  One wave = 32 consecutive HR pixels of one output row x all 32 NB output channels; two lanes
 // (half 0 / half 1) per pixel, each owning 16 NB of them in MFMA accumulator order.
 // grid_sample (zeros padding, align_corners=True) semantics of savsr_arch.py:262-295.
@@ -769,18 +1137,30 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
         if (G ? valid1 : valid0) {
             unsigned oo = G ? o_off1 : o_off0;
             asm volatile("" : "+v"(oo));
+            // HR_ST 2: `sc1` (write-through) stores -- the planes leave L2 as they are written, so the kernel's end has (almost) no
+            // dirty lines left to write back in front of the dependent tail launch; 1: `nt`
+            auto st1 = [&](float* pl, unsigned off, float v) {
+                __attribute__((address_space(1))) float* a_ = (__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)pl + off);
+#if HR_ST == 2
+                __hip_atomic_store(a_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif HR_ST == 1
+                __builtin_nontemporal_store(v, a_);
+#else
+                *a_ = v;
+#endif
+            };
 #pragma unroll
             for (int r = 0; r < 12; ++r) {
                 float* pl = outp + (long long)acc_row(r, 0) * HW;
                 asm volatile("" : "+s"(pl));
-                *(__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)pl + oo) = acc[r];
+                st1(pl, oo, acc[r]);
             }
             if (half == 0) {
 #pragma unroll
                 for (int r = 12; r < 15; ++r) {
                     float* pl = outp + (long long)acc_row(r, 0) * HW;
                     asm volatile("" : "+s"(pl));
-                    *(__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)pl + oo) = acc[r];
+                    st1(pl, oo, acc[r]);
                 }
             }
         }
@@ -1143,6 +1523,25 @@ extern "C" int savsr_satu_phase_table(const savsr_satu_weights* wt, const float*
     return check_launch("satu_phase_table_kernel");
 }
 
+constexpr size_t LR_LDS_BYTES = LR_NPX * LR_XS * sizeof(float) + 2 * LR_PHASE * 16 + 26 * 64 * sizeof(float);     // 150.7 KB
+static_assert(LR_LDS_BYTES <= 160 * 1024, "LR stage LDS budget");
+
+namespace savsr {
+// every product instantiation's dynamic-LDS attribute on the current device (savsr_prepare_device)
+int satu_prepare_device() {
+#if LR_STREAM
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_stream_kernel<1>), (int)LR_LDS_BYTES, "satu_lr_stage")) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_stream_kernel<2>), (int)LR_LDS_BYTES, "satu_lr_stage")) return rc;
+#else
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_kernel<false, 1>), (int)LR_LDS_BYTES, "satu_lr_stage")) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_kernel<false, 2>), (int)LR_LDS_BYTES, "satu_lr_stage")) return rc;
+#endif
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 1, 0>), 160 * 1024, "satu_hr")) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 1, 1>), 160 * 1024, "satu_hr")) return rc;
+    return ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 2, 0>), 160 * 1024, "satu_hr");
+}
+}  // namespace savsr
+
 template <int NB>
 static int lr_stage(const savsr_satu_weights* wt, const float* x, const float* st, int32_t pix, int32_t row_px, int h, int w, float* lrcat,
                     void* stream) {
@@ -1155,19 +1554,24 @@ static int lr_stage(const savsr_satu_weights* wt, const float* x, const float* s
     }
     LrParams p;
     p.wt = *wt; p.x = x; p.st = st; p.pix = pix; p.row_px = row_px; p.h = h; p.w = w; p.lrcat = lrcat;
-    constexpr size_t lds = LR_NPX * LR_XS * sizeof(float) + 2 * LR_PHASE * 16 + 25 * 64 * sizeof(float);     // 150.5 KB
-    static_assert(lds <= 160 * 1024, "LR stage LDS budget");
+    constexpr size_t lds = LR_LDS_BYTES;
     dim3 grid((w + LR_TW - 1) / LR_TW, (h + LR_TH - 1) / LR_TH);
-#ifdef SAVSR_DIAG
+#if defined(SAVSR_DIAG) && !LR_STREAM
     if (NB == 1 && g_satu_diag_host) {
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_kernel<true, 1>), (int)lds, "satu_lr_stage")) return rc;
         hipLaunchKernelGGL((satu_lr_kernel<true, 1>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
         return check_launch("satu_lr_kernel");
     }
 #endif
+#if LR_STREAM
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_stream_kernel<NB>), (int)lds, "satu_lr_stage")) return rc;
+    hipLaunchKernelGGL((satu_lr_stream_kernel<NB>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
+    return check_launch("satu_lr_stream_kernel");
+#else
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_kernel<false, NB>), (int)lds, "satu_lr_stage")) return rc;
     hipLaunchKernelGGL((satu_lr_kernel<false, NB>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_lr_kernel");
+#endif
 }
 
 extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const float* st, int32_t pix, int32_t row_px, int h,

@@ -130,6 +130,8 @@ class HipEngine:
                                "there is no CPU fallback")
         self.lib = _lib.load()
         self.dev = device
+        with torch.cuda.device(device):                      # per device: every kernel's > 64 KiB dynamic-LDS attribute, before any capture
+            _lib.check(self.lib.savsr_prepare_device(), "savsr_prepare_device")
         self.cfg = dict(cfg)
         self.nf = cfg["num_feat"]
         if self.nf != 64:
@@ -393,7 +395,7 @@ class HipEngine:
         self._ctx: "OrderedDict[tuple, dict]" = OrderedDict()
         self._axes: "OrderedDict[tuple, dict]" = OrderedDict()
         self._default_ctx = dict(bufs={}, scales=OrderedDict())      # direct kernel-level calls (tests, tools) outside a forward
-        self._default_sc = dict(bufs={}, graphs=None)
+        self._default_sc = dict(bufs={}, graphs=None, chunk=0)
         self.hr_sched = torch.zeros(16, dtype=torch.int32, device=self.dev)     # tile-queue scratch of the SATU HR kernel (one per engine = per stream)
         self._cur, self._cur_sc = self._default_ctx, self._default_sc
 
@@ -412,7 +414,7 @@ class HipEngine:
         ckey = (float(scale[0]), float(scale[1]))
         sc = ctx["scales"].get(ckey)
         if sc is None:
-            sc = dict(bufs={}, graphs=None)
+            sc = dict(bufs={}, graphs=None, chunk=0)        # (a scale context holds one or two HR-sized buffers: exact-size allocations)
             ctx["scales"][ckey] = sc
             while len(ctx["scales"]) > self.max_scales:
                 ctx["scales"].popitem(last=False)
@@ -426,21 +428,37 @@ class HipEngine:
         return {"shapes": len(self._ctx), "scales": sum(len(c["scales"]) for c in self._ctx.values()), "axes": len(self._axes),
                 "bytes": sum(n(c["bufs"]) + sum(n(sc["bufs"]) for sc in c["scales"].values()) for c in self._ctx.values())}
 
-    def _get_buf(self, store: dict, name: str, shape: tuple) -> torch.Tensor:
+    ARENA_CHUNK = 64 << 20      # bytes per arena chunk (larger requests get a chunk of their own)
+
+    def _get_buf(self, owner: dict, name: str, shape: tuple) -> torch.Tensor:
+        """Named fp32 buffer of a context, carved out of the context's ARENA: the ~110 feature maps of a clip shape are never
+        freed one by one (the context is dropped as a whole), so they are bump-allocated from a few large device allocations
+        instead of one allocator round trip each -- a new LR shape (every folder x scale of the YAML sweep is one) costs a
+        handful of hipMallocs, not a hundred.  256-byte aligned (the kernels ask for 16)."""
+        store = owner["bufs"]
         key = (name,) + tuple(shape)
         t = store.get(key)
         if t is None:
-            t = torch.empty(shape, device=self.dev, dtype=torch.float32)
+            n = 1
+            for d in shape:
+                n *= int(d)
+            nbytes = (4 * n + 255) & ~255
+            arena = owner.setdefault("arena", [])
+            if not arena or arena[-1][1] + nbytes > arena[-1][0].numel():
+                arena.append([torch.empty(max(nbytes, owner.get("chunk", self.ARENA_CHUNK)), device=self.dev, dtype=torch.uint8), 0])
+            chunk, off = arena[-1]
+            t = chunk[off:off + 4 * n].view(torch.float32).view(shape)
+            arena[-1][1] = off + nbytes
             store[key] = t
         return t
 
     def buf(self, name: str, *shape: int) -> torch.Tensor:
         """Named LR-sized buffer of the current clip shape."""
-        return self._get_buf(self._cur["bufs"], name, shape)
+        return self._get_buf(self._cur, name, shape)
 
     def sbuf(self, name: str, *shape: int) -> torch.Tensor:
         """Named buffer whose size depends on the scale (HR-sized), owned by the current (shape, scale) context."""
-        return self._get_buf(self._cur_sc["bufs"], name, shape)
+        return self._get_buf(self._cur_sc, name, shape)
 
     @staticmethod
     def _stream() -> int:
@@ -684,8 +702,9 @@ class HipEngine:
             out = []
             if finite:
                 rx, ry = float(ox.max() - ox.min()), float(oy.max() - oy.min())
+                # tile rows: whole rounds of the compute waves first (rpw * cw, 2 rpw * cw), then the generic 8 / 16 / 32
                 cands = [(int(forced.split(",")[0]), int(forced.split(",")[1]))] if forced else \
-                    [(r, c) for c in (1, 2, 4) for r in sorted({4, 8, 12, 16, 20, 24, 28, 32, rpw * cw, 2 * rpw * cw}) if r % 4 == 0 and r <= 64]   # (+ whole rounds of the compute waves)
+                    [(r, c) for c in (1, 2) for r in sorted({8, 16, 32, rpw * cw, 2 * rpw * cw}) if r % 4 == 0 and r <= 64]
                 for trows, tcols in cands:
                     lr_c = min(max(int(np.ceil(32 * tcols / scale[1] + rx)) + 2, 2), w)
                     lr_r = min(int(np.ceil(trows / scale[0] + ry)) + 2, h)
@@ -754,20 +773,19 @@ class HipEngine:
             elif torch.cuda.is_current_stream_capturing():
                 ax["tiling_tail"] = cands[0]
             else:                               # one-time choice by measurement: every plan writes the same `out`, bit for bit
-                best = None
+                evs = []                        # (the plans' timings queue up on the stream; ONE host sync at the end)
                 for til in cands:
                     launch(til)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    for _ in range(4):
+                    for _ in range(3):
                         launch(til)
                     e1.record()
-                    e1.synchronize()
-                    t_us = e0.elapsed_time(e1)
-                    if best is None or t_us < best[0]:
-                        best = (t_us, til)
-                ax["tiling_tail"] = best[1]
-                self._hr_choice[ckey] = (best[1].variant, best[1].tile_rows, best[1].tile_cols32)
+                    evs.append((e0, e1, til))
+                evs[-1][1].synchronize()
+                best = min(evs, key=lambda e: e[0].elapsed_time(e[1]))[2]
+                ax["tiling_tail"] = best
+                self._hr_choice[ckey] = (best.variant, best.tile_rows, best.tile_cols32)
         launch(ax["tiling_tail"])
         return out
 
@@ -896,18 +914,25 @@ class HipEngine:
             s_in = torch.empty_like(lq)
             s_out = torch.empty_like(out)
             s_in.copy_(lq)
-            self.forward_one(s_in, scale, s_out)            # eager warm-up: allocates buffers, sets kernel attributes, plans SATU
-            torch.cuda.synchronize()
+            # Everything a capture cannot hold happens here, once per (size, scale): the SATU tables (host arithmetic, H2D copies,
+            # one read-back of the offset range) and the measured choice of the HR launch plan, on this context's own LRcat / P
+            # buffers (their contents do not matter: no control flow of the HR kernel depends on the feature values).  The kernels'
+            # LDS attributes were set by savsr_prepare_device.  There is no eager run of the frame: the launch sequence is issued
+            # exactly once, into the capture, and the buffers it names are allocated there (arena chunks from the graphs' pool).
+            h_, w_ = int(lq.shape[-2]), int(lq.shape[-1])
+            H_, W_ = get_hw(h_, w_, scale)
+            plane_ = self.hr_plane(H_, W_)
+            self.satu_hr(self.buf("satu.lrcat_tail", h_, w_, _lib.SATU_LRCAT_TAIL), h_, w_, scale,
+                         self.sbuf("satu.p27", _lib.TAIL_PLANES, plane_), plane_, tail_form=True)
+            torch.cuda.current_stream().synchronize()
             graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
             ev = self.satu_events
             self.satu_events = None
+            box = {}
             try:
-                with torch.cuda.graph(graphs[0]):
-                    c = self._stage_body(s_in, scale)
-                with torch.cuda.graph(graphs[1], pool=graphs[0].pool()):
-                    self._stage_satu(c, scale)
-                with torch.cuda.graph(graphs[2], pool=graphs[0].pool()):
-                    self._stage_tail(c, s_in, s_out)
+                self._capture(graphs[0], None, lambda: box.update(c=self._stage_body(s_in, scale)))
+                self._capture(graphs[1], graphs[0].pool(), lambda: self._stage_satu(box["c"], scale))
+                self._capture(graphs[2], graphs[0].pool(), lambda: self._stage_tail(box["c"], s_in, s_out))
             finally:
                 self.satu_events = ev
             # The captured launches bake in the raw device pointers of this (size, scale)'s SATU tables (phase table, per-pixel
@@ -928,6 +953,26 @@ class HipEngine:
         graphs[2].replay()
         out.copy_(s_out)
         return out
+
+    def _capture(self, graph: "torch.cuda.CUDAGraph", pool, fn) -> None:
+        """Record fn()'s launches into `graph` on a side stream.  This is torch.cuda.graph() without its entry ritual
+        (device-wide synchronize + gc.collect() + empty_cache() per graph: tens of ms, and the emptied cache turns the next
+        shape's allocations into fresh hipMallocs) -- a YAML sweep captures one graph set per (folder, scale, stream)."""
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_cap_stream", None) is None:
+            self._cap_stream = torch.cuda.Stream(device=self.dev)
+        cap = self._cap_stream
+        cap.wait_stream(cur)
+        with torch.cuda.stream(cap):
+            if pool is None:
+                graph.capture_begin()
+            else:
+                graph.capture_begin(pool=pool)
+            try:
+                fn()
+            finally:
+                graph.capture_end()
+        cur.wait_stream(cap)
 
     def _ensure_streams(self, ns: int):
         while len(self._siblings) < ns - 1:

@@ -376,7 +376,7 @@ def test_satu_hr_variants_bit_identical(eng, h, w, sc):
     lrcat = eng.satu_lr(eng.full(cl(x[0])), eng.full(cl(st[0])), w, h, w, tail_form=True)
     ax = eng.satu_axes(h, w, sc)
     assert len({t.variant for t in ax["tail_plans"]}) == eng.lib.savsr_satu_hr_variants() >= 2
-    assert len({(t.tile_rows, t.tile_cols32) for t in ax["tail_plans"]}) >= 3
+    assert len({(t.tile_rows, t.tile_cols32) for t in ax["tail_plans"]}) >= 2
     outs = []
     for til in ax["tail_plans"]:
         ax["tiling_tail"] = til
