@@ -45,8 +45,15 @@ __device__ __forceinline__ f32x4 ldg4(const float* base, unsigned byte_off) {
 __device__ __forceinline__ float ldg1(const float* base, unsigned idx) {
     return *((const SAVSR_GLOBAL float*)base + idx);
 }
+#ifndef CONV_ST
+#define CONV_ST 1                 // output stores of the conv epilogue: 0 plain, 1 nt (whole 128-B lines per wave store; solo 6 x 128->64 launch 182 -> 167 us, frame +0.4 %)
+#endif
 __device__ __forceinline__ void stg4(float* base, unsigned byte_off, const f32x4& v) {
+#if CONV_ST == 1
+    __builtin_nontemporal_store(v, (SAVSR_GLOBAL f32x4*)((SAVSR_GLOBAL char*)base + byte_off));
+#else
     *(SAVSR_GLOBAL f32x4*)((SAVSR_GLOBAL char*)base + byte_off) = v;
+#endif
 }
 // max without the NaN canonicalisation hipcc puts in front of fmaxf (one extra v_max_f32 per call); operands here are
 // results of fp32 arithmetic, never signalling NaNs

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from ._xfer import h2d
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvDesc, OSConvAttnDesc, SatuTiling, SatuWeights
 
 BN_EPS = 1e-5
@@ -657,7 +658,7 @@ class HipEngine:
             def up(a, dt):          # device copy padded to a multiple of 4 elements (the HR stage reads these arrays in 16-byte groups)
                 a = np.ascontiguousarray(a.astype(dt)).reshape(-1)
                 pad = (-len(a)) % 4
-                return torch.from_numpy(np.concatenate([a, np.repeat(a[-1:], pad)]) if pad else a).to(self.dev)
+                return h2d(torch.from_numpy(np.concatenate([a, np.repeat(a[-1:], pad)]) if pad else a), self.dev)
             ent = dict(H=H, W=W, n_uh=len(uh), n_uw=len(uw), uh=up(uh, np.float32), uw=up(uw, np.float32),
                        ih=up(ih.reshape(-1), np.int32), iw=up(iw.reshape(-1), np.int32), gyn=up(gyn, np.float32), gxn=up(gxn, np.float32),
                        table=torch.empty(len(uh) * len(uw) * _lib.SATU_TABLE, device=self.dev))
@@ -679,16 +680,24 @@ class HipEngine:
         scale (there is no cost model).  Purely a performance plan: waves whose taps leave the window gather from global
         memory, so results never depend on it."""
         sw = C.byref(self.satu_w)
-        _lib.check(self.lib.savsr_satu_phase_table(sw, ent["uh"].data_ptr(), ent["n_uh"], ent["uw"].data_ptr(), ent["n_uw"],
-                                                   1.0 / scale[1], 1.0 / scale[0], ent["table"].data_ptr(), self._stream()),
-                   "savsr_satu_phase_table")
         n_table = ent["n_uh"] * ent["n_uw"]
         ent["ptab"] = None
-        if n_table > self.HR_TABLE_LDS:
-            ent["ptab"] = torch.empty(ent["H"] * ent["W"] * _lib.SATU_TABLE, device=self.dev)     # the table per HR pixel, offsets normalised
-            _lib.check(self.lib.savsr_satu_expand_table(ent["table"].data_ptr(), ent["n_uw"], ent["ih"].data_ptr(), ent["iw"].data_ptr(), h, w,
-                                                        ent["H"], ent["W"], ent["ptab"].data_ptr(), self._stream()), "savsr_satu_expand_table")
-        tab = ent["table"].view(-1, _lib.SATU_TABLE).cpu().numpy()       # synchronises once
+        # The tables depend on (size, scale, weights) only, not on anything the compute stream holds: they are evaluated and read
+        # back on a side stream, so the read-back's host wait does not stand behind the frames still in flight.
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.dev)
+        with torch.cuda.stream(self._side_stream):
+            _lib.check(self.lib.savsr_satu_phase_table(sw, ent["uh"].data_ptr(), ent["n_uh"], ent["uw"].data_ptr(), ent["n_uw"],
+                                                       1.0 / scale[1], 1.0 / scale[0], ent["table"].data_ptr(), self._stream()),
+                       "savsr_satu_phase_table")
+            if n_table > self.HR_TABLE_LDS:
+                ent["ptab"] = torch.empty(ent["H"] * ent["W"] * _lib.SATU_TABLE, device=self.dev)     # the table per HR pixel, offsets normalised
+                ent["ptab"].record_stream(cur)
+                _lib.check(self.lib.savsr_satu_expand_table(ent["table"].data_ptr(), ent["n_uw"], ent["ih"].data_ptr(), ent["iw"].data_ptr(), h, w,
+                                                            ent["H"], ent["W"], ent["ptab"].data_ptr(), self._stream()), "savsr_satu_expand_table")
+            tab = ent["table"].view(-1, _lib.SATU_TABLE).cpu().numpy()   # waits for the side stream only
+        cur.wait_stream(self._side_stream)
         ox = np.concatenate([tab[:, 4], tab[:, 6]])
         oy = np.concatenate([tab[:, 5], tab[:, 7]])
         finite = bool(np.isfinite(ox).all() and np.isfinite(oy).all())
@@ -768,8 +777,15 @@ class HipEngine:
             cands = ax["tail_plans"]
             ckey = (h, w, float(scale[0]), float(scale[1]))
             pick = lambda k: next((t for t in cands if (t.variant, t.tile_rows, t.tile_cols32) == k), cands[0])
+            skey = ("scale", float(scale[0]), float(scale[1]))
+            near = self._hr_choice.get(skey)    # (plan, h, w) measured at this scale on another LR size
             if ckey in self._hr_choice:         # (a sibling engine has timed this size / scale already)
                 ax["tiling_tail"] = pick(self._hr_choice[ckey])
+            elif near is not None and 0.5 <= (h * w) / float(near[1] * near[2]) <= 2.0 and any((t.variant, t.tile_rows, t.tile_cols32) == near[0] for t in cands):
+                # the folders of a YAML dataset differ by a few rows / columns at one scale (Vid4 x4: 144x180, 144x176, 120x180): the
+                # plan is a function of the scale and the offset range far more than of the size -- one measurement per scale
+                ax["tiling_tail"] = pick(near[0])
+                self._hr_choice[ckey] = near[0]
             elif torch.cuda.is_current_stream_capturing():
                 ax["tiling_tail"] = cands[0]
             else:                               # one-time choice by measurement: every plan writes the same `out`, bit for bit
@@ -786,6 +802,7 @@ class HipEngine:
                 best = min(evs, key=lambda e: e[0].elapsed_time(e[1]))[2]
                 ax["tiling_tail"] = best
                 self._hr_choice[ckey] = (best.variant, best.tile_rows, best.tile_cols32)
+                self._hr_choice[skey] = (self._hr_choice[ckey], h, w)
         launch(ax["tiling_tail"])
         return out
 
@@ -919,22 +936,30 @@ class HipEngine:
             # buffers (their contents do not matter: no control flow of the HR kernel depends on the feature values).  The kernels'
             # LDS attributes were set by savsr_prepare_device.  There is no eager run of the frame: the launch sequence is issued
             # exactly once, into the capture, and the buffers it names are allocated there (arena chunks from the graphs' pool).
+            import time as _time
+            _t0 = _time.perf_counter()
             h_, w_ = int(lq.shape[-2]), int(lq.shape[-1])
             H_, W_ = get_hw(h_, w_, scale)
             plane_ = self.hr_plane(H_, W_)
             self.satu_hr(self.buf("satu.lrcat_tail", h_, w_, _lib.SATU_LRCAT_TAIL), h_, w_, scale,
                          self.sbuf("satu.p27", _lib.TAIL_PLANES, plane_), plane_, tail_form=True)
             torch.cuda.current_stream().synchronize()
+            _t1 = _time.perf_counter()
             graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
             ev = self.satu_events
             self.satu_events = None
             box = {}
             try:
                 self._capture(graphs[0], None, lambda: box.update(c=self._stage_body(s_in, scale)))
+                _t2 = _time.perf_counter()
                 self._capture(graphs[1], graphs[0].pool(), lambda: self._stage_satu(box["c"], scale))
                 self._capture(graphs[2], graphs[0].pool(), lambda: self._stage_tail(box["c"], s_in, s_out))
             finally:
                 self.satu_events = ev
+            if os.environ.get("SAVSR_PROFILE_CAPTURE"):
+                _t3 = _time.perf_counter()
+                print(f"[capture] {tuple(lq.shape)} x{scale}: plan {1e3 * (_t1 - _t0):.1f} ms, body {1e3 * (_t2 - _t1):.1f} ms "
+                      f"(python launches {1e3 * box.get('t_launch', 0):.1f}), satu+tail {1e3 * (_t3 - _t2):.1f} ms", file=__import__("sys").stderr, flush=True)
             # The captured launches bake in the raw device pointers of this (size, scale)'s SATU tables (phase table, per-pixel
             # expansion, row / column index and coordinate arrays).  Replays never go through satu_axes(), so its LRU neither sees
             # them nor may it free them: the graph tuple owns a reference and the tables live exactly as long as the graph does.

@@ -206,7 +206,11 @@ class FrameStore:
             self.stats["device_hits"] += 1
             self._dev.move_to_end(k)
             return t
-        t = torch.from_numpy(self.host(path)).to(device, non_blocking=False)
+        from ._xfer import h2d
+        arr = self.host(path)
+        if not arr.flags.writeable:                # (PIL hands out read-only buffers; torch wants to be told it may not write)
+            arr = arr.copy()
+        t = h2d(torch.from_numpy(arr), device)
         self.stats["uploaded"] += 1
         self._dev[k] = t
         self._dev_bytes += t.numel()
@@ -228,7 +232,8 @@ class FrameStore:
         dk = str(device)
         lut = self._lut.get(dk)
         if lut is None:
-            lut = torch.from_numpy(np.arange(256, dtype=np.uint8).astype(np.float32) / 255.0).to(device)
+            from ._xfer import h2d
+            lut = h2d(torch.from_numpy(np.arange(256, dtype=np.uint8).astype(np.float32) / 255.0), device)
             self._lut[dk] = lut
         out = []
         for p in paths:
