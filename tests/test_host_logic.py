@@ -172,3 +172,17 @@ def test_cal_step_and_as_mod_crop():
         assert as_mod_crop_hw(h, w, tuple(sc)) == (oh, ow), (sc, h, w)
         assert (cal_step(sc[0]), cal_step(sc[1])) == (st_h, st_w)
 
+
+
+def test_bench_gpus_flag_fails_loudly_without_the_gpus():
+    """`bench.py --gpus N` must never run a smaller job under the N-GPU label: on a node with fewer GPUs (none here) it refuses
+    before touching a device, and a launcher environment whose WORLD_SIZE disagrees with --gpus is refused too."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    if "node shows" in r.stderr:                  # fewer than 2 GPUs visible (the build container, a 1-GPU box)
+        assert r.returncode == 2 and r.stdout.strip() == ""
+    env["WORLD_SIZE"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr and r.stdout.strip() == ""
