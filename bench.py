@@ -160,7 +160,7 @@ def satu_roofline(eng, clip, h, w, scale, in_flight_ms=None):
         traffic, src = tr.get("bytes_per_stage"), tr.get("source")
     except (OSError, ValueError):
         pass
-    r = {"kernel": "SATU = satu_lr_kernel<NB=1> + satu_hr_kernel<NB=1> (tail-projected form: the 3x3 tail conv's channel contraction is folded in; "
+    r = {"kernel": "SATU = satu_lr_stream_kernel<NB=1> + satu_hr_kernel<NB=1> (tail-projected form: the 3x3 tail conv's channel contraction is folded in; "
                    "the phase table is evaluated once per size / scale / weights)",
          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
          "traffic": traffic if (h, w, tuple(scale)) == (LR_H, LR_W, SCALE) else None, "traffic_source": src,
