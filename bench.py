@@ -468,7 +468,7 @@ def run_run_test(args, rank, world, dev, dist):
         m = model_box["m"]
         net = m.net_g
         eng = net.engine()
-        t_net = 0.0
+        t_net, t_one = 0.0, 0.0
         for dsname, dso in sorted(opt["datasets"].items()):
             from savsr_amd.datasets import build_dataset
             ds = build_dataset(dict(dso))
@@ -481,6 +481,11 @@ def run_run_test(args, rank, world, dev, dist):
                 for k0 in range(0, len(items), g):
                     net.forward_many(items[k0:k0 + g], [dso["downsampling_scale"]] * len(items[k0:k0 + g]))
             t_net += timed(dist, dev, region2)
+
+            def region1():                    # ... and one clip in flight: the reference's own flow (video_base_model.py:51-53)
+                for it in items:
+                    net(it.unsqueeze(0))
+            t_one += timed(dist, dev, region1)
         if rank != 0:
             return
         warm = passes[1]
@@ -494,6 +499,9 @@ def run_run_test(args, rank, world, dev, dist):
         line["bench_config"] = "run_test"
         line["cold_pass"], line["steady_pass"] = passes[0], passes[1]
         line["network_only_frames_per_s"] = round(n_frames / t_net, 2)
+        line["network_only_one_in_flight_frames_per_s"] = round(n_frames / t_one, 2)
+        line["steady_vs_one_in_flight"] = round(warm["frames_per_s"] / (n_frames / t_one), 4)
+        line["cold_vs_one_in_flight"] = round(passes[0]["frames_per_s"] / (n_frames / t_one), 4)
         line["steady_vs_network_only"] = round(warm["frames_per_s"] / (n_frames / t_net), 4)
         line["cold_vs_network_only"] = round(passes[0]["frames_per_s"] / (n_frames / t_net), 4)
         line["metrics_x4"] = {k: round(v, 4) for k, v in results[0]["metrics"].items()}
