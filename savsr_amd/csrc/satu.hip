@@ -1180,9 +1180,12 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
 //   variant 1 = 10 compute + 6 producer waves (4 per SIMD: the lane = pixel tile needs 126 VGPRs)
 // measured at 180x320, tail form (us; 8+4 -> 10+6): x4 40.4 -> 37.1, x3.7 37.3 -> 36.3, x3.9 37.2 -> 38.4, x3 28.0 -> 29.3, x2 22.0 -> 23.7,
 // (2.95, 3.75) 38.6 -> 43.9, 480x318 x(1.5, 4) 51.4 -> 60.0; other splits at x4: 12+4 38.6-39.1, 10+2 38.5-38.9, 8+8 37.9-39.3, 6+10 42-43, 14+2 50.
-constexpr int HR_VARIANTS = 2;
-__host__ __device__ constexpr int hr_compute_waves(int variant) { return variant == 1 ? 10 : 8; }
-__host__ __device__ constexpr int hr_producer_waves(int variant) { return variant == 1 ? 6 : 4; }
+//   variant 2 = 12 compute + 4 producer waves, variant 3 = 8 + 8 (round 3: with write-through plane stores the balance between
+//               gather waves and staging waves is measured again per size / scale; the engine times every plan)
+//               variant 4 = 6 + 10: staging-bound shapes (low vertical scale: a tile's LRcat window is large against its HR pixels)
+constexpr int HR_VARIANTS = 5;
+__host__ __device__ constexpr int hr_compute_waves(int variant) { return variant == 1 ? 10 : (variant == 2 ? 12 : (variant == 4 ? 6 : 8)); }
+__host__ __device__ constexpr int hr_producer_waves(int variant) { return variant == 1 ? 6 : (variant == 3 ? 8 : (variant == 4 ? 10 : 4)); }
 // One LDS-DMA: the active lanes move 16 B each, global (uniform 64-bit base in SGPRs + a 32-bit byte offset per lane) ->
 // lds_base + 16 * lane (no registers, no ds_write).  The scalar-base form keeps the whole address computation of a staging
 // loop on the scalar unit: with a per-lane 64-bit address every DMA cost ~40 vector instructions (quarter-rate 64-bit
@@ -1538,6 +1541,9 @@ int satu_prepare_device() {
 #endif
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 1, 0>), 160 * 1024, "satu_hr")) return rc;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 1, 1>), 160 * 1024, "satu_hr")) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 1, 2>), 160 * 1024, "satu_hr")) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 1, 3>), 160 * 1024, "satu_hr")) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 1, 4>), 160 * 1024, "satu_hr")) return rc;
     return ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 2, 0>), 160 * 1024, "satu_hr");
 }
 }  // namespace savsr
@@ -1674,6 +1680,9 @@ static int hr_stage(const savsr_satu_weights* wt, const float* lrcat, int h, int
     hipStream_t st = static_cast<hipStream_t>(stream);
     if constexpr (NB == 1) {
         if (variant == 1) return hr_launch<1, 1>(p, lds, grid, diag, st);
+        if (variant == 2) return hr_launch<1, 2>(p, lds, grid, diag, st);
+        if (variant == 3) return hr_launch<1, 3>(p, lds, grid, diag, st);
+        if (variant == 4) return hr_launch<1, 4>(p, lds, grid, diag, st);
     }
     return hr_launch<NB, 0>(p, lds, grid, diag, st);
 }

@@ -713,7 +713,7 @@ class HipEngine:
                 rx, ry = float(ox.max() - ox.min()), float(oy.max() - oy.min())
                 # tile rows: whole rounds of the compute waves first (rpw * cw, 2 rpw * cw), then the generic 8 / 16 / 32
                 cands = [(int(forced.split(",")[0]), int(forced.split(",")[1]))] if forced else \
-                    [(r, c) for c in (1, 2) for r in sorted({8, 16, 32, rpw * cw, 2 * rpw * cw}) if r % 4 == 0 and r <= 64]
+                    [(r, c) for c in (1, 2) for r in sorted({4, 8, 16, 32, rpw * cw, 2 * rpw * cw}) if r % 4 == 0 and r <= 64]   # (4 rows: the only window that fits below ~x1.6)
                 for trows, tcols in cands:
                     lr_c = min(max(int(np.ceil(32 * tcols / scale[1] + rx)) + 2, 2), w)
                     lr_r = min(int(np.ceil(trows / scale[0] + ry)) + 2, h)
