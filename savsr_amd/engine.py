@@ -852,8 +852,8 @@ class HipEngine:
         for i in range(self.n_l2):
             u = f"h_win.{i}"
             ws = steps - 2 * i
-            hfs = [self.conv(f"{u}.conv_h.{j}", [level[j]], self.full(self.buf(f"l2.{i}.hf{j}", hp, wp, nf)), hp, wp, ACT_LRELU, 0.2)
-                   for j in range(ws)]
+            hfs = [self.full(self.buf(f"l2.{i}.hf{j}", hp, wp, nf)) for j in range(ws)]       # :488: ws independent convs, one launch
+            self.conv_launch([self.conv_desc(f"{u}.conv_h.{j}", [level[j]], hfs[j], hp, wp, ACT_LRELU, 0.2) for j in range(ws)], "conv_h")
             nxt: List[Src] = []
             for j in range(ws - fw + 1):
                 swf = hfs[j:j + fw]
