@@ -83,7 +83,13 @@ def gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int, owners
     k = local.shape[1]
     padded = torch.zeros(per, k, dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
-    if local.is_cuda:
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # a gloo group over GPU ranks (several ranks sharing ONE GPU in a test -- RCCL refuses duplicate devices): the rows take
+        # the host path of the collective and come back to the device
+        lst = [torch.empty(per, k, dtype=local.dtype) for _ in range(world)]
+        dist.all_gather(lst, padded.cpu())
+        parts = torch.stack(lst, 0).to(local.device)
+    elif local.is_cuda:
         buf = torch.empty(world * per, k, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(buf, padded)
         parts = buf.view(world, per, k)

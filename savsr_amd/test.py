@@ -38,7 +38,11 @@ def run_test(opt: Union[str, dict], root_path: str = ".", model=None) -> List[di
     if opt["dist"]:
         import torch.distributed as dist
         if not dist.is_initialized():
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))   # RCCL over xGMI
+            backend = os.environ.get("SAVSR_DIST_BACKEND", "nccl")          # "gloo": tests with several ranks on one GPU
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))   # RCCL over xGMI
+            else:
+                dist.init_process_group(backend=backend)
             own_group = True
     try:
         test_sets = [build_dataset(d) for _, d in sorted(opt["datasets"].items())]       # test.py:26-32

@@ -261,3 +261,36 @@ def test_sharded_datasets_read_their_block_only(workdir, monkeypatch):
         ds2.shard(rank, 2)
         ds2[mine[0]]
         assert sio.frame_store().stats["decoded"] == 9 and sio.frame_store().stats["uploaded"] == 9
+
+
+def test_two_ranks_on_one_gpu(workdir, tmp_path):
+    """The N > 1 flow end to end on the hardware at hand: TWO ranks (fresh processes from torch.distributed.run, both on cuda:0,
+    gloo group because RCCL refuses two ranks on one device) run run_test(opt) over the PNG tree -- per-folder block partition,
+    every rank reading only its block + window reach, ONE gather per dataset, aggregation -- and both return exactly the
+    single-process table."""
+    import subprocess
+    import sys
+    from savsr_amd.test import run_test
+    opt = _opt(workdir)
+    opt["val"]["save_img"] = False
+    base = run_test(opt)
+    ypath = str(tmp_path / "two_rank.yml")
+    open(ypath, "w").write(YAML.format(root=workdir))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "res")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_two_rank_run_test.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), helper, ypath, workdir, out], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    tabs = [torch.load(f"{out}.{k}.pt", weights_only=False) for k in range(2)]
+    n_files = sum(n for n, _, _ in FOLDERS.values())
+    for t in tabs:
+        assert [x["dataset"] for x in t["results"]] == [b["dataset"] for b in base]
+        for x, b in zip(t["results"], base):
+            assert x["metrics"] == b["metrics"] and x["folders"] == b["folders"]
+            for f in b["frames"]:
+                assert torch.equal(x["frames"][f], b["frames"][f])
+        assert 0 < t["store"]["decoded"] <= n_files            # (tiny folders: block + window reach may cover a whole folder)
