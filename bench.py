@@ -209,7 +209,7 @@ def timed(dist, dev, fn):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     return elapsed
@@ -255,7 +255,12 @@ def run_config2(args, rank, world, dev, dist):
         for i in range(args.steps):
             step(i, True)
         if dist is not None:      # the one collective of the "dataset" (RCCL all_gather over xGMI)
-            dist.all_gather_into_tensor(gathered, rows)
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(gathered, rows)
+            else:                 # SAVSR_DIST_BACKEND=gloo (ranks sharing one GPU in a test): the rows take the host path
+                lst = [torch.empty(rows.shape, dtype=rows.dtype) for _ in range(world)]
+                dist.all_gather(lst, rows.cpu())
+                gathered.copy_(torch.cat(lst, 0))
     elapsed = timed(dist, dev, region)
     in_flight = [a.elapsed_time(b) for a, b in eng.satu_events]
     eng.satu_events = None
@@ -528,6 +533,8 @@ def self_launch(args, argv):
     import socket
     import subprocess
     have = torch.cuda.device_count()
+    if os.environ.get("SAVSR_BENCH_SHARE_GPU") == "1" and have >= 1:
+        have = args.gpus              # TEST mode: all ranks on GPU 0 over a gloo group (exercises the N > 1 code path on a 1-GPU box)
     if have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} requested but this node shows {have} GPU(s); refusing to run a smaller job under that label",
               file=sys.stderr, flush=True)
@@ -569,6 +576,10 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    share = os.environ.get("SAVSR_BENCH_SHARE_GPU") == "1"      # test mode (see self_launch): not a performance configuration
+    if share:
+        local_rank = 0
+        os.environ.setdefault("SAVSR_DIST_BACKEND", "gloo")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
@@ -578,7 +589,10 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group(backend="nccl", device_id=dev)    # RCCL over xGMI
+        if os.environ.get("SAVSR_DIST_BACKEND", "nccl") == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)    # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=os.environ["SAVSR_DIST_BACKEND"])
     try:
         if args.config == "run_test":
             run_run_test(args, rank, world, dev, dist)

@@ -294,3 +294,22 @@ def test_two_ranks_on_one_gpu(workdir, tmp_path):
             for f in b["frames"]:
                 assert torch.equal(x["frames"][f], b["frames"][f])
         assert 0 < t["store"]["decoded"] <= n_files            # (tiny folders: block + window reach may cover a whole folder)
+
+
+def test_bench_two_ranks_share_the_gpu():
+    """bench.py's N > 1 path on a 1-GPU box: `--gpus 2` starts its own two ranks (SAVSR_BENCH_SHARE_GPU=1: both on GPU 0, gloo
+    group), rank 0 prints ONE JSON line with n_gpus 2 and the whole-job value; a test of the code path, not a performance figure."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SAVSR_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips-per-step", "3",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"] == "clip-sharded dp2"
+    assert abs(d["value"] - 2 * 2 * 3 * 0.9216 / (d["ms_per_step"] * 2 / 1e3)) < 0.05 * d["value"]      # whole-job: all ranks' clips / max time
