@@ -660,8 +660,7 @@ class HipEngine:
                 pad = (-len(a)) % 4
                 return h2d(torch.from_numpy(np.concatenate([a, np.repeat(a[-1:], pad)]) if pad else a), self.dev)
             ent = dict(H=H, W=W, n_uh=len(uh), n_uw=len(uw), uh=up(uh, np.float32), uw=up(uw, np.float32),
-                       ih=up(ih.reshape(-1), np.int32), iw=up(iw.reshape(-1), np.int32), gyn=up(gyn, np.float32), gxn=up(gxn, np.float32),
-                       table=torch.empty(len(uh) * len(uw) * _lib.SATU_TABLE, device=self.dev))
+                       ih=up(ih.reshape(-1), np.int32), iw=up(iw.reshape(-1), np.int32), gyn=up(gyn, np.float32), gxn=up(gxn, np.float32))
             self._plan_hr_tiling(ent, h, w, scale)
             self._axes[key] = ent
             while len(self._axes) > max(self.max_shapes, self.max_scales):
@@ -688,6 +687,10 @@ class HipEngine:
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=self.dev)
         with torch.cuda.stream(self._side_stream):
+            # (allocated under the side stream: a block the allocator recycles from the compute stream could still have work
+            # pending there, and this stream does not wait for it)
+            ent["table"] = torch.empty(n_table * _lib.SATU_TABLE, device=self.dev)
+            ent["table"].record_stream(cur)
             _lib.check(self.lib.savsr_satu_phase_table(sw, ent["uh"].data_ptr(), ent["n_uh"], ent["uw"].data_ptr(), ent["n_uw"],
                                                        1.0 / scale[1], 1.0 / scale[0], ent["table"].data_ptr(), self._stream()),
                        "savsr_satu_phase_table")

@@ -281,7 +281,7 @@ def test_two_ranks_on_one_gpu(workdir, tmp_path):
         port = s.getsockname()[1]
     out = str(tmp_path / "res")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_two_rank_run_test.py")
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "two_rank_worker.py")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), helper, ypath, workdir, out], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
