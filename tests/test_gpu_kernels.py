@@ -296,8 +296,9 @@ def test_tail_residual(eng, synth_sd):
     center = torch.from_numpy(np.random.RandomState(52).uniform(0, 1, (1, 3, h, w)).astype(np.float32))
     out = torch.empty(3, H, W, device="cuda:0")
     from savsr_amd import _lib
-    _lib.check(eng.lib.savsr_tail_residual(_dev(feat[0]).data_ptr(), H * W, eng.tail_w.data_ptr(), eng.tail_b.data_ptr(),
-                                           (cd := _dev(center[0])).data_ptr(), h, w, H, W, out.data_ptr(), None), "tail")
+    fd, cd = _dev(feat[0]), _dev(center[0])        # (named: a temporary would be freed -- and its block reused -- before the launch reads it)
+    _lib.check(eng.lib.savsr_tail_residual(fd.data_ptr(), H * W, eng.tail_w.data_ptr(), eng.tail_b.data_ptr(),
+                                           cd.data_ptr(), h, w, H, W, out.data_ptr(), None), "tail")
     torch.cuda.synchronize()
     ref = F.conv2d(feat, synth_sd["tail.weight"], synth_sd["tail.bias"], padding=1) + \
         F.interpolate(center, size=(H, W), mode="bilinear", align_corners=False)
@@ -457,7 +458,8 @@ def test_pack_windows_reflect_pad(eng):
     T, h, w = 7, 7, 9
     lq = torch.from_numpy(np.random.RandomState(3).uniform(0, 1, (T, 3, h, w)).astype(np.float32))
     o = torch.empty(T - 2, 8, 10, 16, device="cuda:0")
-    _lib.check(eng.lib.savsr_pack_windows(_dev(lq).data_ptr(), o.data_ptr(), T, h, w, 8, 10, None), "pack_windows")
+    lqd = _dev(lq)
+    _lib.check(eng.lib.savsr_pack_windows(lqd.data_ptr(), o.data_ptr(), T, h, w, 8, 10, None), "pack_windows")
     torch.cuda.synchronize()
     padded = F.pad(lq, [0, 1, 0, 1], mode="reflect")
     for q in range(T - 2):
