@@ -701,6 +701,9 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
     }
 
     // ---- LR-side projections (bf16x3): image in LDS buffer 0 (DMA'd behind B(8), published by B(9)) ----
+    // No LDS-DMA of this wave may be in flight when the workgroup's LDS is released: the last phase's (dummy) pieces were issued
+    // ~4 groups ago; this also covers the centre-pixel loads the projections consume next.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const bf16x8* pa = wbuf + lane;
     const bf16x8* pb = pa + NB * 4 * 2 * 64;
     const bf16x8* pc = pb + NB * 4 * 2 * 64;
