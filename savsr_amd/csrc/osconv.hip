@@ -373,20 +373,34 @@ __global__ __launch_bounds__(1024) void se_scale_residual_kernel(const float* pa
                                                                const float* w2, const float* b2, int c, int cmid, const f32x4* __restrict__ r,
                                                                const f32x4* __restrict__ x, f32x4* __restrict__ out, long long n4) {
     __shared__ __attribute__((aligned(16))) float g[128];
-    // the streaming operands of this workgroup's first elements do not depend on the gate: their loads go out first
-    const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, b0 = a0;
-    if (i0 < n4) { a0 = r[i0]; b0 = x[i0]; }
+    // The streaming operands do not depend on the gate: the loads of this thread's first SE_UNROLL elements (all of them at
+    // 180x320: 3.5 per thread) go out before the gate is evaluated and land under it -- one memory round trip per thread instead
+    // of one per element (the loop used to issue two loads, wait, store: 11.5 us for 44 MB).  The result is read by the next
+    // kernel, not by this one: nt stores.
+    constexpr int SE_UNROLL = 4;
+    const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x, stride = (long long)gridDim.x * 1024;
+    f32x4 av[SE_UNROLL], bv[SE_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SE_UNROLL; ++u) {
+        const long long i = i0 + u * stride;
+        av[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[u] = av[u];
+        if (i < n4) { av[u] = r[i]; bv[u] = x[i]; }
+    }
     se_gate_block(partial, nblk, inv_n, w1, b1, w2, b2, c, cmid, g);
     const int c4 = c >> 2;
-    for (long long i = i0; i < n4; i += (long long)gridDim.x * 1024) {
+    auto apply = [&](long long i, const f32x4& a, const f32x4& b2_) {
         const f32x4 gq = *reinterpret_cast<const f32x4*>(g + 4 * (int)(i % c4));
-        f32x4 a, b2_;
-        if (i == i0) { a = a0; b2_ = b0; } else { a = r[i]; b2_ = x[i]; }
         f32x4 o;
         o[0] = a[0] * gq[0] + b2_[0]; o[1] = a[1] * gq[1] + b2_[1]; o[2] = a[2] * gq[2] + b2_[2]; o[3] = a[3] * gq[3] + b2_[3];
-        out[i] = o;
+        __builtin_nontemporal_store(o, out + i);
+    };
+#pragma unroll
+    for (int u = 0; u < SE_UNROLL; ++u) {
+        const long long i = i0 + u * stride;
+        if (i < n4) apply(i, av[u], bv[u]);
     }
+    for (long long i = i0 + SE_UNROLL * stride; i < n4; i += stride) apply(i, r[i], x[i]);
 }
 
 // out[px][c] = r[px][c] * gate[c] + x[px][c]   (savsr_arch.py:524,548-549), c == 64 contiguous
