@@ -53,6 +53,9 @@
 #ifndef CONV_EXP
 #define CONV_EXP 0
 #endif
+#ifndef CONV_1X1_WIDE
+#define CONV_1X1_WIDE 1           // 16-row tiles for the 1x1 convs too (experiment switch)
+#endif
 #ifndef ROWS_SKIP
 #define ROWS_SKIP 1               // 0: one phase body, MFMAs on zeros below the image; 1: a wave with NO row inside the image runs a body without MFMAs;
                                   // 2: also a one-row body for waves with one row of two inside (three bodies: 69 spilled VGPRs in the 16-row kernel)
@@ -775,6 +778,9 @@ int conv_prepare_device() {
     if (int rc = conv_attr<3, 2, 1>()) return rc;
     if (int rc = conv_attr<3, 1, 1>()) return rc;
     if (int rc = conv_attr<1, 2, 1>()) return rc;
+#if CONV_1X1_WIDE
+    if (int rc = conv_attr<1, 2, 2>()) return rc;
+#endif
     return conv_attr<1, 1, 1>();
 }
 
@@ -903,6 +909,15 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
         return launch_conv<3, 2, 1>(mp, st);
     }
     if (d->ksize == 3) return launch_conv<3, 1, 1>(mp, st);
+#if CONV_1X1_WIDE
+    if (wide && d->cout % 64 == 0) {               // 1x1: 16-row tiles from the same tile counts up (half the barriers and fragment reads per pixel)
+        const int nty2 = (d->h + 2 * CONV_TH - 1) / (2 * CONV_TH);
+        if (n * mp.ncob * mp.ntx * nty2 >= (d->algo == SAVSR_CONV_DIRECT_THROUGHPUT ? CONV_WIDE_MIN_TILES_TP : CONV_WIDE_MIN_TILES)) {
+            mp.nty = nty2;
+            return launch_conv<1, 2, 2>(mp, st);
+        }
+    }
+#endif
     return wide ? launch_conv<1, 2, 1>(mp, st) : launch_conv<1, 1, 1>(mp, st);
 }
 

@@ -146,6 +146,18 @@ def test_conv2d_algo_field(eng):
     assert eng.lib.savsr_conv2d(C.byref(d), None) < 0 and b"algo" in eng.lib.savsr_last_error()
     d = eng.conv_desc("t", [eng.full(x)], eng.full(outs[0]), h, w, weights=(img, None, 128, 64, 3, 1))
     assert eng.lib.savsr_conv2d(C.byref(d), None) < 0 and b"algo" in eng.lib.savsr_last_error()
+    # 1x1 convs take the 16-row tiling from the same tile counts up (round 3): same bits, and right against fp32 F.conv2d
+    wt1 = torch.from_numpy((g.standard_normal((128, 64, 1, 1)) / 16.0).astype(np.float32))
+    img1 = _dev(E.pack_conv_weight(wt1))
+    outs1 = []
+    for algo in (_lib.CONV_DIRECT, _lib.CONV_DIRECT_THROUGHPUT):
+        o = torch.full((h, w, 128), float("nan"), device="cuda:0")
+        eng.conv("t", [eng.full(x)], eng.full(o), h, w, weights=(img1, None, 128, 64, 1, algo))
+        outs1.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(outs1[0], outs1[1])
+    ref1 = F.conv2d(x.permute(2, 0, 1)[None].cpu(), wt1)[0]
+    assert _maxerr(pl(outs1[0]), ref1) < 3e-5
 
 
 @pytest.mark.parametrize("tag,pfx,cin", OSCONV_CASES)
