@@ -144,14 +144,27 @@ class VideoBaseModel(BaseModel):
         cur_folder = None
         ev = []                                                        # (start, end) HIP events around the device work of a group
         timing = bool(self.opt.get("profile_gpu_time"))
-        for k0 in range(0, len(mine), group):
+        # Groups never straddle folders (a folder is one LR shape = one captured graph set per stream), and a folder block with few
+        # frames -- a rank's share at world size 8 is ~5 frames of a 41-frame Vid4 folder -- keeps fewer clips in flight: every
+        # stream's engine captures its own graphs (~5 ms each), which only pays back over enough frames.
+        chunks = []
+        k = 0
+        while k < len(mine):
+            f0 = folders_all[mine[k]]
+            k1 = k
+            while k1 < len(mine) and folders_all[mine[k1]] == f0:
+                k1 += 1
+            g_f = group if k1 - k >= 4 * group else (min(group, 2) if k1 - k >= 6 else 1)
+            chunks += [(a, min(a + g_f, k1)) for a in range(k, k1, g_f)]
+            k = k1
+        for k0, k_end in chunks:
             f0 = folders_all[mine[k0]]
             if f0 != cur_folder:                                      # entering a folder: the pool decodes the NEXT one meanwhile
                 cur_folder = f0
                 nxt = my_folders.index(f0) + 1
                 if hasattr(dataset, "prefetch") and nxt < len(my_folders):
                     dataset.prefetch(my_folders[nxt])
-            vals = [dataset[idx] for idx in mine[k0:k0 + group]]
+            vals = [dataset[idx] for idx in mine[k0:k_end]]
             if timing:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
