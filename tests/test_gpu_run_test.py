@@ -80,7 +80,7 @@ val:
       test_y_channel: true
 """
 
-FOLDERS = {"calendar": (5, 45, 62), "city": (4, 45, 62)}       # name -> (frames, H, W); a 7-frame reflection window needs >= 4 frames
+FOLDERS = {"calendar": (12, 45, 62), "city": (4, 45, 62)}       # name -> (frames, H, W); a 7-frame reflection window needs >= 4 frames
 
 
 @pytest.fixture(scope="module")
