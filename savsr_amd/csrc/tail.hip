@@ -138,25 +138,39 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ fea
 // savsr_arch.py:738-739 is the spatial part and the residual:
 //     out[o][Y][X] = tail_b[o] + sum_{ky,kx} P[3 (3 ky + kx) + o][Y + ky - 1][X + kx - 1]  (zero outside)  + bilinear(center)
 // Pure HBM streaming: every element of the 27 planes is read once (99.5 MB at 720x1280 instead of the 236 MB feature map),
-// 11 MB written.  One thread = 4 consecutive pixels of a row (16-B loads; the kx = 0 / 2 planes are read at a +-4-B
-// offset, which global loads allow), rows of 27 independent loads in flight per thread.
+// 11 MB written.  One thread = 4 consecutive pixels of a row of ONE output channel (16-B loads; the kx = 0 / 2 planes are
+// read at a +-4-B offset, which global loads allow): 9 plane loads per thread.  Measured at 720x1280 (99.5 MB + 11 MB): all
+// three channels per thread (27 loads) 31.9 us, one channel per thread 22.6 us (4.9 TB/s); 8 pixels per thread 49 us,
+// non-temporal loads 43.7 us, one / two / eight rows per workgroup 34.3 / 22.3 / 24.5 us -- the light thread wins.
 // ------------------------------------------------------------------------------------------
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+#ifndef TG_OSPLIT
+#define TG_OSPLIT 1               // 1: one output channel per thread (grid z = 3): 9 plane loads per thread instead of 27
+#endif
+#ifndef TG_ROWS
+#define TG_ROWS 4                 // image rows per 256-thread workgroup
+#endif
+#ifndef TG_PX
+#define TG_PX 4                   // pixels per thread on the vector path (4: 16-B accesses, 2: 8-B)
+#endif
+typedef float tg_vec __attribute__((ext_vector_type(TG_PX)));
+typedef float tg_vecu __attribute__((ext_vector_type(TG_PX), aligned(4)));
 
-template <bool VEC>   // VEC: W % 4 == 0 and the plane pitch a multiple of 4 floats -> 16-B accesses; else one pixel per thread
+template <bool VEC>   // VEC: W % TG_PX == 0 and the plane pitch a multiple of 4 floats -> vector accesses; else one pixel per thread
 __global__ __launch_bounds__(256) void tail_gather_kernel(const float* __restrict__ P, long long PP, const float* __restrict__ bias,
                                                           const float* __restrict__ center, int h, int w, int H, int W, float* __restrict__ out) {
-    constexpr int NPX = VEC ? 4 : 1;
-    const int xq = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int X = xq * NPX;
+    constexpr int NPX = VEC ? TG_PX : 1;
+    constexpr int TPR = 256 / TG_ROWS;                           // threads per row
+    constexpr int NO = TG_OSPLIT ? 1 : 3;                        // output channels per thread
+    const int X = (blockIdx.x * TPR + (threadIdx.x % TPR)) * NPX;
+    const int Y = blockIdx.y * TG_ROWS + (threadIdx.x / TPR);
+    const int O0 = TG_OSPLIT ? (int)blockIdx.z : 0;
     if (X >= W || Y >= H) return;
-    float acc[3][NPX];
+    float acc[NO][NPX];
 #pragma unroll
-    for (int o = 0; o < 3; ++o)
+    for (int o = 0; o < NO; ++o)
 #pragma unroll
         for (int i = 0; i < NPX; ++i) acc[o][i] = 0.f;
-    const bool interior = VEC && X >= 4 && X + 8 <= W;           // every shifted 4-vector of this thread lies inside the row
+    const bool interior = VEC && X >= 4 && X + NPX + 4 <= W;     // every shifted vector of this thread lies inside the row
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int yy = Y + ky - 1;
@@ -164,10 +178,10 @@ __global__ __launch_bounds__(256) void tail_gather_kernel(const float* __restric
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                const float* row = P + (long long)(3 * (3 * ky + kx) + o) * PP + (long long)yy * W;
+            for (int o = 0; o < NO; ++o) {
+                const float* row = P + (long long)(3 * (3 * ky + kx) + O0 + o) * PP + (long long)yy * W;
                 if (VEC && (interior || kx == 1)) {
-                    const f32x4u v = *reinterpret_cast<const f32x4u*>(row + X + kx - 1);
+                    const tg_vecu v = *reinterpret_cast<const tg_vecu*>(row + X + kx - 1);
 #pragma unroll
                     for (int i = 0; i < NPX; ++i) acc[o][i] += v[i];
                 } else {
@@ -184,25 +198,29 @@ __global__ __launch_bounds__(256) void tail_gather_kernel(const float* __restric
     float ly;
     bil_src(Y, (float)h / (float)H, h, y0, y1, ly);
     const long long HW = (long long)H * W;
-    float res[3][NPX];
+    float res[NO][NPX];
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
         int x0, x1;
         float lx;
         bil_src(X + i, (float)w / (float)W, w, x0, x1, lx);
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const float* c = center + (long long)o * h * w;
+        for (int o = 0; o < NO; ++o) {
+            const float* c = center + (long long)(O0 + o) * h * w;
             const float top = (1.f - lx) * c[y0 * w + x0] + lx * c[y0 * w + x1];
             const float bot = (1.f - lx) * c[y1 * w + x0] + lx * c[y1 * w + x1];
-            res[o][i] = (acc[o][i] + bias[o]) + ((1.f - ly) * top + ly * bot);
+            res[o][i] = (acc[o][i] + bias[O0 + o]) + ((1.f - ly) * top + ly * bot);
         }
     }
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        float* dst = out + (long long)o * HW + (long long)Y * W + X;
-        if (VEC) *reinterpret_cast<f32x4*>(dst) = f32x4{res[o][0], res[o][VEC ? 1 : 0], res[o][VEC ? 2 : 0], res[o][VEC ? 3 : 0]};
-        else dst[0] = res[o][0];
+    for (int o = 0; o < NO; ++o) {
+        float* dst = out + (long long)(O0 + o) * HW + (long long)Y * W + X;
+        if (VEC) {
+            tg_vec r;
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) r[i] = res[o][i];
+            *reinterpret_cast<tg_vec*>(dst) = r;
+        } else dst[0] = res[o][0];
     }
 }
 
@@ -225,9 +243,9 @@ extern "C" int savsr_tail_gather(const float* p27, int64_t p_plane, const float*
                                  float* out, void* stream) {
     if (!p27 || !b || !center || !out) return fail_arg("tail_gather: null pointer");
     if (h < 1 || wd < 1 || H < 1 || W < 1 || p_plane < (int64_t)H * W) return fail_arg("tail_gather: shape");
-    const bool vec = (W & 3) == 0 && (p_plane & 3) == 0 && !((reinterpret_cast<uintptr_t>(p27) | reinterpret_cast<uintptr_t>(out)) & 15);
-    const int npx = vec ? 4 : 1;
-    dim3 grid((W + 64 * npx - 1) / (64 * npx), (H + 3) / 4);
+    const bool vec = (W & (TG_PX - 1)) == 0 && (p_plane & 3) == 0 && !((reinterpret_cast<uintptr_t>(p27) | reinterpret_cast<uintptr_t>(out)) & 15);
+    const int npx = vec ? TG_PX : 1, tpr = 256 / TG_ROWS;
+    dim3 grid((W + tpr * npx - 1) / (tpr * npx), (H + TG_ROWS - 1) / TG_ROWS, TG_OSPLIT ? 3 : 1);
     if (vec) hipLaunchKernelGGL(tail_gather_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p27, (long long)p_plane, b, center, h, wd, H, W, out);
     else hipLaunchKernelGGL(tail_gather_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p27, (long long)p_plane, b, center, h, wd, H, W, out);
     return check_launch("tail_gather_kernel");

@@ -69,7 +69,14 @@ def main():
             print(f"LR stream kernel, wave {4 * wv}: cycles at [prologue end, cg0 loop end, tile swap, cg1 loop end, projections] = {m[:5].astype(int).tolist()}, "
                   f"total {int(m[7])} cycles, clock {clk:.0f} MHz; workgroup start spread {(stt[:, 0, 5].max() - stt[:, 0, 5].min()) / 100.0:.2f} us, "
                   f"first start -> last end {(stt[:, :, 6].max() - stt[:, 0, 5].min()) / 100.0:.2f} us")
+    center = torch.rand(3, h, w, generator=g).to(dev)
+    outb = torch.empty(3, H, W, device=dev)
+    tb = torch.zeros(3, device=dev)
+    st_ = torch.cuda.current_stream().cuda_stream
+    tail = lambda: _lib.check(eng.lib.savsr_tail_gather(p27.data_ptr(), plane, tb.data_ptr(), center.data_ptr(), h, w, H, W, outb.data_ptr(), st_), "tail")
     for _ in range(a.reps):
+        tt, tht = t(tail), t(lambda: (hr(), tail()))
+        print(f"tail_gather alone {tt:.1f} us   HR->tail pair {tht:.1f} us", flush=True)
         tl, th = t(lr), t(hr)
         tp = t(lambda: (lr(), hr()))          # the stage as the frame runs it: LR, then the dependent HR launch
         til = eng.satu_axes(h, w, sc)["tiling_tail"]
