@@ -56,6 +56,9 @@
 #ifndef CONV_1X1_WIDE
 #define CONV_1X1_WIDE 1           // 16-row tiles for the 1x1 convs too (experiment switch)
 #endif
+#ifndef EPI_PREFETCH
+#define EPI_PREFETCH 1            // the epilogue's first global loads (bias quads, first residual group) are issued in front of the tile's LAST phase
+#endif
 #ifndef ROWS_SKIP
 #define ROWS_SKIP 1               // 0: one phase body, MFMAs on zeros below the image; 1: a wave with NO row inside the image runs a body without MFMAs;
                                   // 2: also a one-row body for waves with one row of two inside (three bodies: 69 spilled VGPRs in the 16-row kernel)
@@ -350,7 +353,36 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         // every variant stages, reads its fragments (the ring feeds the NEXT tile too) and meets the barriers alike; only the MFMA
         // groups of absent rows are left out.
         const int rows_valid = __builtin_amdgcn_readfirstlane((y0 + wave < H ? 1 : 0) + (PXT > 1 && y0 + wave + CONV_TH < H ? 1 : 0));
-        for (int chunk = 0; chunk < mp.nchunk; ++chunk) {
+        // EPI_PREFETCH: the loads the epilogue would start with -- the bias quads of both channel groups and the residual quads of
+        // its first (row, channel-group) step -- go out in front of the tile's LAST phase, so their global latency (one exposed
+        // HBM round trip per tile and wave, ~1.5 k of a single-tile launch's ~30 k cycles) runs under that phase's MFMAs.  They are
+        // older than everything the phase's barrier waits for, so its counted vmcnt is unchanged.  Always issued, always used
+        // (absent operands read zeros): hipcc's wait insertion keeps count only of unconditional loads.
+        constexpr bool EPI_PF = EPI_PREFETCH && !DIAG && KS == 3;       // (the 1x1 kernels have no registers to spare: 25 spills)
+        [[maybe_unused]] f32x4 pf_bias[NT], pf_r[4];
+        auto epi_prefetch = [&]() {
+            const float* pb = p.bias;
+            const float* pr = p.res1;
+            int prpix = p.res1_pix;
+            asm volatile("" : "+s"(pb), "+s"(pr), "+s"(prpix));
+            const float* zero16 = (const float*)g_conv_zero16;
+            const bool full = (PXT > 1) || (cob + 1) * COT <= mp.cout;      // the epilogue path that uses them
+            const int c4 = lane & 7;
+            const float* b_base = (pb && full) ? pb : zero16;
+            const unsigned b_off = (pb && full) ? 4u * (unsigned)(cob * COT + 4 * c4) : 0u, b_step = (pb && full) ? 128u : 0u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) pf_bias[t] = ldg4(b_base, b_off + (unsigned)t * b_step);
+            const int y = y0 + __builtin_amdgcn_readfirstlane(wave);
+            const bool row_ok = pr && full && !(CONV_EXP & 32) && y < H, x_in = x0 + CONV_TW <= W;
+            const float* r1_base = row_ok ? pr : zero16;
+            const unsigned off0 = 4u * (unsigned)((y * W + x0 + (lane >> 3)) * prpix + cob * COT + 4 * c4), ustride = 32u * (unsigned)prpix;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = row_ok && (x_in || x0 + (lane >> 3) + 8 * i < W);
+                pf_r[i] = ldg4(r1_base, ok ? off0 + (unsigned)i * ustride : 0u);
+            }
+        };
+        auto chunk_body = [&](const int chunk) __attribute__((always_inline)) {
           bool pend2 = false;                               // phase c+2 exists (decided at the barrier)
           auto phase = [&](auto rows_tag) {
             constexpr int R = decltype(rows_tag)::value;    // rows of this wave that get MFMAs
@@ -459,6 +491,13 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             if (chunk == 0 && tile == (int)blockIdx.x) stamp(stamps_on, 2);
             pend = pend2;
             buf ^= 1;
+        };
+        if (EPI_PF) {
+            for (int chunk = 0; chunk + 1 < mp.nchunk; ++chunk) chunk_body(chunk);
+            epi_prefetch();
+            chunk_body(mp.nchunk - 1);
+        } else {
+            for (int chunk = 0; chunk < mp.nchunk; ++chunk) chunk_body(chunk);
         }
         if (tile == (int)blockIdx.x) stamp(stamps_on, 3);
 
@@ -517,7 +556,10 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             const unsigned b_off = e_bias ? 4u * (unsigned)(cob * COT + 4 * c4) : 0u, b_step = e_bias ? 128u : 0u;
             f32x4 bias4[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bias4[t] = (DIAG && (dbg_all & 512)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ldg4(b_base, b_off + (unsigned)t * b_step);   // (512: timing experiment without the bias load)
+            for (int t = 0; t < NT; ++t) {
+                if (EPI_PF) bias4[t] = pf_bias[t];
+                else bias4[t] = (DIAG && (dbg_all & 512)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ldg4(b_base, b_off + (unsigned)t * b_step);   // (512: timing experiment without the bias load)
+            }
             const float* r1_base = (e_r1 && !(CONV_EXP & 32)) ? e_r1 : zero16;
             f32x4 rr[2][4];
             auto load_r1 = [&](int r, int t, f32x4 (&dst)[4]) {
@@ -532,7 +574,10 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                     dst[i] = ldg4(r1_base, ok ? off0 + (unsigned)i * ustride : 0u);
                 }
             };
-            load_r1(0, 0, rr[0]);
+            if (EPI_PF) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rr[0][i] = pf_r[i];
+            } else load_r1(0, 0, rr[0]);
 #pragma unroll
             for (int r = 0; r < PXT; ++r) {
                 const int y = y0 + wave_s + CONV_TH * r;
@@ -615,6 +660,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 }
             }
         } else if constexpr (PXT == 1) {
+        if (EPI_PF) asm volatile("" :: "v"(pf_bias[0]), "v"(pf_bias[NT - 1]), "v"(pf_r[0]), "v"(pf_r[1]), "v"(pf_r[2]), "v"(pf_r[3]));   // (zeros on this path; used on every path)
 #pragma unroll
         for (int r = 0; r < PXT; ++r) {
         const int y = y0 + wave + CONV_TH * r;
