@@ -803,6 +803,10 @@ class HipEngine:
                     evs.append((e0, e1, til))
                 evs[-1][1].synchronize()
                 best = min(evs, key=lambda e: e[0].elapsed_time(e[1]))[2]
+                if os.environ.get("SAVSR_HR_PRINT_PLANS"):     # diagnostics: what every feasible plan measured (us per launch)
+                    for e0, e1, t in evs:
+                        print(f"[hr plan] {h}x{w} x{scale}: variant {t.variant} tile {t.tile_rows} x {32 * t.tile_cols32} window {t.lr_rows} x {t.lr_cols}: "
+                              f"{1e3 * e0.elapsed_time(e1) / 3:.1f} us", flush=True)
                 ax["tiling_tail"] = best
                 self._hr_choice[ckey] = (best.variant, best.tile_rows, best.tile_cols32)
                 self._hr_choice[skey] = (self._hr_choice[ckey], h, w)
