@@ -247,21 +247,46 @@ def pad_spatial(x: Tensor, multiple: int = 2) -> Tensor:
     return x.view(n, t, c, h + ph, w + pw)
 
 
+def frame_sample(frames: Tensor, num_frame: int, interval: int):
+    """SAVSR.frame_sample, savsr_arch.py:638-659: (past -> future sub-sequence, future -> past sub-sequence) of [b, t, ...]; the
+    method's own centre index is num_frame // 2 (:642), both sub-sequences hold that frame."""
+    if interval == 0:
+        return frames, frames
+    c = num_frame // 2
+    index = list(range(num_frame))
+    if c % 2 == 0:
+        fwd = index[1::interval + 1]                                               # :646-648
+        fwd.insert(c // 2, c)
+        bwd = index[::interval + 1]
+    else:
+        fwd = index[::interval + 1]                                                # :650-655
+        fwd.insert(c // 2 + 1, c)
+        bwd = index[1::interval + 1]
+        if len(fwd) != len(bwd):
+            bwd.append(fwd[-1])
+            bwd.insert(0, fwd[0])
+    return frames[:, fwd], frames[:, bwd]
+
+
 def forward(sd: SD, lq: Tensor, scale: Sequence[float], cfg: dict | None = None,
             taps: dict | None = None) -> Tensor:
-    """savsr_arch.py:692-742 for interval == 0 (the only configuration the test YAMLs use).
+    """savsr_arch.py:692-742 (interval == 0 is what the test YAMLs use; frame sampling, :638-659, is restated too).
 
     `taps`, when given, is filled with named intermediate tensors for stage-level parity tests."""
     c = dict(DEFAULT_CFG)
     c.update(cfg or {})
-    assert c["interval"] == 0, "oracle covers interval == 0 (options/test/SAVSR/*.yml)"
     nf, t = c["num_feat"], c["num_frame"]
     center = t // 2 if c["center_frame_idx"] is None else c["center_frame_idx"]
-    iter_win, sw, fw = t, c["slid_win"], c["fusion_win"]
+    sw, fw = c["slid_win"], c["fusion_win"]
+    if c["interval"] == 0:                                                          # :597-604
+        iter_win = t
+    else:
+        iter_win = center + 1 if center % 2 == 0 else center + 2
     b, _, _, h_in, w_in = lq.shape
     H, W = get_hw(h_in, w_in, scale)
     x_center = lq[:, center].contiguous()
     x = pad_spatial(lq)
+    x_f, x_b = frame_sample(x, t, c["interval"])                                    # :699
     hp, wp = x.shape[-2:]
     ht_b = torch.zeros(b, nf, hp, wp)
     ht_f = torch.zeros(b, nf, hp, wp)
@@ -269,10 +294,10 @@ def forward(sd: SD, lq: Tensor, scale: Sequence[float], cfg: dict | None = None,
     steps = iter_win - sw + 1
     for idx in range(steps):                                                        # :708-719
         cur = iter_win - 1 - sw // 2 - idx
-        ht_b = window_unit_l1(sd, "f2p_win", x[:, cur - sw // 2: cur + sw // 2 + 1], ht_b, scale, c["w1_num_block"])
+        ht_b = window_unit_l1(sd, "f2p_win", x_b[:, cur - sw // 2: cur + sw // 2 + 1], ht_b, scale, c["w1_num_block"])
         lb.insert(0, ht_b)
         cur = idx + sw // 2
-        ht_f = window_unit_l1(sd, "p2f_win", x[:, cur - sw // 2: cur + sw // 2 + 1], ht_f, scale, c["w1_num_block"])
+        ht_f = window_unit_l1(sd, "p2f_win", x_f[:, cur - sw // 2: cur + sw // 2 + 1], ht_f, scale, c["w1_num_block"])
         lf.append(ht_f)
     feats = [torch.cat([lb[i], lf[i]], dim=1) for i in range(steps)]               # :721
     n_l2 = (iter_win - fw + 1) // 2

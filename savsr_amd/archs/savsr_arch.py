@@ -152,6 +152,35 @@ class ResidualGroup(_Holder):
         self.conv = nn.Conv2d(nf, nf, 3, 1, 1)
 
 
+def iteration_window(num_frame: int, interval: int, center_frame_idx: int) -> int:
+    """Frames each propagation direction iterates over (savsr_arch.py:597-604): all of them without frame sampling,
+    center + 1 / + 2 (even / odd centre index) with it."""
+    if interval == 0:
+        return num_frame
+    return center_frame_idx + 1 if center_frame_idx % 2 == 0 else center_frame_idx + 2
+
+
+def frame_sample_indices(num_frame: int, interval: int):
+    """SAVSR.frame_sample (savsr_arch.py:638-659) as index lists: (past -> future frames, future -> past frames).  Both hold
+    the centre frame (num_frame // 2: the method computes its own, whatever center_frame_idx the module was given)."""
+    index = list(range(num_frame))
+    if interval == 0:
+        return index, index
+    c = num_frame // 2
+    if c % 2 == 0:
+        fwd = index[1::interval + 1]
+        fwd.insert(c // 2, c)
+        bwd = index[::interval + 1]
+    else:
+        fwd = index[::interval + 1]
+        fwd.insert(c // 2 + 1, c)
+        bwd = index[1::interval + 1]
+        if len(fwd) != len(bwd):
+            bwd.append(fwd[-1])
+            bwd.insert(0, fwd[0])
+    return fwd, bwd
+
+
 @ARCH_REGISTRY.register()
 class SAVSR(nn.Module):
     def __init__(self, num_in_ch=3, num_feat=64, num_frame=7, slid_win=3, fusion_win=5, interval=0, w1_num_block=4,
@@ -161,12 +190,18 @@ class SAVSR(nn.Module):
                         fusion_win=fusion_win, interval=interval, w1_num_block=w1_num_block, w2_num_block=w2_num_block,
                         n_resgroups=n_resgroups, n_resblocks=n_resblocks, downsample_scale=downsample_scale,
                         center_frame_idx=center_frame_idx)
-        if interval != 0:
-            raise NotImplementedError("only interval == 0 (the shipped test/train configs) is implemented")
         self.scale: Tuple[float, float] = (4, 4)
         self.center_frame_idx = num_frame // 2 if center_frame_idx is None else center_frame_idx
         self.num_frame, self.num_feat = num_frame, num_feat
-        iter_win = num_frame
+        iter_win = iteration_window(num_frame, interval, self.center_frame_idx)
+        self.iter_win, self.interval = iter_win, interval
+        if iter_win < slid_win:
+            raise ValueError("num_frame / interval leave fewer frames than the sliding window")
+        if (iter_win - fusion_win + 1) // 2 > 1:
+            # two pyramid levels: the reference constructs them (:616-618) but its forward fails (WindowUnit_l2 :488 reads
+            # win_size inputs, the level above returns win_size - fusion_win + 1) -- nothing to be a drop-in for
+            raise ValueError("more than one pyramid level (num_frame - fusion_win + 1 >= 4 without frame sampling): "
+                             "the reference's own forward raises an IndexError for this configuration")
         self.f2p_win = WindowUnit_l1(num_in_ch, num_feat, slid_win, w1_num_block)
         self.p2f_win = WindowUnit_l1(num_in_ch, num_feat, slid_win, w1_num_block)
         self.h_win = _seq([WindowUnit_l2(num_feat, (iter_win - slid_win + 1) - 2 * i, fusion_win, w2_num_block)

@@ -325,8 +325,14 @@ class HipEngine:
                 else:
                     self._add_conv(sd, b + ".conv1")
             self._add_conv(sd, d + ".merge")
-        steps = cfg["num_frame"] - cfg["slid_win"] + 1
-        self.n_l2 = (cfg["num_frame"] - cfg["fusion_win"] + 1) // 2
+        from .archs.savsr_arch import frame_sample_indices, iteration_window
+        center = cfg["num_frame"] // 2 if cfg["center_frame_idx"] is None else cfg["center_frame_idx"]
+        self.iter_win = iteration_window(cfg["num_frame"], cfg["interval"], center)      # frames per propagation direction (:597-604)
+        self.fwd_idx, self.bwd_idx = frame_sample_indices(cfg["num_frame"], cfg["interval"])   # frame_sample (:638-659)
+        if cfg["interval"] != 0 and (len(self.fwd_idx) < self.iter_win or len(self.bwd_idx) < self.iter_win):
+            raise ValueError("num_frame / interval: the sampled frame lists are shorter than the iteration window")
+        steps = self.iter_win - cfg["slid_win"] + 1
+        self.n_l2 = (self.iter_win - cfg["fusion_win"] + 1) // 2
         for i in range(self.n_l2):
             u = f"h_win.{i}"
             for j in range(steps - 2 * i):
@@ -368,6 +374,7 @@ class HipEngine:
         e.lib, e.dev, e.cfg, e.nf = self.lib, self.dev, self.cfg, self.nf
         e.pw, e.se, e._keep = self.pw, self.se, self._keep
         e.satu_t, e.satu_w, e.tail_w, e.tail_b, e.gamma, e.n_l2 = self.satu_t, self.satu_w, self.tail_w, self.tail_b, self.gamma, self.n_l2
+        e.iter_win, e.fwd_idx, e.bwd_idx = self.iter_win, self.fwd_idx, self.bwd_idx
         e.satu_tail_t, e.satu_w_tail = self.satu_tail_t, self.satu_w_tail
         e.osc = {}
         for k, ent in self.osc.items():
@@ -836,15 +843,31 @@ class HipEngine:
         """Everything up to the SATU inputs (savsr_arch.py:692-734).  lq: [T, 3, h, w] on device."""
         cfg, nf = self.cfg, self.nf
         T, cin, h_in, w_in = lq.shape
-        assert T == cfg["num_frame"] and cin == cfg["num_in_ch"] == 3 and cfg["interval"] == 0
+        assert T == cfg["num_frame"] and cin == cfg["num_in_ch"] == 3
         if h_in < 2 or w_in < 2:
             raise ValueError("SAVSR needs h, w >= 2")
         hp, wp = h_in + (h_in & 1), w_in + (w_in & 1)              # pad_spatial to even (savsr_arch.py:670-690)
         st = self._stream()
-        wins = self.buf("windows", T - 2, hp, wp, 16)
-        _lib.check(self.lib.savsr_pack_windows(lq.data_ptr(), wins.data_ptr(), T, h_in, w_in, hp, wp, st), "savsr_pack_windows")
-        win = lambda t: Src(wins, 16, 16, 0, float_off=(t - 1) * hp * wp * 16)
         sw, fw = cfg["slid_win"], cfg["fusion_win"]
+        if cfg["interval"] == 0:
+            wins = self.buf("windows", T - 2, hp, wp, 16)
+            _lib.check(self.lib.savsr_pack_windows(lq.data_ptr(), wins.data_ptr(), T, h_in, w_in, hp, wp, st), "savsr_pack_windows")
+            win_b = win_f = lambda t: Src(wins, 16, 16, 0, float_off=(t - 1) * hp * wp * 16)
+            T = self.iter_win
+        else:
+            # frame_sample (:638-659, :699): each direction walks its own sub-sequence of the clip -- gathered (a device copy of
+            # iter_win frames) and packed into its own window buffer
+            T = self.iter_win
+            packs = []
+            for tag, idx in (("f", self.fwd_idx), ("b", self.bwd_idx)):
+                sel = self.buf("frames_" + tag, T, 3, h_in, w_in)
+                for k, fi in enumerate(idx[:T]):
+                    sel[k].copy_(lq[fi])
+                wb = self.buf("windows_" + tag, T - 2, hp, wp, 16)
+                _lib.check(self.lib.savsr_pack_windows(sel.data_ptr(), wb.data_ptr(), T, h_in, w_in, hp, wp, st), "savsr_pack_windows")
+                packs.append(wb)
+            win_f = lambda t, wb=packs[0]: Src(wb, 16, 16, 0, float_off=(t - 1) * hp * wp * 16)
+            win_b = lambda t, wb=packs[1]: Src(wb, 16, 16, 0, float_off=(t - 1) * hp * wp * 16)
         steps = T - sw + 1
         zero = self.buf("zero", hp, wp, nf)
         zero.zero_()          # hidden state restarts from zero every window (savsr_arch.py:705-706)
@@ -852,8 +875,8 @@ class HipEngine:
         hpair = [self.buf(f"hpair{i}", hp, wp, 2 * nf) for i in range(steps)]   # cat(f2p[i], p2f[i]) of :721, written in place
         for idx in range(steps):                                                    # :708-719, both directions per launch
             cur_b, cur_f = T - 1 - sw // 2 - idx, idx + sw // 2
-            hb, hf = self.windows_l1([("f2p_win", win(cur_b), hb, self.full(hpair[steps - 1 - idx], nf, 0), "f2p"),
-                                      ("p2f_win", win(cur_f), hf, self.full(hpair[idx], nf, nf), "p2f")], hp, wp, scale)
+            hb, hf = self.windows_l1([("f2p_win", win_b(cur_b), hb, self.full(hpair[steps - 1 - idx], nf, 0), "f2p"),
+                                      ("p2f_win", win_f(cur_f), hf, self.full(hpair[idx], nf, nf), "p2f")], hp, wp, scale)
         # pyramid fusion (:616-618, :485-501, :721-722)
         level: List[Src] = [self.full(t) for t in hpair]
         for i in range(self.n_l2):

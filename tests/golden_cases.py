@@ -22,3 +22,25 @@ GRID_SIZES = [(180, 320), (135, 239), (144, 176)]
 
 def rnd(shape, seed, scale=1.0):
     return torch.from_numpy((scale * np.random.RandomState(seed).standard_normal(shape)).astype(np.float32))
+
+
+# Constructor configurations beside the shipped one (savsr_arch.py:576-604,638-659): frame sampling and other clip lengths.
+# (name, ctor kwargs, h, w, scale); goldens: tools/gen_golden_configs.py -> tests/golden/config_outputs.npz
+CONFIG_CASES = [
+    ("t7_i1", dict(num_frame=7, interval=1), 12, 14, (2.5, 3.0)),     # odd centre index: iter_win 5, no pyramid level
+    ("t9_i1", dict(num_frame=9, interval=1), 10, 12, (4, 4)),         # even centre index: the other branch of frame_sample
+    ("t5_i0", dict(num_frame=5), 11, 13, (3.5, 2)),                   # 5 frames, no pyramid level, odd LR size
+    # (num_frame = 9 without frame sampling has two pyramid levels: the REFERENCE's forward fails there -- WindowUnit_l2 :488 indexes
+    #  five inputs, level one returns three -- so there is nothing to match; this repo's constructor rejects it)
+]
+
+
+def manifest_hash(manifest) -> str:
+    """sha256 over the (name, shape, dtype) entries of a state_dict manifest (synth.manifest_of), in order."""
+    import hashlib
+    m = hashlib.sha256()
+    for k, shape, dtype in manifest:
+        m.update(k.encode())
+        m.update(repr(tuple(int(v) for v in shape)).encode())
+        m.update(str(dtype).encode())
+    return m.hexdigest()
