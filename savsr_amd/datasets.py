@@ -202,10 +202,8 @@ class ASVideoTestDataset(VideoTestDataset):
         super().__init__(opt)
         if "downsampling_scale" in self.opt.keys():
             self.opt["scale"] = self.opt["downsampling_scale"]
-        mode = self.opt.get("downsampling_mode", "torch")
-        if self._synthesise() and mode != "torch":
-            raise NotImplementedError(f"downsampling_mode '{mode}': only 'torch' (bicubic, antialias) is implemented -- the mode of "
-                                      "every shipped test YAML (data_util.py:405-412)")
+        if self._synthesise() and self.opt.get("downsampling_mode", "torch") not in ("torch", "core"):
+            raise ValueError(f"downsampling_mode '{self.opt['downsampling_mode']}' (data_util.py:408-412 knows 'torch' and 'core')")
 
     def _synthesise(self) -> bool:
         # cache_data=True synthesises unconditionally (video_test_dataset.py:303-306); otherwise the YAML switch decides
@@ -221,7 +219,7 @@ class ASVideoTestDataset(VideoTestDataset):
         # cropped only when the YAML carries `use_arbitrary_scale_downsampling` (:101-110)
         crop = scale if (not self.cache_data or self.as_down) else None
         gt = self._read(self.imgs_gt[folder], folder, crop)
-        lq = arbitrary_scale_downsample(gt, scale) if self._synthesise() else gt     # :308-312
+        lq = arbitrary_scale_downsample(gt, scale, self.opt.get("downsampling_mode", "torch")) if self._synthesise() else gt     # :308-312
         return {"gt": gt, "lq": lq}
 
 

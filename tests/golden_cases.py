@@ -44,3 +44,15 @@ def manifest_hash(manifest) -> str:
         m.update(repr(tuple(int(v) for v in shape)).encode())
         m.update(str(dtype).encode())
     return m.hexdigest()
+
+
+# `downsampling_mode: core` (lbasicsr/data/core.py::imresize, data_util.py:411-412): (name, channels, h, w, (sh, sw)); the output
+# size is data_util.py's (round(h / sh), round(w / sw)).  Goldens: tools/gen_golden_core.py -> tests/golden/core_resize.npz
+CORE_RESIZE_CASES = [
+    ("x4", 3, 40, 52, (4, 4)), ("x1p5_4", 3, 42, 48, (1.5, 4)), ("x3p5_2", 2, 35, 44, (3.5, 2)), ("x3p7", 3, 37, 53, (3.7, 3.7)),
+    ("x1p1", 1, 33, 44, (1.1, 1.1)), ("x2p95_3p75", 3, 59, 75, (2.95, 3.75)), ("id_h", 2, 20, 36, (1, 3)), ("small", 1, 9, 11, (4, 4)),
+]
+
+
+def core_input(c, h, w):
+    return torch.from_numpy(np.random.RandomState(c * 1000 + h * 10 + w).uniform(0, 1, (c, h, w)).astype(np.float32))
