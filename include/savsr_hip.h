@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 21
+#define SAVSR_ABI_VERSION 22
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -292,6 +292,11 @@ int savsr_tail_residual(const float* feat, int64_t feat_plane, const float* tail
 int savsr_metrics_blocks(int H, int W, int crop_border);       /* < 0: the cropped image is smaller than 11 x 11 */
 int savsr_metrics_psnr_ssim_y(const float* sr, int64_t sr_plane, const float* gt, int64_t gt_plane, int H, int W,
                               int crop_border, double* partial, double* out, void* stream);
+/* The same with `test_y_channel` as the YAML's metric option (psnr_ssim.py:12,85): != 0 is savsr_metrics_psnr_ssim_y; 0 takes the
+ * three colour planes of the quantised image -- PSNR from the mean squared difference over H x W x 3, SSIM as the mean of the
+ * planes' SSIM (psnr_ssim.py:115-129) -- and needs partial[3 * savsr_metrics_blocks(..) * 2]. */
+int savsr_metrics_psnr_ssim(const float* sr, int64_t sr_plane, const float* gt, int64_t gt_plane, int H, int W, int crop_border,
+                            int test_y_channel, double* partial, double* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * One axis of the anti-aliased bicubic resize behind the reference's LR synthesis (SURVEY section 8, row f2 -- the step

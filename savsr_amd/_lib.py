@@ -18,7 +18,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 21
+ABI_VERSION = 22
 CONV_DIRECT, CONV_DIRECT_THROUGHPUT = 0, 2
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
@@ -114,6 +114,7 @@ SIGNATURES = {
     "savsr_resize_aa_axis": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int, fptr, C.c_void_p]),
     "savsr_metrics_blocks": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "savsr_metrics_psnr_ssim_y": (C.c_int, [fptr, C.c_int64, fptr, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "savsr_metrics_psnr_ssim": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "savsr_tail_residual": (C.c_int, [fptr, C.c_int64, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
 }
 

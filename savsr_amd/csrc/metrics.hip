@@ -36,12 +36,21 @@ __device__ __forceinline__ double y_of(const float* __restrict__ img, long long 
     return (double)(y32 * 255.0f);
 }
 
+// test_y_channel: false -- the metric of every colour plane of the quantised image (calculate_psnr: the mean over H x W x 3 of the
+// squared uint8 differences; calculate_ssim: the mean of the three planes' SSIM, psnr_ssim.py:115-129): plane ch of tensor2img's output
+__device__ __forceinline__ double level_of(const float* __restrict__ img, long long plane, long long idx, int ch) {
+    float v = img[ch * plane + idx];
+    v = fminf(fmaxf(v, 0.f), 1.f) * 255.0f;
+    return (double)rintf(v);
+}
+
 struct MetricsParams {
     const float* sr;
     const float* gt;
     long long sr_plane, gt_plane;
     int H, W, crop;
-    double* partial;                   // [blocks][2] = sum of SSIM values, sum of squared Y differences
+    int y_channel;                     // 1: BT.601 luma (one plane of blocks); 0: the three colour planes (blockIdx.z)
+    double* partial;                   // [planes][blocks][2] = sum of SSIM values, sum of squared differences
 };
 
 __global__ __launch_bounds__(256) void metrics_y_kernel(const MetricsParams p) {
@@ -59,8 +68,8 @@ __global__ __launch_bounds__(256) void metrics_y_kernel(const MetricsParams p) {
         double a = 0.0, b = 0.0;
         if (y < Hc && x < Wc) {
             const long long idx = (long long)(y + p.crop) * p.W + (x + p.crop);
-            a = y_of(p.sr, p.sr_plane, idx);
-            b = y_of(p.gt, p.gt_plane, idx);
+            a = p.y_channel ? y_of(p.sr, p.sr_plane, idx) : level_of(p.sr, p.sr_plane, idx, blockIdx.z);
+            b = p.y_channel ? y_of(p.gt, p.gt_plane, idx) : level_of(p.gt, p.gt_plane, idx, blockIdx.z);
             // PSNR: every cropped pixel is owned by the tile whose 16 x 16 core contains it; the last tile row / column
             // also owns the 10-pixel rim beyond the SSIM map
             const bool own_r = r < MT || blockIdx.y == gridDim.y - 1, own_c = c < MT || blockIdx.x == gridDim.x - 1;
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(256) void metrics_y_kernel(const MetricsParams p) {
         __syncthreads();
     }
     if (tid == 0) {
-        const long long b = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long long b = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         p.partial[2 * b] = red[0][0];
         p.partial[2 * b + 1] = red[1][0];
     }
@@ -151,20 +160,29 @@ extern "C" int savsr_metrics_blocks(int H, int W, int crop_border) {
     return ((ow + MT - 1) / MT) * ((oh + MT - 1) / MT);
 }
 
-extern "C" int savsr_metrics_psnr_ssim_y(const float* sr, int64_t sr_plane, const float* gt, int64_t gt_plane, int H, int W, int crop_border,
-                                         double* partial, double* out, void* stream) {
+extern "C" int savsr_metrics_psnr_ssim(const float* sr, int64_t sr_plane, const float* gt, int64_t gt_plane, int H, int W, int crop_border,
+                                       int test_y_channel, double* partial, double* out, void* stream) {
     if (!sr || !gt || !partial || !out) return fail_arg("metrics: null pointer");
+    const int planes = test_y_channel ? 1 : 3;
     const int nblk = savsr_metrics_blocks(H, W, crop_border);
     if (nblk < 1) return fail_arg("metrics: the cropped image must be at least 11 x 11");
     if (sr_plane < (int64_t)H * W || gt_plane < (int64_t)H * W) return fail_arg("metrics: plane pitch < H*W");
     const int Hc = H - 2 * crop_border, Wc = W - 2 * crop_border;
     MetricsParams p;
     p.sr = sr; p.gt = gt; p.sr_plane = sr_plane; p.gt_plane = gt_plane; p.H = H; p.W = W; p.crop = crop_border; p.partial = partial;
-    dim3 grid((Wc - 10 + MT - 1) / MT, (Hc - 10 + MT - 1) / MT);
+    p.y_channel = test_y_channel ? 1 : 0;
+    dim3 grid((Wc - 10 + MT - 1) / MT, (Hc - 10 + MT - 1) / MT, planes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(metrics_y_kernel, grid, dim3(256), 0, st, p);
     int rc = check_launch("metrics_y_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, (double)Hc * Wc, (double)(Hc - 10) * (Wc - 10), out);
+    // (three planes: the pooled means ARE the reference's -- one mean over H x W x 3 for the PSNR, the mean of three equally sized maps' means for the SSIM)
+    hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk * planes, (double)Hc * Wc * planes,
+                       (double)(Hc - 10) * (Wc - 10) * planes, out);
     return check_launch("metrics_finalize_kernel");
+}
+
+extern "C" int savsr_metrics_psnr_ssim_y(const float* sr, int64_t sr_plane, const float* gt, int64_t gt_plane, int H, int W, int crop_border,
+                                         double* partial, double* out, void* stream) {
+    return savsr_metrics_psnr_ssim(sr, sr_plane, gt, gt_plane, H, W, crop_border, 1, partial, out, stream);
 }

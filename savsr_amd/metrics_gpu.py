@@ -13,10 +13,11 @@ import torch
 from . import _lib
 
 
-def psnr_ssim_y(sr: torch.Tensor, gt: torch.Tensor, crop_border: int = 0, out: torch.Tensor = None) -> torch.Tensor:
+def psnr_ssim_y(sr: torch.Tensor, gt: torch.Tensor, crop_border: int = 0, out: torch.Tensor = None, test_y_channel: bool = True) -> torch.Tensor:
     """sr, gt: [3, H, W] (or [1, 3, H, W]) fp32 RGB on the same GPU, values nominally in [0, 1]
     (clamped and quantised to uint8 levels exactly as tensor2img does).  Returns a float64 device
-    tensor [2] = (PSNR-Y, SSIM-Y); PSNR is inf for identical images.  Asynchronous on the current stream."""
+    tensor [2] = (PSNR-Y, SSIM-Y); PSNR is inf for identical images.  Asynchronous on the current stream.
+    test_y_channel=False: the metrics over the three colour planes instead of the luma (the YAML option of psnr_ssim.py:12,85)."""
     if sr.dim() == 4:
         sr = sr[0]
     if gt.dim() == 4:
@@ -32,9 +33,9 @@ def psnr_ssim_y(sr: torch.Tensor, gt: torch.Tensor, crop_border: int = 0, out: t
     nblk = lib.savsr_metrics_blocks(H, W, crop_border)
     if nblk < 1:
         raise ValueError("the cropped image must be at least 11 x 11")
-    partial = torch.empty(nblk * 2, dtype=torch.float64, device=sr.device)
+    partial = torch.empty(nblk * 2 * (1 if test_y_channel else 3), dtype=torch.float64, device=sr.device)
     if out is None:
         out = torch.empty(2, dtype=torch.float64, device=sr.device)
-    _lib.check(lib.savsr_metrics_psnr_ssim_y(sr.data_ptr(), H * W, gt.data_ptr(), H * W, H, W, crop_border, partial.data_ptr(),
-                                             out.data_ptr(), torch.cuda.current_stream(sr.device).cuda_stream), "savsr_metrics_psnr_ssim_y")
+    _lib.check(lib.savsr_metrics_psnr_ssim(sr.data_ptr(), H * W, gt.data_ptr(), H * W, H, W, crop_border, int(bool(test_y_channel)), partial.data_ptr(),
+                                           out.data_ptr(), torch.cuda.current_stream(sr.device).cuda_stream), "savsr_metrics_psnr_ssim")
     return out

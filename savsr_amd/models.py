@@ -31,22 +31,22 @@ from .registry import METRIC_REGISTRY, MODEL_REGISTRY
 from .resize_gpu import resize_bicubic_aa
 
 
-def _gpu_metric_plan(metrics_opt) -> Optional[int]:
-    """The fused GPU kernel produces (PSNR-Y, SSIM-Y) of one crop_border in one pass.  Returns that crop_border when
-    every requested metric is one of the two with test_y_channel=True and a common crop_border (every shipped YAML),
-    else raises: there is deliberately no host fallback inside the product path."""
-    crop = None
+def _gpu_metric_plan(metrics_opt):
+    """The fused GPU kernel produces (PSNR, SSIM) of one crop_border and one test_y_channel setting in one pass.  Returns
+    (crop_border, test_y_channel) when every requested metric is calculate_psnr / calculate_ssim with common settings (every
+    shipped YAML: test_y_channel true), else raises: there is deliberately no host fallback inside the product path."""
+    crop = ych = None
     for name, m in metrics_opt.items():
-        if m["type"] not in ("calculate_psnr", "calculate_ssim") or not m.get("test_y_channel", False) or m.get("input_order", "HWC") != "HWC":
-            raise NotImplementedError(f"metric '{name}' ({dict(m)}): the GPU metric kernel implements calculate_psnr / calculate_ssim with "
-                                      "test_y_channel: true (the metrics of options/test/SAVSR/*.yml)")
+        if m["type"] not in ("calculate_psnr", "calculate_ssim") or m.get("input_order", "HWC") != "HWC":
+            raise NotImplementedError(f"metric '{name}' ({dict(m)}): the GPU metric kernel implements calculate_psnr / calculate_ssim "
+                                      "on HWC images (the metrics of options/test/SAVSR/*.yml)")
         if m["type"] not in METRIC_REGISTRY:
             raise KeyError(m["type"])
-        c = int(m.get("crop_border", 0))
-        if crop is not None and c != crop:
-            raise NotImplementedError("metrics with different crop_border values in one run are not supported by the fused kernel")
-        crop = c
-    return crop
+        c, y = int(m.get("crop_border", 0)), bool(m.get("test_y_channel", False))
+        if (crop is not None and c != crop) or (ych is not None and y != ych):
+            raise NotImplementedError("metrics with different crop_border / test_y_channel values in one run are not supported by the fused kernel")
+        crop, ych = c, y
+    return crop, ych
 
 
 class BaseModel:
@@ -127,7 +127,7 @@ class VideoBaseModel(BaseModel):
             mine = frame_indices(n, rank, world)
             owners = None
         names = list(metrics_opt.keys()) if with_metrics else []
-        crop = _gpu_metric_plan(metrics_opt) if with_metrics else None
+        crop, ych = _gpu_metric_plan(metrics_opt) if with_metrics else (None, True)
         rows = torch.zeros(len(mine), 2, dtype=torch.float64, device=self.device)
         # Frames are independent units (the hidden state restarts per window, savsr_arch.py:705-706): instead of one frame at a
         # time (video_base_model.py:51-53) this rank's frames go through the network `group` at a time, each on its own HIP
@@ -186,7 +186,7 @@ class VideoBaseModel(BaseModel):
                                                self.opt["name"], self.opt["val"].get("suffix"))
                     sio.imwrite_async(tensor2img(vis["result"]), path)
                 if with_metrics:
-                    psnr_ssim_y(vis["result"][0], vis["gt"][0], crop, out=rows[k0 + j])
+                    psnr_ssim_y(vis["result"][0], vis["gt"][0], crop, out=rows[k0 + j], test_y_channel=ych)
                 del self.lq, self.output, self.gt
             if timing:
                 e1.record()

@@ -32,6 +32,23 @@ def test_psnr_ssim_y_vs_numpy(H, W, crop):
     assert abs(float(got[1]) - s_ref) <= 1e-9, (float(got[1]), s_ref)
 
 
+@pytest.mark.parametrize("H,W,crop", [(64, 80, 0), (37, 53, 3), (11, 11, 0), (180, 320, 0)])
+def test_psnr_ssim_rgb_vs_numpy(H, W, crop):
+    """test_y_channel: false (psnr_ssim.py:12,85): the mean squared difference over H x W x 3 and the mean of the three colour
+    planes' SSIM, against the numpy restatement on the quantised BGR images."""
+    from savsr_amd.metrics_gpu import psnr_ssim_y
+    g = np.random.RandomState(H * 5 + W)
+    gt = synth.synth_gt(3, H, W, seed=H + 2 * W)
+    sr = gt + torch.from_numpy(g.normal(0, 0.05, (3, H, W)).astype(np.float32))
+    a, b = tensor2img(sr), tensor2img(gt)
+    p_ref, s_ref = calculate_psnr(a, b, crop, test_y_channel=False), calculate_ssim(a, b, crop, test_y_channel=False)
+    got = psnr_ssim_y(sr.cuda(), gt.cuda(), crop, test_y_channel=False).cpu()
+    assert abs(float(got[0]) - p_ref) <= 1e-9, (float(got[0]), p_ref)
+    assert abs(float(got[1]) - s_ref) <= 1e-9, (float(got[1]), s_ref)
+    y = psnr_ssim_y(sr.cuda(), gt.cuda(), crop).cpu()
+    assert abs(float(y[0]) - float(got[0])) > 1e-6                   # (not the luma metric)
+
+
 def test_identical_images_and_batch_dim():
     from savsr_amd.metrics_gpu import psnr_ssim_y
     gt = synth.synth_gt(3, 40, 56, seed=3).cuda()

@@ -176,6 +176,27 @@ def test_post_resize_when_output_and_gt_differ(workdir):
     assert float((vis["result"].cpu() - ref).abs().max()) < 2e-6
 
 
+def test_run_test_with_colour_metrics(workdir):
+    """`test_y_channel: false` for both metrics (psnr_ssim.py:12,85): the rows of the GPU kernel against the host restatement on the
+    saved, quantised images."""
+    from savsr_amd.test import run_test
+    opt = _opt(workdir)
+    for m in opt["val"]["metrics"].values():
+        m["test_y_channel"] = False
+    opt["datasets"] = {"test_01": opt["datasets"]["test_01"]}
+    r = run_test(opt)[0]
+    sc = opt["datasets"]["test_01"]["downsampling_scale"]
+    name, (n, H, W) = "city", FOLDERS["city"]
+    Hc, Wc = as_mod_crop_hw(H, W, sc)
+    rows = r["frames"][name]
+    for i in range(n):
+        sr = sio.imread(os.path.join(workdir, "results", opt["name"], "visualization", r["dataset"], name, f"{i:08d}_{opt['name']}.png"))
+        gt = sio.imread(os.path.join(workdir, "GT", name, f"{i:08d}.png"))[:Hc, :Wc]
+        assert abs(M.calculate_psnr(sr, gt, 0, test_y_channel=False) - float(rows[i, 0])) < 1e-4
+        assert abs(M.calculate_ssim(sr, gt, 0, test_y_channel=False) - float(rows[i, 1])) < 1e-6
+        assert abs(M.calculate_psnr(sr, gt, 0, test_y_channel=True) - float(rows[i, 0])) > 1e-3      # not the luma numbers
+
+
 def test_unsupported_metric_config_raises(workdir):
     from savsr_amd.models import build_model
     from savsr_amd.datasets import build_dataset
