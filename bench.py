@@ -90,7 +90,42 @@ def cpu_baseline(sd, threads):
             "sample": f"{n} frame(s) of the workload clip (7x3x180x320, x4 -> 720x1280) through oracle/savsr_oracle.py, {dt:.2f} s"}, out, lq
 
 
-def conv_roofline(eng, dev, iters=20):
+def sysfs_sclk_mhz():
+    """Current shader-clock level the driver reports (pp_dpm_sclk, the line marked '*'); None where sysfs is not readable.  Not the
+    clock a loaded kernel holds (MI355X_MICROARCH.md, DVFS give-back item 6): reported beside the in-kernel probe."""
+    import glob
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for ln in open(f):
+                if "*" in ln:
+                    return int(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
+class ClockProbe:
+    """savsr_clock_probe on a side stream: one wave reads s_memtime / s_memrealtime around `ms` of wall time; launched just before
+    some load is enqueued on the main stream it reports the shader clock the chip holds under that load."""
+
+    def __init__(self, eng, dev):
+        self.lib, self.dev = eng.lib, dev
+        self.stream = torch.cuda.Stream(device=dev)
+        self.buf = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def start(self, ms):
+        self.buf.zero_()
+        torch.cuda.synchronize()
+        rc = self.lib.savsr_clock_probe(self.buf.data_ptr(), int(ms * 1e5), self.stream.cuda_stream)
+        assert rc == 0, rc
+
+    def mhz(self):
+        self.stream.synchronize()
+        c, r = (int(v) for v in self.buf.cpu())
+        return round(100.0 * c / r, 1) if r > 0 else None
+
+
+def conv_roofline(eng, dev, iters=20, probe=None):
     """The kernel that dominates GPU time (conv_bf16x3_kernel, ~85 % of a frame) on its most frequent launch
     geometry: one savsr_conv2d_batch of six 128->64 3x3 convs at 180x320 with bias, LeakyReLU and a residual
     (the ResidualBlock conv2 launches, savsr_arch.py:412-414; 20 of them per frame).  HIP events on the launch
@@ -119,11 +154,20 @@ def conv_roofline(eng, dev, iters=20):
     ev1.record()
     torch.cuda.synchronize()
     sec = ev0.elapsed_time(ev1) / 1e3 / iters
+    clock = None
+    if probe is not None:                                   # the clock the chip holds under this launch, looped (~40 ms)
+        n = max(iters, int(0.04 / sec))
+        probe.start(0.6 * n * sec * 1e3)
+        for _ in range(n):
+            eng.conv_launch(descs)
+        torch.cuda.synchronize()
+        clock = probe.mhz()
     alg = 2.0 * n * cin * cout * 9 * LR_H * LR_W            # fp32-equivalent flops (2 x MACs)
     issued = 3.0 * alg                                      # split-bf16: three bf16 MFMA products per fp32 product
     return {"kernel": "conv_bf16x3_kernel<3,2,2> (6 x conv3x3 128->64 + bias + LeakyReLU + residual, 180x320)", "bound": "mfma",
             "achieved": round(issued / sec / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(issued / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "traffic": None, "algorithmic_flops": alg, "fp32_equivalent_tflops": round(alg / sec / 1e12, 1), "avg_ms": round(1e3 * sec, 4),
+            "clock_mhz_under_launch": clock,
             "note": "achieved counts the bf16 MFMA flops issued (3 per fp32-equivalent product); launch timed solo after the timed region"}
 
 
@@ -154,14 +198,19 @@ def satu_roofline(eng, clip, h, w, scale, in_flight_ms=None):
     t = (parts["satu_lr_us"] + parts["satu_hr_us"]) * 1e-6
     alg = satu_alg_bytes(h, w, H, W)
     achieved = alg / t / 1e9
-    traffic, src = None, None
+    traffic, src, traffic_note = None, None, None
+    lib_hash = eng.lib.savsr_source_hash_satu().decode()
     try:
         tr = json.load(open(TRAFFIC_FILE))
-        traffic, src = tr.get("bytes_per_stage"), tr.get("source")
+        if tr.get("lib_source_hash") == lib_hash:
+            traffic, src = tr.get("bytes_per_stage"), tr.get("source")
+        else:           # PMC bytes of ANOTHER build say nothing about the library that ran: drop them
+            traffic_note = f"profiles/satu_traffic.json was measured on library sources {tr.get('lib_source_hash')}, this run is {lib_hash}: traffic dropped"
     except (OSError, ValueError):
         pass
-    r = {"kernel": "SATU = satu_lr_stream_kernel<NB=1> + satu_hr_kernel<NB=1> (tail-projected form: the 3x3 tail conv's channel contraction is folded in; "
-                   "the phase table is evaluated once per size / scale / weights)",
+    r = {"kernel": "SATU = satu_lr_stream_kernel<NB=1> + satu_hr_kernel<NB=1" + (", row-summed" if eng.satu_q else "") + "> (tail-projected form: the 3x3 tail conv's channel "
+                   "contraction is folded in" + ("; the HR stage also adds the tail's three horizontal taps and writes 9 planes + seams instead of 27 planes" if eng.satu_q else "")
+                   + "; the phase table is evaluated once per size / scale / weights)",
          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
          "traffic": traffic if (h, w, tuple(scale)) == (LR_H, LR_W, SCALE) else None, "traffic_source": src,
          "algorithmic_bytes": alg, "avg_ms": round(1e3 * t, 4), "lr_us": round(parts["satu_lr_us"], 1), "hr_us": round(parts["satu_hr_us"], 1),
@@ -174,6 +223,17 @@ def satu_roofline(eng, clip, h, w, scale, in_flight_ms=None):
          "note": "launches alone on the GPU, each looped on the tensors of a real frame (inputs of 22-29 MB may be served by the 256 MB Infinity "
                  "Cache, as they are in the frame itself, where the previous kernels have just written them)"}
     r["frac_algorithmic"] = r["frac"]
+    r["lib_source_hash"] = lib_hash
+    if traffic_note:
+        r["traffic_note"] = traffic_note
+    # SATU + tail against the bytes of the REFERENCE formulation of savsr_arch.py:315-376 + :738-739: SATU's contract bytes + the tail conv
+    # reading the [64,H,W] map again and writing [3,H,W] + the centre LR frame of the bilinear residual.  Work moved between the HR launch
+    # and the tail launch (the row-summed form) does not change this figure; it does change `frac` (LR + HR only).
+    alg_tail = alg + 4 * (64 + 3) * H * W + 12 * h * w
+    t_all = t + parts["tail_us"] * 1e-6
+    r["satu_tail"] = {"algorithmic_bytes": alg_tail, "us": round(1e6 * t_all, 1), "achieved": round(alg_tail / t_all / 1e9, 1), "unit": "GB/s",
+                      "frac": round(alg_tail / t_all / 1e9 / HBM_PEAK_GBS, 4),
+                      "definition": "(265.42 MB-form SATU bytes + 4 (64 + 3) H W + 12 h w) / (LR + HR + tail launches alone) / 8 TB/s"}
     if r["traffic"]:
         r["moved_gbs"] = round(r["traffic"] / t / 1e9, 1)
         r["moved_frac"] = round(r["traffic"] / t / 1e9 / HBM_PEAK_GBS, 4)
@@ -261,7 +321,12 @@ def run_config2(args, rank, world, dev, dist):
                 lst = [torch.empty(rows.shape, dtype=rows.dtype) for _ in range(world)]
                 dist.all_gather(lst, rows.cpu())
                 gathered.copy_(torch.cat(lst, 0))
-    elapsed = timed(dist, dev, region)
+    # THREE timed regions of exactly K steps each, each bracketed by barrier + synchronize with the MAX over ranks; `value` is the
+    # MEDIAN region's (a lease's shader clock drifts by a few % over seconds; one region cannot tell that from a code change)
+    sclk0 = sysfs_sclk_mhz()
+    regions = [timed(dist, dev, region) for _ in range(max(1, args.regions))]
+    sclk1 = sysfs_sclk_mhz()
+    elapsed = sorted(regions)[len(regions) // 2]
     in_flight = [a.elapsed_time(b) for a, b in eng.satu_events]
     eng.satu_events = None
     if rank != 0:
@@ -272,6 +337,17 @@ def run_config2(args, rank, world, dev, dist):
                      {"frames_per_step": cps, "streams_per_gpu": min(cps, eng.n_streams)})
     line["metric"] = "HR Mpixels/sec (Vid4-shape x4, 7-frame window)"
     line["timed_region_s"] = round(elapsed, 3)
+    vals = sorted(world * args.steps * cps * hr_mpx / e for e in regions)
+    line["value_min"], line["value_median"], line["value_max"] = round(vals[0], 3), round(vals[len(vals) // 2], 3), round(vals[-1], 3)
+    line["region_values"] = [round(world * args.steps * cps * hr_mpx / e, 3) for e in regions]
+    line["regions_note"] = f"{len(regions)} timed regions of {args.steps} steps each, back to back; value = ms_per_step = the median region"
+    probe = ClockProbe(eng, dev)
+    probe.start(2.0)
+    clock = {"idle_probe": probe.mhz(), "sysfs_sclk_before": sclk0, "sysfs_sclk_after": sclk1}
+    probe.start(0.5 * 1e3 * elapsed / args.steps)          # under the frame load: half a step, beside one untimed step
+    step(0, False)
+    torch.cuda.synchronize()
+    clock["under_frame_load"] = probe.mhz()
     allrows = (gathered if dist is not None else rows).cpu()
     line["psnr_y_vs_synthetic_gt"] = round(float(allrows[:, 0].mean()), 4)
     line["ssim_y_vs_synthetic_gt"] = round(float(allrows[:, 1].mean()), 6)
@@ -293,7 +369,11 @@ def run_config2(args, rank, world, dev, dist):
     line["whole_frame_mfma_frac"] = round(3 * 2 * macs / frame_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
     line["whole_frame_note"] = "3 bf16 MFMA products per fp32-equivalent MAC x 2 flop x 1.34 TMAC per frame (SURVEY 8(d) census) / frame time / 2.5 PF"
     line["roofline"] = satu_roofline(eng, clips[0][0], LR_H, LR_W, SCALE, in_flight)
-    line["roofline_conv"] = conv_roofline(eng, dev)
+    line["roofline_conv"] = conv_roofline(eng, dev, probe=probe)
+    clock["under_conv_launch"] = line["roofline_conv"]["clock_mhz_under_launch"]
+    clock["note"] = ("in-kernel shader clock = s_memtime / s_memrealtime x 100 MHz read by one wave on a side stream (savsr_clock_probe) while the named load runs; "
+                     "sysfs_sclk_* = pp_dpm_sclk before / after the timed regions")
+    line["clock_mhz"] = clock
     if world == 1 and not args.no_cpu_baseline:
         threads = effective_cpus()
         cb, ref, lq_c = cpu_baseline(sd, threads)
@@ -558,6 +638,7 @@ def main():
     ap.add_argument("--frames-per-folder", type=int, default=32, help="run_test: frames per synthetic folder (4 folders)")
     ap.add_argument("--save-img", action="store_true", help="run_test: also write every output frame as PNG (val.save_img)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--regions", type=int, default=3, help="config 2: timed regions of K steps each (value = the median region)")
     ap.add_argument("--clips-per-step", type=int, default=18,
                     help="independent clips per step (3 in flight on separate HIP streams; 18 keeps a 20-step timed region at ~3 s)")
     ap.add_argument("--scales", type=str, default="", help="config 3: comma-separated subset, e.g. 1.1,2.5,4")

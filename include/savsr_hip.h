@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 22
+#define SAVSR_ABI_VERSION 23
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -48,6 +48,15 @@ int savsr_abi_version(void);
  * the library, which the launch entry points otherwise do lazily on a kernel's first use.  Optional -- a caller that records
  * the launches into a hipGraph calls it before the capture so that no attribute call falls inside it.  Idempotent, thread-safe. */
 int savsr_prepare_device(void);
+/* First 16 hex digits of the sha256 over the kernel sources, headers and compile flags this library was built from (build.sh):
+ * lets a measurement file name the build it was taken on (profiles/satu_traffic.json; bench.py drops `traffic` when it differs). */
+const char* savsr_source_hash(void);
+const char* savsr_source_hash_satu(void);     /* the same over the SATU + tail kernel sources only (satu.hip, tail.hip, common.hpp, this header) */
+/* Measurement aid (bench.py `clock_mhz`): ONE wave spins until `realtime_ticks` ticks of the 100 MHz s_memrealtime counter have passed
+ * and writes out2 = { s_memtime delta (shader cycles), s_memrealtime delta }: shader clock = out2[0] / out2[1] x 100 MHz
+ * (MI355X_MICROARCH.md, DVFS give-back item 6).  Launched on a side stream beside other work it reads the clock the chip holds
+ * under that load (one wave with s_sleep in its loop; no LDS, co-resides with any workgroup).  realtime_ticks in 1 .. 10^8. */
+int savsr_clock_probe(int64_t* out2, int realtime_ticks, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Feature-map layout: every LR-resolution feature map is CHANNEL-LAST fp32, [h][w][C], addressed
@@ -275,6 +284,18 @@ int savsr_satu_hr_tail(const savsr_satu_weights* wt, const float* lrcat, int h, 
 /* p27: [27] planes of [H][W], p_plane floats apart; center: [3][h][w]; out: [3][H][W] contiguous. */
 int savsr_tail_gather(const float* p27, int64_t p_plane, const float* tail_b, const float* center,
                       int h, int w, int H, int W, float* out, void* stream);
+/* The ROW-SUMMED tail form.  Same stage, with the rows of Wt27 in the order savsr_satu_hr_tail_q wants them -- the three horizontal
+ * taps kx of group g = 3 ky + o at MFMA rows acc_row(3 gi + kx, half), gi = g (half 0) for g < 5, g - 5 (half 1) otherwise, where
+ * acc_row(r, half) = 8 (r / 4) + 4 half + r % 4 -- in every tail-form matrix (LR stage included: savsr_satu_lr_stage_tail with those
+ * weights).  The HR stage adds the three horizontal taps itself and writes q9: [9] planes Q[g] of [H][W] (q_plane floats apart) plus
+ * seam: [H][ceil(W / 32)][2][9] floats (the terms that cross a 32-pixel segment border); savsr_tail_gather_q adds the vertical
+ * taps, the seams, tail_b and the bilinear residual.  Results equal the 27-plane form's up to the summation order of the nine taps. */
+int savsr_satu_hr_tail_q(const savsr_satu_weights* wt, const float* lrcat, int h, int w,
+                         const float* table, int n_uh, int n_uw, const int32_t* idx_h, const int32_t* idx_w, const float* ptab,
+                         const float* gyn, const float* gxn, int H, int W, const savsr_satu_tiling* tiling, int32_t* sched,
+                         float* q9, int64_t q_plane, float* seam, int64_t seam_floats, void* stream);
+int savsr_tail_gather_q(const float* q9, int64_t q_plane, const float* seam, int64_t seam_floats, const float* tail_b, const float* center,
+                        int h, int w, int H, int W, float* out, void* stream);
 
 /* tail conv 3x3 64->3 + bias at HR plus the bilinear residual of the (unpadded) centre frame
  * (savsr_arch.py:738-739).  feat: [64] planes of [H][W], feat_plane floats apart; center: [3][h][w];

@@ -18,7 +18,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 22
+ABI_VERSION = 23
 CONV_DIRECT, CONV_DIRECT_THROUGHPUT = 0, 2
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
@@ -77,6 +77,9 @@ class SatuTiling(C.Structure):
 # name -> (restype, argtypes); must list every symbol include/savsr_hip.h declares
 SIGNATURES = {
     "savsr_version": (C.c_char_p, []),
+    "savsr_source_hash": (C.c_char_p, []),
+    "savsr_source_hash_satu": (C.c_char_p, []),
+    "savsr_clock_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "savsr_last_error": (C.c_char_p, []),
     "savsr_abi_version": (C.c_int, []),
     "savsr_prepare_device": (C.c_int, []),
@@ -111,6 +114,9 @@ SIGNATURES = {
     "savsr_satu_hr_rows_per_wave_tile": (C.c_int, [C.c_int]),
     "savsr_satu_hr_lds_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "savsr_tail_gather": (C.c_int, [fptr, C.c_int64, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
+    "savsr_satu_hr_tail_q": (C.c_int, [C.POINTER(SatuWeights), fptr, C.c_int, C.c_int, fptr, C.c_int, C.c_int, fptr, fptr, fptr, fptr, fptr,
+                                       C.c_int, C.c_int, C.POINTER(SatuTiling), fptr, fptr, C.c_int64, fptr, C.c_int64, C.c_void_p]),
+    "savsr_tail_gather_q": (C.c_int, [fptr, C.c_int64, fptr, C.c_int64, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
     "savsr_resize_aa_axis": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int, fptr, C.c_void_p]),
     "savsr_metrics_blocks": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "savsr_metrics_psnr_ssim_y": (C.c_int, [fptr, C.c_int64, fptr, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -39,9 +39,17 @@ int ensure_dynamic_lds(const void* fn, int bytes, const char* what) {
 }  // namespace savsr
 
 extern "C" {
-const char* savsr_version(void) { return "savsr_hip 0.3 (gfx950, split-bf16 MFMA, channel-last)"; }
+const char* savsr_version(void) { return "savsr_hip 0.4 (gfx950, split-bf16 MFMA, channel-last)"; }
 const char* savsr_last_error(void) { return savsr::g_err; }
 int savsr_abi_version(void) { return SAVSR_ABI_VERSION; }
+#ifndef SAVSR_SOURCE_HASH
+#define SAVSR_SOURCE_HASH "unknown"
+#endif
+#ifndef SAVSR_SATU_HASH
+#define SAVSR_SATU_HASH "unknown"
+#endif
+const char* savsr_source_hash(void) { return SAVSR_SOURCE_HASH; }
+const char* savsr_source_hash_satu(void) { return SAVSR_SATU_HASH; }
 int savsr_prepare_device(void) {
     if (int rc = savsr::conv_prepare_device()) return rc;
     return savsr::satu_prepare_device();

@@ -40,6 +40,9 @@
 #ifndef LR_ST
 #define LR_ST 0                   // LRcat stores of satu_lr_stream_kernel: 0 plain, 1 nt, 2 sc1 (write-through), 3 sc0 sc1
 #endif
+#ifndef QS_EXP
+#define QS_EXP 0                  // timing experiments on the row-summed HR form (results invalid): 1 no DPP shifts, 2 no seam stores, 4 ds_bpermute shifts
+#endif
 #ifndef HR_ST
 #define HR_ST 2                   // plane stores of the lane = pixel HR tile: 0 plain, 1 nt, 2 sc1 (write-through)
 #endif
@@ -833,6 +836,8 @@ struct HrParams {
     float step_x, step_y;        // LR pixels per HR pixel (1 / scale), for the window origin only
     int ntx, nty;                // tiles per row / per column of the HR image
     int* sched;                  // [16] tile-queue heads (one per XCD chunk) + exit count, all zero between launches; NULL: static walk
+    float* seam;                 // row-summed form (QS kernels): [H][nseg][2 sides][9 groups], see hr_tile_px
+    int nseg;                    // 32-pixel column segments per HR row
 };
 
 constexpr int HR_MAX_ROWS = 64;
@@ -1030,10 +1035,16 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
 // accumulators and the expert B operands are transposed in registers in front of it: with a = rows of half 0 and b = rows of
 // half 1 of the lane's own pixel, v_permlane32_swap(a, b) leaves [a of lanes 0-31 | b of lanes 0-31] = the accumulator layout
 // of the first row's 32 pixels in a, and that of the second row's in b (one instruction per register pair).
-template <bool FROM_LDS>
+// QS (row-summed form, savsr_satu_hr_tail_q): the 27 planes are ordered so that the three horizontal taps of a (tap row ky, colour o)
+// group sit in ONE lane half at accumulator registers 3 gi, 3 gi + 1, 3 gi + 2 (groups 0 .. 4 in half 0, 5 .. 8 in half 1: the
+// caller's Wt27 row order), and the stage adds them itself -- Q[g][Y][X] = P(kx = 1)[X] + P(kx = 0)[X - 1] + P(kx = 2)[X + 1], the
+// neighbours' values by wave-wide DPP shifts -- and stores 9 planes instead of 27 (33 MB instead of 99.5 at 720x1280); the terms
+// that cross a 32-pixel segment border go to two small side planes (`seam`: what the right neighbour's first pixel / the left
+// neighbour's last pixel still needs), which savsr_tail_gather_q adds with the three vertical taps.
+template <bool FROM_LDS, bool QS = false>
 __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, int ly0, int lx0, const Taps& to, const Taps& ts,
                                            const f32x4 rr, int lane, bool valid0, bool valid1, unsigned o_off0, unsigned o_off1,
-                                           const float* cst) {
+                                           const float* cst, int Y = 0, int seg = 0, bool row1 = false) {
     constexpr int REC = rec_floats(1), LREC = hr_lds_rec(1);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -1134,6 +1145,82 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
     const long long HW = p.out_plane;
     float* outp = p.out;
     asm volatile("" : "+s"(outp));
+    if constexpr (QS) {
+        const int px = lane & 31;
+        const bool vx = valid0;                                   // this lane's column lies inside the image (X < W)
+        // q = c1 + shr(c0) * m0 + shl(c2) * m31 (wave-wide DPP shifts).  m0 keeps lane 0 of a half from seeing the OTHER half's lane 31,
+        // m31 lane 31 from the other half's lane 0 -- those two terms are the seams' business -- and zeroes the right neighbour's term
+        // where that neighbour lies beyond the image's last column (the tail conv's zero padding; a left neighbour beyond it only
+        // feeds pixels that are not stored).
+        const float m0 = px == 0 ? 0.f : 1.f, m31 = (px == 31 || 32 * seg + px + 1 >= p.W) ? 0.f : 1.f;
+#pragma unroll
+        for (int G = 0; G < 2; ++G) {
+            const f32x16& acc = G ? b : a;
+            const bool row_ok = G == 0 || row1;                   // (wave-uniform) the pixel row exists
+            const bool valid = G ? valid1 : valid0;
+            unsigned oo = G ? o_off1 : o_off0;
+            asm volatile("" : "+v"(oo));
+            auto st1 = [&](float* pl, unsigned off, float v) {
+                __attribute__((address_space(1))) float* a_ = (__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)pl + off);
+#if HR_ST == 2
+                __hip_atomic_store(a_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif HR_ST == 1
+                __builtin_nontemporal_store(v, a_);
+#else
+                *a_ = v;
+#endif
+            };
+            float q[5];
+#pragma unroll
+            for (int gi = 0; gi < 5; ++gi) {
+#if QS_EXP & 1
+                const float l = acc[3 * gi], r = acc[3 * gi + 2];
+#elif QS_EXP & 4
+                const float l = __shfl_up(acc[3 * gi], 1, 64), r = __shfl_down(acc[3 * gi + 2], 1, 64);
+#else
+                const float l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[3 * gi]), 0x138, 0xf, 0xf, true));        // wave_shr:1: lane i <- lane i - 1
+                const float r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[3 * gi + 2]), 0x130, 0xf, 0xf, true));    // wave_shl:1: lane i <- lane i + 1
+#endif
+                q[gi] = __builtin_fmaf(r, m31, __builtin_fmaf(l, m0, acc[3 * gi + 1]));
+            }
+            if (valid) {
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    float* pl = outp + (long long)gi * HW;
+                    asm volatile("" : "+s"(pl));
+                    st1(pl, oo, q[gi]);
+                }
+                if (half == 0) {
+                    float* pl = outp + 4ll * HW;
+                    asm volatile("" : "+s"(pl));
+                    st1(pl, oo, q[4]);
+                }
+            }
+            // seams: [row][segment][side A | side B][9 groups], 72 B per (row, segment): what the right neighbour's first pixel (side A of
+            // segment seg + 1: this segment's last pixel's kx = 0 terms) and the left neighbour's last pixel (side B of seg - 1) still need
+            // (two separate blocks with static register indices: a select between acc[3 gi] and acc[3 gi + 2] on the lane becomes a
+            // dynamic register index -- 16 compares + selects per value and a scratch reload behind an s_waitcnt vmcnt(0), i.e. behind
+            // every output store in flight: 35 -> 47 us.  The row's seam record has a wave-uniform base: scalar address arithmetic,
+            // the lane supplies only its half's 20-byte offset.)
+            typedef float f32x4u_ __attribute__((ext_vector_type(4), aligned(4)));
+            if (!(QS_EXP & 2) && row_ok) {
+                float* rowb = p.seam + (long long)((Y + G) * p.nseg + seg) * 18;      // this segment's record: [side A 9 | side B 9]
+                asm volatile("" : "+s"(rowb));
+                const unsigned ho = half ? 20u : 0u;
+                if (vx && px == 31 && seg + 1 < p.nseg) {                               // side A of segment seg + 1
+                    __attribute__((address_space(1))) char* d_ = (__attribute__((address_space(1))) char*)(rowb + 18) + ho;
+                    *(__attribute__((address_space(1))) f32x4u_*)d_ = f32x4u_{acc[0], acc[3], acc[6], acc[9]};
+                    if (half == 0) *(__attribute__((address_space(1))) float*)(d_ + 16) = acc[12];
+                }
+                if (vx && px == 0 && seg > 0) {                                         // side B of segment seg - 1
+                    __attribute__((address_space(1))) char* d_ = (__attribute__((address_space(1))) char*)(rowb - 9) + ho;
+                    *(__attribute__((address_space(1))) f32x4u_*)d_ = f32x4u_{acc[2], acc[5], acc[8], acc[11]};
+                    if (half == 0) *(__attribute__((address_space(1))) float*)(d_ + 16) = acc[14];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int G = 0; G < 2; ++G) {
         const f32x16& acc = G ? b : a;
@@ -1216,9 +1303,10 @@ __host__ __device__ constexpr int hr_producer_waves(int variant) { return varian
 //     (workgroups launched together stage together), and 52-55 us with the compute waves issuing the DMAs themselves -- the
 //     CU's memory pipe queues them behind the output stores, ~200 cycles of issue stall per DMA, 3.7 k cycles per tile.
 // DIAG = the instrumented build (section stamps, timing experiments); the product launch uses DIAG = false.
-template <bool DIAG, int NB, int VAR>
+template <bool DIAG, int NB, int VAR, bool QS = false>
 __global__ __launch_bounds__(64 * (hr_compute_waves(VAR) + hr_producer_waves(VAR)), (hr_compute_waves(VAR) + hr_producer_waves(VAR) + 3) / 4)
 void satu_hr_kernel(const HrParams p) {
+    static_assert(!QS || (NB == 1 && HR_LANE_PX), "the row-summed form is the lane = pixel tail form");
     constexpr int HR_WAVES = hr_compute_waves(VAR), HR_PRODUCERS = hr_producer_waves(VAR);
     constexpr int REC = rec_floats(NB), LREC = hr_lds_rec(NB);
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1397,11 +1485,12 @@ void satu_hr_kernel(const HrParams p) {
                     (unsigned)(ts.y0 - ly0) < (unsigned)(p.lrh - ts.dy) && (unsigned)(ts.x0 - lx0) < (unsigned)(p.lrw - ts.dx);
                 // after the transposes lane (px, hl) holds rows acc_row(r, hl) of pixel (row, Xb + px) for each of the two rows
                 const bool vx = X < p.W && !dbg_nostore;
-                const unsigned o_off0 = 4u * (unsigned)(Y * p.W + X) + (hl ? 16u * (unsigned)p.out_plane : 0u);
+                // (QS: lane half 1 holds groups 5 .. 8 = planes 5 .. 8; else rows acc_row(r, 1) = acc_row(r, 0) + 4)
+                const unsigned o_off0 = 4u * (unsigned)(Y * p.W + X) + (hl ? (QS ? 20u : 16u) * (unsigned)p.out_plane : 0u);
                 const unsigned o_off1 = o_off0 + 4u * (unsigned)p.W;
-                if (__all(inside)) hr_tile_px<true>(p, buf_cur, ly0, lx0, to, ts, rr, lane, vx, vx && row1, o_off0, o_off1, cst);
+                if (__all(inside)) hr_tile_px<true, QS>(p, buf_cur, ly0, lx0, to, ts, rr, lane, vx, vx && row1, o_off0, o_off1, cst, Y, Xb >> 5, row1);
                 else {
-                    hr_tile_px<false>(p, buf_cur, ly0, lx0, to, ts, rr, lane, vx, vx && row1, o_off0, o_off1, cst);
+                    hr_tile_px<false, QS>(p, buf_cur, ly0, lx0, to, ts, rr, lane, vx, vx && row1, o_off0, o_off1, cst, Y, Xb >> 5, row1);
                     __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the fallback's gathers are not left pending
                 }
             }
@@ -1617,6 +1706,13 @@ extern "C" int savsr_satu_expand_table(const float* table, int n_uw, const int32
 template <int NB, int VAR>
 static int hr_launch(const HrParams& p, size_t lds, int grid, bool diag, hipStream_t st) {
     constexpr int threads = 64 * (hr_compute_waves(VAR) + hr_producer_waves(VAR));
+    if constexpr (NB == 1) {
+        if (p.seam) {                                               // the row-summed form (savsr_satu_hr_tail_q)
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 1, VAR, true>), 160 * 1024, "satu_hr")) return rc;
+            hipLaunchKernelGGL((satu_hr_kernel<false, 1, VAR, true>), dim3(grid), dim3(threads), lds, st, p);
+            return check_launch("satu_hr_kernel");
+        }
+    }
 #ifdef SAVSR_DIAG
     if (diag) {
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<true, 1, VAR>), 160 * 1024, "satu_hr")) return rc;
@@ -1633,7 +1729,7 @@ static int hr_launch(const HrParams& p, size_t lds, int grid, bool diag, hipStre
 template <int NB>
 static int hr_stage(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uh, int n_uw, const int32_t* idx_h,
                     const int32_t* idx_w, const float* ptab, const float* gyn, const float* gxn, int H, int W, const savsr_satu_tiling* tiling,
-                    int32_t* sched, float* out, int64_t out_plane, void* stream) {
+                    int32_t* sched, float* out, int64_t out_plane, void* stream, float* seam = nullptr, int64_t seam_floats = 0) {
     if (!satu_weights_ok(wt) || !lrcat || !table || !idx_h || !idx_w || !gyn || !gxn || !out) return fail_arg("satu_hr: null pointer");
     if (h < 2 || w < 2 || H < 1 || W < 1 || n_uh < 1 || n_uw < 1 || out_plane < (int64_t)H * W) return fail_arg("satu_hr: shape (h, w >= 2, out_plane >= H*W required)");
     if (out_plane * 32 * NB * 4 >= ((int64_t)1 << 32)) return fail_arg("satu_hr: output of 4 GiB or more is not supported (32-bit store offsets)");
@@ -1649,6 +1745,8 @@ static int hr_stage(const savsr_satu_weights* wt, const float* lrcat, int h, int
     p.wt = *wt; p.lrcat = lrcat; p.h = h; p.w = w; p.table = table; p.n_table = small ? n_uh * n_uw : (1 << 30); p.n_uw = n_uw;
     p.idx_h = idx_h; p.idx_w = idx_w; p.ptab = ptab;
     p.gyn = gyn; p.gxn = gxn; p.H = H; p.W = W; p.out = out; p.out_plane = out_plane; p.sched = sched;
+    p.seam = seam; p.nseg = (W + 31) / 32;
+    if (seam && (seam_floats < (int64_t)H * p.nseg * 18 || (reinterpret_cast<uintptr_t>(seam) & 3))) return fail_arg("satu_hr: seam buffer (>= H * ceil(W / 32) * 18 floats)");
     p.ty = 8; p.txw = 1; p.lrh = 0; p.lrw = 0; p.omin_x = 0.f; p.omin_y = 0.f;      // default: no window staging, gathers from global
     p.step_x = (float)w / (float)W; p.step_y = (float)h / (float)H;
     int variant = 0;
@@ -1700,4 +1798,13 @@ extern "C" int savsr_satu_hr_tail(const savsr_satu_weights* wt, const float* lrc
                                   const int32_t* idx_h, const int32_t* idx_w, const float* ptab, const float* gyn, const float* gxn, int H, int W,
                                   const savsr_satu_tiling* tiling, int32_t* sched, float* out, int64_t out_plane, void* stream) {
     return hr_stage<1>(wt, lrcat, h, w, table, n_uh, n_uw, idx_h, idx_w, ptab, gyn, gxn, H, W, tiling, sched, out, out_plane, stream);
+}
+
+extern "C" int savsr_satu_hr_tail_q(const savsr_satu_weights* wt, const float* lrcat, int h, int w, const float* table, int n_uh, int n_uw,
+                                    const int32_t* idx_h, const int32_t* idx_w, const float* ptab, const float* gyn, const float* gxn, int H, int W,
+                                    const savsr_satu_tiling* tiling, int32_t* sched, float* q9, int64_t q_plane, float* seam, int64_t seam_floats,
+                                    void* stream) {
+    if (!seam) return fail_arg("satu_hr_tail_q: null seam planes");
+    if (!tiling) return fail_arg("satu_hr_tail_q: needs a tiling (the lane = pixel kernels)");
+    return hr_stage<1>(wt, lrcat, h, w, table, n_uh, n_uw, idx_h, idx_w, ptab, gyn, gxn, H, W, tiling, sched, q9, q_plane, stream, seam, seam_floats);
 }

@@ -148,6 +148,9 @@ class HipEngine:
         self.conv_algo = _lib.CONV_DIRECT           # CONV_DIRECT_THROUGHPUT while several clips are in flight (forward_many / batches)
         self._hr_choice: Dict[tuple, int] = {}      # (h, w, sh, sw) -> timed choice of the HR kernel's wave split; shared with the sibling engines
         self.use_graphs = os.environ.get("SAVSR_GRAPHS", "1") != "0"
+        # SATU in the row-summed tail form (savsr_satu_hr_tail_q + savsr_tail_gather_q: 9 planes + seams between the HR stage and the
+        # tail instead of 27 planes); SAVSR_SATU_Q=0: the 27-plane form
+        self.satu_q = os.environ.get("SAVSR_SATU_Q", "1") != "0"
         self.n_streams = max(1, int(os.environ.get("SAVSR_STREAMS", "3")))   # clips of a batch in flight concurrently
         self._siblings: List["HipEngine"] = []
         self._streams: List[torch.cuda.Stream] = []
@@ -277,39 +280,49 @@ class HipEngine:
         self.tail_w = self._dev(sd["tail.weight"].reshape(3, 64 * 9))
         self.tail_b = self._dev(sd["tail.bias"])
         # ---- tail-projected form (include/savsr_hip.h, savsr_satu_*_tail): the 3x3 tail conv's channel contraction
-        # Wt27[p = 3 (3 ky + kx) + o][c] (rows 27..31 zero) multiplied into fusion / expand / the LR projections in float64
-        wt27 = np.zeros((32, c), dtype=np.float64)
+        # Wt27[p][c] (rows 27..31 zero) multiplied into fusion / expand / the LR projections in float64.  Two row orders:
+        # p = 3 (3 ky + kx) + o (savsr_satu_hr_tail + savsr_tail_gather), and the row-summed form's (savsr_satu_hr_tail_q: the three kx
+        # of group g = 3 ky + o at MFMA rows acc_row(3 gi + kx, half), groups 0 .. 4 in lane half 0, 5 .. 8 in half 1)
         tw = sd["tail.weight"].to("cpu", torch.float64).numpy()                          # [3 o][64 c][3 ky][3 kx]
-        for ky in range(3):
-            for kx in range(3):
-                for o in range(3):
-                    wt27[3 * (3 * ky + kx) + o] = tw[o, :, ky, kx]
-        ta = (wt27 @ wa.astype(np.float64)).astype(np.float32)                           # [32][64] applies to sta
-        tb = (wt27 @ wb.astype(np.float64)).astype(np.float32)                           # [32][64] applies to x
-        pa1 = np.zeros((1, 4, 64, 8), dtype=np.float32)
-        pb1 = np.zeros((1, 4, 64, 8), dtype=np.float32)
-        for kidx in range(4):
-            cgi, s = kidx // 2, kidx % 2
-            ch = 32 * cgi + 16 * s + 8 * (jj[None, :] >> 2) + 4 * lh[:, None] + (jj[None, :] & 3)
-            pa1[0, kidx] = ta[li[:, None], ch]
-            pb1[0, kidx] = tb[li[:, None], 16 * kidx + 8 * lh[:, None] + jj[None, :]]
-        proj1 = np.concatenate([pa1.reshape(-1), pb1.reshape(-1), pc.reshape(-1)])
-        twbe = np.einsum("pc,ncj->npj", wt27 @ wb.astype(np.float64), expd.astype(np.float64)).astype(np.float32)   # (Wt27 Wb E_n)[p][j]
-        twbe_p = np.zeros((1, 2, 64, 8), dtype=np.float32)
-        for ksi in range(2):
-            twbe_p[0, ksi] = twbe[(2 * ksi + lh)[:, None], li[:, None], jj[None, :]]
-        tfb = (wt27 @ fb.astype(np.float64)).astype(np.float32)
-        tfb_p = np.zeros((2, 16), dtype=np.float32)
-        for hh in range(2):
-            for r in range(16):
-                tfb_p[hh, r] = tfb[acc_row(r, hh)]
-        self.satu_tail_t = dict(proj_w=img(proj1), wbe_w=img(twbe_p), fusion_b=t_(tfb_p))
-        swt = SatuWeights()
-        for k, v in self.satu_t.items():
-            setattr(swt, k, v.data_ptr())
-        for k, v in self.satu_tail_t.items():
-            setattr(swt, k, v.data_ptr())
-        self.satu_w_tail = swt
+
+        def fold(row_of):
+            wt27 = np.zeros((32, c), dtype=np.float64)
+            for ky in range(3):
+                for kx in range(3):
+                    for o in range(3):
+                        wt27[row_of(ky, kx, o)] = tw[o, :, ky, kx]
+            ta = (wt27 @ wa.astype(np.float64)).astype(np.float32)                           # [32][64] applies to sta
+            tb = (wt27 @ wb.astype(np.float64)).astype(np.float32)                           # [32][64] applies to x
+            pa1 = np.zeros((1, 4, 64, 8), dtype=np.float32)
+            pb1 = np.zeros((1, 4, 64, 8), dtype=np.float32)
+            for kidx in range(4):
+                cgi, s_ = kidx // 2, kidx % 2
+                ch = 32 * cgi + 16 * s_ + 8 * (jj[None, :] >> 2) + 4 * lh[:, None] + (jj[None, :] & 3)
+                pa1[0, kidx] = ta[li[:, None], ch]
+                pb1[0, kidx] = tb[li[:, None], 16 * kidx + 8 * lh[:, None] + jj[None, :]]
+            proj1 = np.concatenate([pa1.reshape(-1), pb1.reshape(-1), pc.reshape(-1)])
+            twbe = np.einsum("pc,ncj->npj", wt27 @ wb.astype(np.float64), expd.astype(np.float64)).astype(np.float32)   # (Wt27 Wb E_n)[p][j]
+            twbe_p = np.zeros((1, 2, 64, 8), dtype=np.float32)
+            for ksi in range(2):
+                twbe_p[0, ksi] = twbe[(2 * ksi + lh)[:, None], li[:, None], jj[None, :]]
+            tfb = (wt27 @ fb.astype(np.float64)).astype(np.float32)
+            tfb_p = np.zeros((2, 16), dtype=np.float32)
+            for hh in range(2):
+                for r in range(16):
+                    tfb_p[hh, r] = tfb[acc_row(r, hh)]
+            tens = dict(proj_w=img(proj1), wbe_w=img(twbe_p), fusion_b=t_(tfb_p))
+            swt = SatuWeights()
+            for k, v in self.satu_t.items():
+                setattr(swt, k, v.data_ptr())
+            for k, v in tens.items():
+                setattr(swt, k, v.data_ptr())
+            return tens, swt
+
+        def row_q(ky, kx, o):
+            g = 3 * ky + o
+            return acc_row(3 * g + kx, 0) if g < 5 else acc_row(3 * (g - 5) + kx, 1)
+        self.satu_tail_t, self.satu_w_tail = fold(lambda ky, kx, o: 3 * (3 * ky + kx) + o)
+        self.satu_tailq_t, self.satu_w_tailq = fold(row_q)
 
     def _pack_all(self, sd):
         cfg = self.cfg
@@ -376,6 +389,7 @@ class HipEngine:
         e.satu_t, e.satu_w, e.tail_w, e.tail_b, e.gamma, e.n_l2 = self.satu_t, self.satu_w, self.tail_w, self.tail_b, self.gamma, self.n_l2
         e.iter_win, e.fwd_idx, e.bwd_idx = self.iter_win, self.fwd_idx, self.bwd_idx
         e.satu_tail_t, e.satu_w_tail = self.satu_tail_t, self.satu_w_tail
+        e.satu_tailq_t, e.satu_w_tailq, e.satu_q = self.satu_tailq_t, self.satu_w_tailq, self.satu_q
         e.osc = {}
         for k, ent in self.osc.items():
             c = dict(ent)
@@ -749,37 +763,48 @@ class HipEngine:
         ent["tiling_tail"] = ent["tail_plans"][0] if len(ent["tail_plans"]) == 1 else None
 
     @staticmethod
+    def seam_floats(H: int, W: int) -> int:
+        """Floats of the row-summed form's side buffer: [H][ceil(W / 32)][2 sides][9 groups]."""
+        return ((H * ((W + 31) // 32) * 18 + 63) // 64) * 64
+
+    @staticmethod
     def hr_plane(H: int, W: int) -> int:
         """Plane pitch (floats) of the planar HR feature map: H*W rounded up to 1 KiB plus 4352 B, so the
         64 channel planes of one pixel do not alias onto the same HBM channel (H*W*4 is a multiple of
         16 KiB at 720x1280)."""
         return ((H * W + 255) // 256) * 256 + 1088
 
-    def satu_lr(self, x: Src, st: Src, row_px: int, h: int, w: int, tail_form: bool = False) -> torch.Tensor:
+    def satu_lr(self, x: Src, st: Src, row_px: int, h: int, w: int, tail_form: bool = False, q: bool = False) -> torch.Tensor:
         """LR stage of SATU (kernel_conv + LeakyReLU + sta_conv + LR-side projections, savsr_arch.py:226-228,297-320).
-        tail_form: the projections carry the tail conv's channel contraction (include/savsr_hip.h)."""
+        tail_form: the projections carry the tail conv's channel contraction (include/savsr_hip.h); q: in the row order of
+        the row-summed form (savsr_satu_hr_tail_q)."""
         assert x.pix == st.pix
         if tail_form:
-            lrcat = self.buf("satu.lrcat_tail", h, w, _lib.SATU_LRCAT_TAIL)
-            fn, wts = self.lib.savsr_satu_lr_stage_tail, self.satu_w_tail
+            lrcat = self.buf("satu.lrcat_tailq" if q else "satu.lrcat_tail", h, w, _lib.SATU_LRCAT_TAIL)
+            fn, wts = self.lib.savsr_satu_lr_stage_tail, (self.satu_w_tailq if q else self.satu_w_tail)
         else:
             lrcat = self.buf("satu.lrcat", h, w, _lib.SATU_LRCAT)
             fn, wts = self.lib.savsr_satu_lr_stage, self.satu_w
         _lib.check(fn(C.byref(wts), x.ptr, st.ptr, x.pix, row_px, h, w, lrcat.data_ptr(), self._stream()), "savsr_satu_lr_stage")
         return lrcat
 
-    def satu_hr(self, lrcat: torch.Tensor, h: int, w: int, scale, out: torch.Tensor, out_plane: Optional[int] = None, tail_form: bool = False):
+    def satu_hr(self, lrcat: torch.Tensor, h: int, w: int, scale, out: torch.Tensor, out_plane: Optional[int] = None, tail_form: bool = False,
+                seam: Optional[torch.Tensor] = None):
         """HR stage of SATU (grid_sample x2, expert mixing, fusion, savsr_arch.py:262-295,353-374) -> out [64] planes of [H][W];
-        tail_form: -> the 27 tail-projected planes P."""
+        tail_form: -> the 27 tail-projected planes P, or with `seam` (seam_floats(H, W) floats) the row-summed form: out = the 9 planes Q
+        (lrcat from satu_lr(..., q=True))."""
         ax = self.satu_axes(h, w, scale)       # incl. the phase table: a function of (size, scale, weights) only, evaluated once
         fn, wts = (self.lib.savsr_satu_hr_tail, self.satu_w_tail) if tail_form else (self.lib.savsr_satu_hr_upsample, self.satu_w)
+        if seam is not None:
+            assert tail_form
+            fn, wts = self.lib.savsr_satu_hr_tail_q, self.satu_w_tailq
         sched = self.hr_sched.data_ptr() if os.environ.get("SAVSR_HR_STATIC") != "1" else None
         plane = out_plane if out_plane is not None else ax["H"] * ax["W"]
 
         def launch(til):
             _lib.check(fn(C.byref(wts), lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uh"], ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
                           _ptr(ax["ptab"]), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"],
-                          C.byref(til), sched, out.data_ptr(), plane, self._stream()), "savsr_satu_hr")
+                          C.byref(til), sched, out.data_ptr(), plane, *(() if seam is None else (seam.data_ptr(), seam.numel())), self._stream()), "savsr_satu_hr")
         if not tail_form:
             launch(ax["tiling"])
             return out
@@ -832,10 +857,13 @@ class HipEngine:
         self._select(lq.shape, scale)
         c = self._stage_body(lq, scale)
         out = torch.empty(3, c["H"], c["W"], device=self.dev)
-        lrcat = self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True)
+        q = self.satu_q
+        lrcat = self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True, q=q)
         self._stage_satu(c, scale)
-        return {"satu_lr_us": timer(lambda: self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True)),
-                "satu_hr_us": timer(lambda: self.satu_hr(lrcat, c["h"], c["w"], scale, c["p27"], c["plane"], tail_form=True)),
+        hr = (lambda: self.satu_hr(lrcat, c["h"], c["w"], scale, c["q9"], c["plane"], tail_form=True, seam=c["seam"])) if q else \
+            (lambda: self.satu_hr(lrcat, c["h"], c["w"], scale, c["p27"], c["plane"], tail_form=True))
+        return {"satu_lr_us": timer(lambda: self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True, q=q)),
+                "satu_hr_us": timer(hr),
                 "tail_us": timer(lambda: self._stage_tail(c, lq, out))}
 
     # ------------------------------------------------------------------ whole frame
@@ -905,10 +933,18 @@ class HipEngine:
         hfeat = self.conv("conv_last", [hcur], self.full(self.buf("hfeat", hp, wp, nf)), hp, wp, res1=share)   # :733-734
         H, W = get_hw(h_in, w_in, scale)
         plane = self.hr_plane(H, W)
-        return dict(align=align, hfeat=hfeat, wp=wp, h=h_in, w=w_in, H=H, W=W, plane=plane, p27=self.sbuf("satu.p27", _lib.TAIL_PLANES, plane))
+        d = dict(align=align, hfeat=hfeat, wp=wp, h=h_in, w=w_in, H=H, W=W, plane=plane, p27=self.sbuf("satu.p27", _lib.TAIL_PLANES, plane))
+        if self.satu_q:
+            d["q9"] = self.sbuf("satu.q9", 9, plane)
+            d["seam"] = self.sbuf("satu.seam", self.seam_floats(H, W))
+        return d
 
     def _stage_satu(self, c: dict, scale):
         """SATU in the tail-projected form (savsr_arch.py:315-376 with the channel contraction of :738 folded in): -> P [27][H][W]."""
+        if self.satu_q:        # row-summed form: the HR stage adds the horizontal taps itself -> 9 planes + seams
+            lrcat = self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True, q=True)
+            self.satu_hr(lrcat, c["h"], c["w"], scale, c["q9"], c["plane"], tail_form=True, seam=c["seam"])
+            return
         lrcat = self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True)       # crops of :737 via (row pitch, h, w)
         self.satu_hr(lrcat, c["h"], c["w"], scale, c["p27"], c["plane"], tail_form=True)
 
@@ -918,6 +954,10 @@ class HipEngine:
         T = lq.shape[0]
         center = T // 2 if cfg["center_frame_idx"] is None else cfg["center_frame_idx"]
         cptr = lq.data_ptr() + 4 * center * 3 * c["h"] * c["w"]                     # unpadded centre frame (:696)
+        if self.satu_q:
+            _lib.check(self.lib.savsr_tail_gather_q(c["q9"].data_ptr(), c["plane"], c["seam"].data_ptr(), c["seam"].numel(), self.tail_b.data_ptr(), cptr,
+                                                    c["h"], c["w"], c["H"], c["W"], out.data_ptr(), self._stream()), "savsr_tail_gather_q")
+            return
         _lib.check(self.lib.savsr_tail_gather(c["p27"].data_ptr(), c["plane"], self.tail_b.data_ptr(), cptr,
                                               c["h"], c["w"], c["H"], c["W"], out.data_ptr(), self._stream()), "savsr_tail_gather")
 
@@ -942,6 +982,8 @@ class HipEngine:
             taps["align_feat"] = c["align"].t
             taps["h_feat"] = c["hfeat"].t
             taps["satu"] = self._satu_standalone(c, scale)
+            if self.satu_q:     # the 27-plane form beside the row-summed one the frame runs (taps only)
+                self.satu_hr(self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True), c["h"], c["w"], scale, c["p27"], c["plane"], tail_form=True)
             taps["p27"] = c["p27"][:, : c["H"] * c["W"]].view(_lib.TAIL_PLANES, c["H"], c["W"])
         self._stage_tail(c, lq, out)
         return out
@@ -971,8 +1013,12 @@ class HipEngine:
             h_, w_ = int(lq.shape[-2]), int(lq.shape[-1])
             H_, W_ = get_hw(h_, w_, scale)
             plane_ = self.hr_plane(H_, W_)
-            self.satu_hr(self.buf("satu.lrcat_tail", h_, w_, _lib.SATU_LRCAT_TAIL), h_, w_, scale,
-                         self.sbuf("satu.p27", _lib.TAIL_PLANES, plane_), plane_, tail_form=True)
+            if self.satu_q:
+                self.satu_hr(self.buf("satu.lrcat_tailq", h_, w_, _lib.SATU_LRCAT_TAIL), h_, w_, scale, self.sbuf("satu.q9", 9, plane_), plane_,
+                             tail_form=True, seam=self.sbuf("satu.seam", self.seam_floats(H_, W_)))
+            else:
+                self.satu_hr(self.buf("satu.lrcat_tail", h_, w_, _lib.SATU_LRCAT_TAIL), h_, w_, scale,
+                             self.sbuf("satu.p27", _lib.TAIL_PLANES, plane_), plane_, tail_form=True)
             torch.cuda.current_stream().synchronize()
             _t1 = _time.perf_counter()
             graphs = [torch.cuda.CUDAGraph() for _ in range(3)]

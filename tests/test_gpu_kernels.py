@@ -405,6 +405,48 @@ def test_satu_hr_variants_bit_identical(eng, h, w, sc):
         assert torch.equal(o, other)
 
 
+@pytest.mark.parametrize("h,w,sc", [(40, 52, (4, 4)), (33, 47, (3.5, 2)), (30, 41, (2.7, 2.7)), (19, 23, (1.5, 1.3)), (64, 96, (4, 4)), (181, 97, (4, 3.9))])
+def test_satu_row_summed_form_equals_27_plane_form(eng, h, w, sc):
+    """savsr_satu_hr_tail_q + savsr_tail_gather_q (the HR stage adds the horizontal taps; 9 planes + seams) against
+    savsr_satu_hr_tail + savsr_tail_gather (27 planes): the same nine taps in another summation order (<= 2e-6 on values of ~1), for
+    every launch plan bit-identically; widths that are / are not multiples of 32 and of 4, odd heights."""
+    from savsr_amd import _lib
+    from savsr_amd.engine import get_hw
+    x, st = rnd((1, 64, h, w), 71, 1.0), rnd((1, 64, h, w), 72, 0.6)
+    center = torch.from_numpy(np.random.RandomState(73).uniform(0, 1, (3, h, w)).astype(np.float32)).to("cuda:0")
+    H, W = get_hw(h, w, sc)
+    plane = eng.hr_plane(H, W)
+    sp = eng.seam_floats(H, W)
+    xs, sts = eng.full(cl(x[0])), eng.full(cl(st[0]))
+    stm = torch.cuda.current_stream().cuda_stream
+    # 27-plane form
+    p27 = torch.full((27, plane), float("nan"), device="cuda:0")
+    eng.satu_hr(eng.satu_lr(xs, sts, w, h, w, tail_form=True), h, w, sc, p27, plane, tail_form=True)
+    ref = torch.empty(3, H, W, device="cuda:0")
+    _lib.check(eng.lib.savsr_tail_gather(p27.data_ptr(), plane, eng.tail_b.data_ptr(), center.data_ptr(), h, w, H, W, ref.data_ptr(), stm), "tail")
+    # row-summed form, every plan
+    lrq = eng.satu_lr(xs, sts, w, h, w, tail_form=True, q=True)
+    ax = eng.satu_axes(h, w, sc)
+    outs = []
+    for til in ax["tail_plans"]:
+        ax["tiling_tail"] = til
+        q9 = torch.full((9, plane), float("nan"), device="cuda:0")
+        seam = torch.full((sp,), float("nan"), device="cuda:0")
+        eng.satu_hr(lrq, h, w, sc, q9, plane, tail_form=True, seam=seam)
+        o = torch.full((3, H, W), float("nan"), device="cuda:0")
+        _lib.check(eng.lib.savsr_tail_gather_q(q9.data_ptr(), plane, seam.data_ptr(), sp, eng.tail_b.data_ptr(), center.data_ptr(), h, w, H, W,
+                                               o.data_ptr(), stm), "tail_q")
+        outs.append(o)
+    ax["tiling_tail"] = None
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[0]).all())
+    err = float((outs[0] - ref).abs().max())
+    print("row-summed vs 27-plane form: max-abs", err, "on magnitude", float(ref.abs().max()))
+    assert err < 2e-6 * max(1.0, float(ref.abs().max()))
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 @pytest.mark.parametrize("h,w,sc", [(7, 9, (3.5, 2)), (8, 10, (2, 2.4)), (5, 16, (4, 4)), (6, 7, (1.5, 1.3))])
 def test_tail_gather(eng, synth_sd, h, w, sc):
     """savsr_tail_gather: nine shifted taps per colour + bias + bilinear residual (savsr_arch.py:738-739), both the

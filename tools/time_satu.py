@@ -35,9 +35,11 @@ def main():
     H, W = E.get_hw(h, w, sc)
     plane = eng.hr_plane(H, W)
     p27 = torch.empty(_lib.TAIL_PLANES, plane, device=dev)
-    lr = lambda: eng.satu_lr(eng.full(x), eng.full(st), w, h, w, tail_form=True)
+    q = eng.satu_q                                     # SAVSR_SATU_Q=0: the 27-plane form
+    seam = torch.empty(eng.seam_floats(H, W), device=dev) if q else None
+    lr = lambda: eng.satu_lr(eng.full(x), eng.full(st), w, h, w, tail_form=True, q=q)
     lrcat = lr()
-    hr = lambda: eng.satu_hr(lrcat, h, w, sc, p27, plane, tail_form=True)
+    hr = (lambda: eng.satu_hr(lrcat, h, w, sc, p27, plane, tail_form=True, seam=seam)) if q else (lambda: eng.satu_hr(lrcat, h, w, sc, p27, plane, tail_form=True))
     hr()
     torch.cuda.synchronize()
 
@@ -73,7 +75,10 @@ def main():
     outb = torch.empty(3, H, W, device=dev)
     tb = torch.zeros(3, device=dev)
     st_ = torch.cuda.current_stream().cuda_stream
-    tail = lambda: _lib.check(eng.lib.savsr_tail_gather(p27.data_ptr(), plane, tb.data_ptr(), center.data_ptr(), h, w, H, W, outb.data_ptr(), st_), "tail")
+    if q:
+        tail = lambda: _lib.check(eng.lib.savsr_tail_gather_q(p27.data_ptr(), plane, seam.data_ptr(), seam.numel(), tb.data_ptr(), center.data_ptr(), h, w, H, W, outb.data_ptr(), st_), "tail_q")
+    else:
+        tail = lambda: _lib.check(eng.lib.savsr_tail_gather(p27.data_ptr(), plane, tb.data_ptr(), center.data_ptr(), h, w, H, W, outb.data_ptr(), st_), "tail")
     for _ in range(a.reps):
         tt, tht = t(tail), t(lambda: (hr(), tail()))
         print(f"tail_gather alone {tt:.1f} us   HR->tail pair {tht:.1f} us", flush=True)
