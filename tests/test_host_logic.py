@@ -186,3 +186,29 @@ def test_bench_gpus_flag_fails_loudly_without_the_gpus():
     env["WORLD_SIZE"] = "4"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr and r.stdout.strip() == ""
+
+
+def test_check_readme_logic():
+    """The real-data checker (python -m savsr_amd.test --check-readme) on synthetic result tables: README entries are found for
+    the YAML's dataset names / scales, the tolerance is 0.01 dB / 1e-4 plus half a unit of the published rounding, a dataset
+    without an entry is not a pass."""
+    import json
+    from savsr_amd import test as T
+    table = json.load(open(T.README_TABLE))
+    assert len(table["Vid4"]) == 42 and len(table["UDM10"]) == 42
+    assert table["Vid4"]["4,4"] == [27.17, 0.8184] and table["UDM10"]["3.5,2"] == [42.23, 0.9798]        # README.md:96,124
+    assert T.readme_entry(table, "Vid4_x1.5_x4", (1.5, 4)) == (30.45, 0.9027)
+    assert T.readme_entry(table, "Vid4_x4", (4, 4)) == (27.17, 0.8184) and T.readme_entry(table, "Vid4_x4", (4.0, 4.0)) == (27.17, 0.8184)
+    assert T.readme_entry(table, "REDS4_x4", (4, 4)) is None
+
+    def res(name, sc, p, s):
+        return {"dataset": name, "scale": sc, "metrics": {"psnr_y": p, "ssim_y": s}}
+    rows, st = T.check_readme([res("Vid4_x4", (4, 4), 27.1749, 0.81845), res("UDM10_x3.5_x2", (3.5, 2), 42.2251, 0.97972)], table)
+    assert st == 0 and all(r["ok"] for r in rows)
+    rows, st = T.check_readme([res("Vid4_x4", (4, 4), 27.17 + 0.0151, 0.8184)], table)
+    assert st == 1 and not rows[0]["ok"]
+    rows, st = T.check_readme([res("Vid4_x4", (4, 4), 27.17, 0.8184 + 0.00016)], table)
+    assert st == 1
+    rows, st = T.check_readme([res("Vid4_x4", (4, 4), 27.17, 0.8184), res("Vid4_x6", (6, 6), 25.0, 0.7)], table)
+    assert st == 2 and rows[0]["ok"] and not rows[1]["ok"]
+    assert "NO README ENTRY" in T.format_check(rows) and "ok" in T.format_check(rows)
