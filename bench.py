@@ -111,18 +111,24 @@ class ClockProbe:
     def __init__(self, eng, dev):
         self.lib, self.dev = eng.lib, dev
         self.stream = torch.cuda.Stream(device=dev)
-        self.buf = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.windows = 8
+        self.buf = torch.zeros(2 * self.windows, dtype=torch.int64, device=dev)
 
     def start(self, ms):
         self.buf.zero_()
         torch.cuda.synchronize()
-        rc = self.lib.savsr_clock_probe(self.buf.data_ptr(), int(ms * 1e5), self.stream.cuda_stream)
+        rc = self.lib.savsr_clock_probe(self.buf.data_ptr(), max(1, int(ms * 1e5 / self.windows)), self.windows, self.stream.cuda_stream)
         assert rc == 0, rc
 
     def mhz(self):
+        """Median and range over the probe's windows (the first window may start before the load does)."""
         self.stream.synchronize()
-        c, r = (int(v) for v in self.buf.cpu())
-        return round(100.0 * c / r, 1) if r > 0 else None
+        v = self.buf.cpu().view(self.windows, 2).tolist()
+        mhz = sorted(100.0 * c / r for c, r in v if r > 0)
+        if not mhz:
+            return None
+        self.last_range = [round(mhz[0], 1), round(mhz[-1], 1)]
+        return round(mhz[len(mhz) // 2], 1)
 
 
 def conv_roofline(eng, dev, iters=20, probe=None):

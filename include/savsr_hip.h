@@ -52,11 +52,12 @@ int savsr_prepare_device(void);
  * lets a measurement file name the build it was taken on (profiles/satu_traffic.json; bench.py drops `traffic` when it differs). */
 const char* savsr_source_hash(void);
 const char* savsr_source_hash_satu(void);     /* the same over the SATU + tail kernel sources only (satu.hip, tail.hip, common.hpp, this header) */
-/* Measurement aid (bench.py `clock_mhz`): ONE wave spins until `realtime_ticks` ticks of the 100 MHz s_memrealtime counter have passed
- * and writes out2 = { s_memtime delta (shader cycles), s_memrealtime delta }: shader clock = out2[0] / out2[1] x 100 MHz
- * (MI355X_MICROARCH.md, DVFS give-back item 6).  Launched on a side stream beside other work it reads the clock the chip holds
- * under that load (one wave with s_sleep in its loop; no LDS, co-resides with any workgroup).  realtime_ticks in 1 .. 10^8. */
-int savsr_clock_probe(int64_t* out2, int realtime_ticks, void* stream);
+/* Measurement aid (bench.py `clock_mhz`): ONE wave spins through `windows` (1 .. 64) consecutive windows of `window_ticks` ticks of the
+ * 100 MHz s_memrealtime counter each and writes out[2 i] = s_memtime delta (shader cycles), out[2 i + 1] = s_memrealtime delta of window i:
+ * shader clock = out[2 i] / out[2 i + 1] x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  Launched on a side stream beside other
+ * work it reads the clock of the CU it sits on while that work runs (one wave with s_sleep in its loop; no LDS, co-resides with any
+ * workgroup).  window_ticks x windows <= 10^8 (1 s). */
+int savsr_clock_probe(int64_t* out, int window_ticks, int windows, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Feature-map layout: every LR-resolution feature map is CHANNEL-LAST fp32, [h][w][C], addressed

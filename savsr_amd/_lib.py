@@ -79,7 +79,7 @@ SIGNATURES = {
     "savsr_version": (C.c_char_p, []),
     "savsr_source_hash": (C.c_char_p, []),
     "savsr_source_hash_satu": (C.c_char_p, []),
-    "savsr_clock_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "savsr_clock_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "savsr_last_error": (C.c_char_p, []),
     "savsr_abi_version": (C.c_int, []),
     "savsr_prepare_device": (C.c_int, []),

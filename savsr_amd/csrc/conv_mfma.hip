@@ -59,6 +59,12 @@
 #ifndef EPI_PREFETCH
 #define EPI_PREFETCH 1            // the epilogue's first global loads (bias quads, first residual group) are issued in front of the tile's LAST phase
 #endif
+#ifndef CONV_PRIO
+#define CONV_PRIO 1               // issue priority of the two waves of a SIMD: 0 = alternating per step (rounds 1-3: a scalar branch around s_setprio in
+                                  // every step, which also cut every step into its own basic block), 1 = static (waves 4-7 at priority 1 for the whole
+                                  // kernel, no branch in the steps: the 9 steps of a phase are three basic blocks), 2 = none.  A/B/A/B in one process
+                                  // (tools/ab_conv.py, round 4): 6 x 128->64 150.6 -> 147.6 (1) / 148.4 (2) us, 6 x 64->64 88.6 -> 87.8 / 87.5, 64->64 18.2 -> 17.7 / 17.5
+#endif
 #ifndef ROWS_SKIP
 #define ROWS_SKIP 1               // 0: one phase body, MFMAs on zeros below the image; 1: a wave with NO row inside the image runs a body without MFMAs;
                                   // 2: also a one-row body for waves with one row of two inside (three bodies: 69 spilled VGPRs in the 16-row kernel)
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     static_assert(!EP_ALIAS || B_UNITS * 16 >= CONV_TH * 32 * EPS * 4, "aliased epilogue slices must fit one input buffer");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
-    const int prio_group = __builtin_amdgcn_readfirstlane(wave >> 2);      // wave-uniform by construction: a scalar for the s_setprio branch
+    [[maybe_unused]] const int prio_group = __builtin_amdgcn_readfirstlane(wave >> 2);      // wave-uniform by construction: a scalar for the s_setprio branch
     const int tiles_per_cob = mp.ntx * mp.nty;
     const int total = mp.nconv * mp.ncob * tiles_per_cob;
 #if CONV_HAS_STAMPS
@@ -244,6 +250,9 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     long long t_prev = (stamps_on >= 3) ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define CV_MARK(i) do { if (stamps_on >= 3) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); sec[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
+#if CONV_PRIO == 1
+    if (prio_group) __builtin_amdgcn_s_setprio(1);
+#endif
     stamp(stamps_on, 0);
 #if CONV_EXP & 8
     if (!DIAG && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && blockIdx.x < STAMP_BLOCKS)   // (scalar branch: all of wave 0 stores)
@@ -427,7 +436,9 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 // The two waves of a SIMD alternate issue priority step by step.  Left to the oldest-first arbiter, waves
                 // 0-3 run every step ahead, then idle ~2 k cycles per phase at the barrier while waves 4-7 finish alone
                 // (a lone wave cannot cover its own staging work with MFMAs): stamps, 80 k vs 99 k cycles of steps.
+#if CONV_PRIO == 0
                 if (((s ^ prio_group) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
 #if CONV_INTERLEAVE
                 // Straight-line step (FINE, product build): the staging pieces are issued unconditionally -- without a next
                 // phase they re-stage the cursor's last phase into a buffer nobody reads -- so that the step is ONE basic

@@ -75,18 +75,20 @@ __global__ __launch_bounds__(256) void pack_windows_kernel(const float* __restri
     }
 }
 
-// bench.py's clock probe: one wave, no LDS; shader clock = (s_memtime delta) / (s_memrealtime delta) x 100 MHz
-__global__ __launch_bounds__(64) void clock_probe_kernel(long long* out2, int realtime_ticks) {
-    const long long r0 = (long long)__builtin_amdgcn_s_memrealtime();
-    const long long c0 = (long long)__builtin_amdgcn_s_memtime();
-    long long r1 = r0;
-    while (r1 - r0 < realtime_ticks) {
-        __builtin_amdgcn_s_sleep(32);
+// bench.py's clock probe: one wave, no LDS; per window: shader clock = (s_memtime delta) / (s_memrealtime delta) x 100 MHz
+__global__ __launch_bounds__(64) void clock_probe_kernel(long long* out, int window_ticks, int windows) {
+    for (int wi = 0; wi < windows; ++wi) {
+        const long long r0 = (long long)__builtin_amdgcn_s_memrealtime();
+        const long long c0 = (long long)__builtin_amdgcn_s_memtime();
+        long long r1 = r0;
+        while (r1 - r0 < window_ticks) {
+            __builtin_amdgcn_s_sleep(32);
+            r1 = (long long)__builtin_amdgcn_s_memrealtime();
+        }
+        const long long c1 = (long long)__builtin_amdgcn_s_memtime();
         r1 = (long long)__builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) { out[2 * wi] = c1 - c0; out[2 * wi + 1] = r1 - r0; }
     }
-    const long long c1 = (long long)__builtin_amdgcn_s_memtime();
-    r1 = (long long)__builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) { out2[0] = c1 - c0; out2[1] = r1 - r0; }
 }
 
 static inline int grid_for(long long n) {
@@ -100,9 +102,9 @@ static inline int grid_for(long long n) {
 
 using namespace savsr;
 
-extern "C" int savsr_clock_probe(int64_t* out2, int realtime_ticks, void* stream) {
-    if (!out2 || realtime_ticks < 1 || realtime_ticks > 100000000) return fail_arg("clock_probe: null pointer / ticks out of range");
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), reinterpret_cast<long long*>(out2), realtime_ticks);
+extern "C" int savsr_clock_probe(int64_t* out, int window_ticks, int windows, void* stream) {
+    if (!out || window_ticks < 1 || windows < 1 || windows > 64 || (long long)window_ticks * windows > 100000000ll) return fail_arg("clock_probe: null pointer / ticks or windows out of range");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), reinterpret_cast<long long*>(out), window_ticks, windows);
     return check_launch("clock_probe_kernel");
 }
 
