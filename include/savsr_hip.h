@@ -103,7 +103,7 @@ typedef struct savsr_conv_desc {
                                           row t (t < savsr_conv_pool_blocks(h, w)) = channel sums of pixel tile t,
                                           written at pool[t * pool_stride + co]; consumers add rows in order */
     int32_t      pool_stride;
-    int32_t      algo;                 /* SAVSR_CONV_DIRECT or SAVSR_CONV_DIRECT_THROUGHPUT (tiling only; same results) */
+    int32_t      algo;                 /* SAVSR_CONV_DIRECT, SAVSR_CONV_DIRECT_THROUGHPUT (tiling only; same results) or SAVSR_CONV_WINOGRAD_Y */
 } savsr_conv_desc;
 
 #define SAVSR_CONV_DIRECT   0
@@ -111,6 +111,11 @@ typedef struct savsr_conv_desc {
 #define SAVSR_CONV_DIRECT_THROUGHPUT 2   /* the direct kernel, tiled for several launches in flight on different streams: 16-row
                                             tiles from 100 of them up (120 workgroups for a 64 -> 64 conv at 180x320: slower
                                             alone, faster in aggregate -- DESIGN.md 4a); results are bit-identical to DIRECT */
+
+#define SAVSR_CONV_WINOGRAD_Y 3          /* 3x3, cout % 64 == 0: 1-D Winograd F(2,3) along y on the same split-bf16 matrix products (2/3 of the
+                                            matrix work; conv_wy.hip).  `wpacked` must then be the Winograd-y image (savsr_conv_wy_pack_index):
+                                            U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 over the tap ROWS g_ky, per kx.
+                                            Results differ from DIRECT by rounding only (max-abs error ~1.5 x DIRECT's) */
 
 /* Elements PER PART (hi or lo) of the weight image of a (cout, cin, ksize) conv; the bf16 image
  * holds 2x that many 2-byte elements.  -1 for unsupported shapes. */
@@ -120,6 +125,10 @@ int64_t savsr_conv_packed_elems(int cout, int cin, int ksize);
  * (p/512)*1024 + p%512, of the lo value (p/512)*1024 + 512 + p%512.  An fp32 kernel bank for
  * savsr_osconv_weights stores W at index p directly.  Unaddressed entries must be zero. */
 int64_t savsr_conv_pack_index(int cout, int cin, int ksize, int co, int ci, int tap);
+/* The Winograd-y image of a 3x3 conv: elements per part (cout % 64 == 0, cin % 16 == 0, else -1) and the position of
+ * U[pos][co][ci][kx] (pos = 0..3) inside one part; hi / lo interleaved in groups of 512 exactly as above. */
+int64_t savsr_conv_wy_packed_elems(int cout, int cin);
+int64_t savsr_conv_wy_pack_index(int cout, int cin, int co, int ci, int pos, int kx);
 int savsr_conv_pool_blocks(int h, int w);
 int savsr_conv2d(const savsr_conv_desc* d, void* stream);
 /* n (1..6) independent convs of identical geometry (ksize, nsrc, src_ch, h, w, cout) in ONE launch

@@ -24,12 +24,12 @@ OBJDIR=${OBJDIR:-.}
 mkdir -p "$OBJDIR"
 # savsr_source_hash(): sha256 over the kernel sources + headers + flags this library is built from (first 16 hex digits), compiled into
 # api.cpp, so that a measurement file (profiles/satu_traffic.json) can name the build it was taken on and bench.py can tell a stale one
-SRC_HASH=$( (cat conv_mfma.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip api.cpp common.hpp conv_common.hpp ../../include/savsr_hip.h; printf '%s' "$BASE_FLAGS ${EXTRA_FLAGS:-} ${EXTRA_ONLY:-}") | sha256sum | cut -c1-16)
+SRC_HASH=$( (cat conv_mfma.hip conv_wy.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip api.cpp common.hpp conv_common.hpp ../../include/savsr_hip.h; printf '%s' "$BASE_FLAGS ${EXTRA_FLAGS:-} ${EXTRA_ONLY:-}") | sha256sum | cut -c1-16)
 SATU_HASH=$( (cat satu.hip tail.hip common.hpp ../../include/savsr_hip.h; printf '%s' "$BASE_FLAGS ${EXTRA_FLAGS:-} ${EXTRA_ONLY:-}") | sha256sum | cut -c1-16)   # the SATU + tail kernels alone
 
-# per-file flags: satu.hip keeps its scalar fp32 arithmetic scalar -- packed fp32 instructions (v_pk_mul / v_pk_fma) are an
+# per-file flags: satu.hip and conv_wy.hip keep their scalar fp32 arithmetic scalar -- packed fp32 instructions (v_pk_mul / v_pk_fma) are an
 # anti-lever beside MFMAs on gfx950 (MI355X_MICROARCH.md); the explicit 2-vector code of the HR stage is unaffected
-file_flags() { case "$1" in satu.hip) echo "-fno-slp-vectorize";; api.cpp) echo "-DSAVSR_SOURCE_HASH=\"$SRC_HASH\" -DSAVSR_SATU_HASH=\"$SATU_HASH\"";; *) echo "";; esac; }
+file_flags() { case "$1" in satu.hip|conv_wy.hip) echo "-fno-slp-vectorize";; api.cpp) echo "-DSAVSR_SOURCE_HASH=\"$SRC_HASH\" -DSAVSR_SATU_HASH=\"$SATU_HASH\"";; *) echo "";; esac; }
 flags_for() {  # flags_for <src>
   local f="$BASE_FLAGS $(file_flags "$1")"
   if [ -z "${EXTRA_ONLY:-}" ] || [[ " ${EXTRA_ONLY} " == *" $1 "* ]]; then echo "$f ${EXTRA_FLAGS:-}"; else echo "$f"; fi
@@ -57,7 +57,7 @@ compile() { # compile <src> <obj> [extra hipcc args]
 
 OBJS=()
 PIDS=()
-for f in conv_mfma.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip; do
+for f in conv_mfma.hip conv_wy.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip; do
   o="$OBJDIR/${f%.hip}.o"
   if stale "$f" "$o"; then
     compile "$f" "$o" &

@@ -34,6 +34,9 @@ struct MultiConvParams {
     int nconv, ncob, ntx, nty;        // tile id = ((conv * ncob + cob) * nty + ty) * ntx + tx
 };
 
+int launch_conv_wy(const MultiConvParams& mp, hipStream_t st);      // conv_wy.hip: the Winograd F(2,3)-along-y form (3x3, cout % 64 == 0)
+int conv_wy_prepare_device();
+
 // global accesses as (uniform base, 32-bit byte offset): one VGPR per address instead of a 64-bit pair
 // (savsr_conv2d validates that every tensor of a launch spans < 2 GiB).  The explicit global address space matters: the
 // epilogue's pointers pass through an asm pin, after which hipcc no longer knows their address space and emits FLAT

@@ -838,7 +838,8 @@ int conv_prepare_device() {
 #if CONV_1X1_WIDE
     if (int rc = conv_attr<1, 2, 2>()) return rc;
 #endif
-    return conv_attr<1, 1, 1>();
+    if (int rc = conv_attr<1, 1, 1>()) return rc;
+    return conv_wy_prepare_device();
 }
 
 }  // namespace savsr
@@ -951,6 +952,12 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
     mp.ntx = (d->w + CONV_TW - 1) / CONV_TW;
     mp.nty = (d->h + CONV_TH - 1) / CONV_TH;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d->algo == SAVSR_CONV_WINOGRAD_Y) {
+        // wpacked is the Winograd-y image (savsr_conv_wy_pack_index); one kernel, 16-row tiles, whatever the launch size
+        if (d->ksize != 3 || d->cout % 64) return fail_arg("conv: algo WINOGRAD_Y needs ksize 3 and cout a multiple of 64");
+        mp.nty = (d->h + 15) / 16;
+        return launch_conv_wy(mp, st);
+    }
     if (d->algo != SAVSR_CONV_DIRECT && d->algo != SAVSR_CONV_DIRECT_THROUGHPUT) return fail_arg("conv: unknown algo");
     const bool wide = cot == 64;
     if (d->ksize == 3 && wide) {

@@ -1,0 +1,557 @@
+// 3x3 convolution (stride 1, zero pad 1, cout a multiple of 64) on channel-last fp32 feature maps as a 1-D WINOGRAD F(2,3) ALONG Y
+// implicit GEMM on the bf16 matrix cores with split-precision ("bf16x3") operands -- the algebraic form of conv_mfma.hip's direct
+// kernel with 2/3 of its matrix work (savsr_conv_desc.algo = SAVSR_CONV_WINOGRAD_Y, round 4).
+//
+//   out rows (Y, Y+1) from input rows d0..d3 = Y-1 .. Y+2, per horizontal tap kx and input channel:
+//     V0 = d0 - d2,  V1 = d1 + d2,  V2 = d2 - d1,  V3 = d1 - d3                      (input transform, fp32, then (hi, lo) bf16 split)
+//     U0 = g0,  U1 = (g0 + g1 + g2) / 2,  U2 = (g0 - g1 + g2) / 2,  U3 = g2            (weights g_ky; float64 on the host, then split)
+//     M_i = sum_{kx, ci} U_i[co][ci][kx] * V_i[ci](x + kx - 1)                           (4 "positions" x 3 kx = 12 taps instead of 2 x 9)
+//     out(Y) = M0 + M1 + M2,  out(Y+1) = M1 - M2 - M3                                    (output transform, in registers)
+//
+// Why along y, and how it maps to a CU.  Workgroup = 8 waves = a 16-row x 32-pixel x 64-channel output tile; wave w owns the row
+// PAIR (2w, 2w+1), so its four transformed rows are built from its own four input rows and live in a WAVE-PRIVATE LDS region: no
+// activation is shared between waves (a Winograd form along x, or the 2-D form of round 2, shares transformed rows / needs its
+// weights per transform position in registers).  Only the weights are shared: per 16-channel phase the 12 taps are a 48 KB slab
+// in two halves (positions {0,1} | {2,3}), each half re-filled by LDS-DMA while the other is being read and published by its own
+// barrier -- 2 barriers per phase, none for the activations: positions {0,1} of the next phase are written while {2,3} of this
+// one are read and vice versa, so the 70 KB V image needs no double buffer (LDS: 70 + 48 + 37 KB epilogue slices = 152 KB).
+// Per (position, kx) step a wave reads 4 weight + 2 activation fragments and issues 6 MFMAs; 72 MFMAs per wave and phase against
+// 108 in the direct kernel for the same outputs; 8 accumulators (4 positions x 2 channel blocks = 128 registers).
+// Measured before it was built (tools/micro/conv_skel.hip, K-loop skeletons with the real staging traffic, one MI355X, steady
+// state): 897 us direct vs 753 us for this form (-16 %): the launch is power-limited, the matrix instructions are most of the
+// energy, and fewer of them buy clock (1.68 -> 1.80 GHz) on top of cycles (7.85 k -> 7.0 k per phase); fewer LDS fragment bytes at
+// equal MFMAs bought nothing (same skeleton file, "B reuse").
+//
+// Numerics: the same split products and fp32 accumulation as the direct kernel; the transforms add one fp32 rounding on the
+// activations (d0 - d2 ...) and the cancellation of the output transform: measured max-abs error 1.3-1.6 x the direct kernel's
+// (tests/test_gpu_kernels.py::test_conv2d_winograd_y), inside the same per-kernel bound.
+//
+// Replaces (when selected by the engine): the static-weight 3x3 convs of savsr_arch.py:388-397,429-442,480-483,541-543,567,723,733.
+#include "conv_common.hpp"
+
+#include <type_traits>
+
+// Timing experiments (results invalid; never set in a shipped build): 1 = no fragment reads in the steps, 2 = no transform / split / V stores,
+// 4 = no weight DMA in the steps, 8 = no row loads in the steps, 16 = no epilogue body.  Compare CYCLES (tools/ab_conv.py prints them):
+// constant operands also change the power draw and with it the clock.
+#ifndef WY_EXP
+#define WY_EXP 0
+#endif
+
+namespace savsr {
+
+namespace wy {
+constexpr int TH = 16, TW = 32, IC = TW + 2, NTHR = 512, COT = 64;
+constexpr int V_PLANE = 2 * IC;                    // 16-B units of one (half, row, part) plane: [q 2][px IC]
+constexpr int V_WAVE = 2 * 2 * 2 * V_PLANE;        // [hf][vr][part] planes per wave = 544 units
+constexpr int W_HALF = 6 * 2 * 2 * 64;             // [s = vr * 3 + kx][t][part][lane] = 1536 units = 24 KiB
+constexpr int W_PHASE = 2 * W_HALF;                // 48 KiB per (cob, chunk)
+constexpr int EPS = 36;                            // floats per pixel in an epilogue slice
+constexpr int LDS_UNITS = 8 * V_WAVE + 2 * W_HALF; // 7424 units = 118 784 B
+constexpr size_t LDS_BYTES = 16ull * LDS_UNITS + 4ull * 8 * 32 * EPS;      // + 36 864 B of epilogue slices = 155 648 B
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+}  // namespace wy
+
+__device__ __attribute__((aligned(16))) const float g_wy_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // what padding lanes load
+
+__device__ __forceinline__ void wy_split_store(const f32x4& v, bf16x4* hi_dst, bf16x4* lo_dst) {
+#if WY_EXP & 32
+    { union { f32x4 f; bf16x4 h[2]; } u; u.f = v; *hi_dst = u.h[0]; *lo_dst = u.h[1]; return; }      // timing: raw bits, no split arithmetic
+#endif
+#if WY_EXP & 128
+    { asm volatile("" :: "v"(v)); return; }                                                          // timing: the loaded value is waited for, nothing else
+#endif
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 hh = (__bf16)v[j];
+        hi[j] = hh;
+        lo[j] = (__bf16)(v[j] - (float)hh);
+    }
+#if WY_EXP & 64
+    asm volatile("" :: "v"(hi), "v"(lo));                                                              // timing: arithmetic kept, no LDS stores
+    return;
+#endif
+    *hi_dst = hi;
+    *lo_dst = lo;
+}
+
+__global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) {
+    using namespace wy;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16x8* smem = reinterpret_cast<bf16x8*>(smem_raw);       // [8 waves][V_WAVE] | [2][W_HALF] | epilogue slices
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+#ifndef WY_TSEL
+#define WY_TSEL 0
+#endif
+#if WY_TSEL
+    const int tsel = wave_s >> 2;                             // the sub-step of every step that carries this wave's staging work (see the phase body)
+#else
+    constexpr int tsel = 0;
+#endif
+    if (wave_s >= 4) __builtin_amdgcn_s_setprio(1);           // static priority for the younger half (conv_mfma.hip, CONV_PRIO)
+    const int tiles_per_cob = mp.ntx * mp.nty;
+    const int total = mp.nconv * mp.ncob * tiles_per_cob;
+    const int H = mp.h, W = mp.w;
+
+    struct TileInfo { int conv, cob, x0, y0, tx, ty; };
+    auto decode = [&](int tile) {
+        const int cc = tile / tiles_per_cob, rem = tile - cc * tiles_per_cob;
+        const int ty = rem / mp.ntx, tx = rem - ty * mp.ntx;
+        TileInfo ti;
+        ti.conv = cc / mp.ncob;
+        ti.cob = cc - ti.conv * mp.ncob;
+        ti.x0 = tx * TW;
+        ti.y0 = ty * TH;
+        ti.tx = tx;
+        ti.ty = ty;
+        return ti;
+    };
+
+    // ---- staging cursor: walks the phases (tile, source, 16-channel chunk) of this workgroup's tiles ---------------------------
+    // Per lane and tile: the pixel index of (input row d0, its column) for the two full rounds (column = (px c, channel quad q4):
+    // c = lane / 4 + 16 r, q4 = lane % 4) and for the tail (the 8 columns of c = 32, 33: lanes < 32 hold ONE (row, column) each).
+    f32x4 d[2][4], dx;
+    int st_pxb[2], st_pxt;                                    // pixel index of (row d0 [+ own row for the tail], x), or INVALID
+    constexpr int INVALID = -(1 << 30);
+    const float* st_base = nullptr;
+    const bf16x8* st_w = nullptr;
+    int st_pix = 0, st_cb = 0, st_src = 0, st_conv = 0, st_row0 = 0;
+    const int q4 = lane & 3;
+    auto stage_begin_tile = [&](const TileInfo& ti) {
+        st_conv = ti.conv;
+        st_src = 0;
+        st_cb = 0;
+        st_base = mp.c[ti.conv].src[0];
+        st_pix = mp.c[ti.conv].src_pix[0];
+        st_w = reinterpret_cast<const bf16x8*>(mp.c[ti.conv].wimg) + (long long)ti.cob * mp.nchunk * W_PHASE;
+        st_row0 = ti.y0 + 2 * wave_s - 1;                     // image row of d0 (scalar)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int x = ti.x0 - 1 + (lane >> 2) + 16 * r;
+            st_pxb[r] = (x >= 0 && x < W) ? st_row0 * W + x : INVALID;
+        }
+        {
+            const int x = ti.x0 - 1 + 32 + ((lane & 7) >> 2), row = st_row0 + ((lane >> 3) & 3);
+            st_pxt = (lane < 32 && x >= 0 && x < W && row >= 0 && row < H) ? row * W + x : INVALID;
+        }
+    };
+    auto stage_advance = [&]() {
+        st_cb += 16;
+        st_w += W_PHASE;
+        if (st_cb >= mp.src_ch) {
+            st_cb = 0;
+            ++st_src;
+            st_base = mp.c[st_conv].src[st_src];
+            st_pix = mp.c[st_conv].src_pix[st_src];
+        }
+    };
+    int st_tile = blockIdx.x, st_chunk = 0;
+    auto stage_next = [&]() -> bool {                         // cursor -> following phase; false (cursor unchanged) when the block has no more
+        if (st_chunk + 1 < mp.nchunk) { ++st_chunk; stage_advance(); return true; }
+        if (st_tile + (int)gridDim.x >= total) return false;
+        st_tile += gridDim.x;
+        st_chunk = 0;
+        stage_begin_tile(decode(st_tile));
+        return true;
+    };
+    // one load instruction per call and lane, always (padding reads 16 B of zeros): hipcc's wait insertion then counts exactly.  (Asm loads with
+    // hand-counted waits -- hipcc does not see the LDS-DMAs queued behind the rows, so its counts are short of them -- were tried: 304 k -> 322 k
+    // cycles per 6 x 128->64 launch, the 64-bit address pairs cost registers the loop does not have.)
+    auto load_at = [&](int pixel, bool ok) -> f32x4 {
+        const SAVSR_GLOBAL float* src = ok ? (const SAVSR_GLOBAL float*)st_base + (pixel * st_pix + st_cb + 4 * q4)
+                                           : (const SAVSR_GLOBAL float*)g_wy_zero16;
+        return *(const SAVSR_GLOBAL f32x4*)src;
+    };
+    auto issue_d = [&](int r) {                               // round r of the cursor's phase: rows d0..d3 of this lane's column
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ii = (WY_EXP & 256) ? (i == 0 ? 1 : (i == 3 ? 2 : i)) : i;      // timing knob: only the wave's own two rows are fetched (wrong results)
+            const bool row_ok = st_row0 + ii >= 0 && st_row0 + ii < H;          // scalar
+            d[r][i] = load_at(st_pxb[r] + ii * W, row_ok && st_pxb[r] != INVALID);
+        }
+    };
+    auto issue_dx = [&]() { dx = load_at(st_pxt, st_pxt != INVALID); };
+    // LDS byte offsets of this lane's staging stores inside a (hf, vr, part) plane of its wave's V region
+    bf16x8* vwave = smem + wave * V_WAVE;
+    constexpr int PLANE_B = V_PLANE * 16;                     // bytes per plane; plane index = (hf * 2 + vr) * 2 + part
+    // (byte offsets into the dynamic LDS block, not pointers: every access below is formed as smem_raw + offset, so hipcc keeps them LDS accesses)
+    const unsigned vst0 = (unsigned)(wave * V_WAVE + (q4 >> 1) * IC + (lane >> 2)) * 16u + (unsigned)(q4 & 1) * 8u;      // round r: + r * 16 px * 16 B
+    const unsigned vst_t = (unsigned)(wave * V_WAVE + (q4 >> 1) * IC + 32 + ((lane & 7) >> 2)) * 16u + (unsigned)(q4 & 1) * 8u;
+    auto vptr = [&](unsigned off) { return reinterpret_cast<bf16x4*>(smem_raw + off); };
+    // Transform + split + store.  Half B of a phase builds positions {0, 1} of the NEXT phase from the rows in d / dx (V0 = d0 - d2, V1 = d1 + d2) and, in
+    // place, the fp32 values of positions {2, 3} (V2 = d2 - d1 -> d[r][0], V3 = d1 - d3 -> d[r][1]: the other two row registers are dead from
+    // there on -- 18 instead of 36 staging registers live across the tile epilogue); half A of the next phase only splits and stores those.
+    auto store_pair = [&](int r, int hf, const f32x4& va, const f32x4& vb) {
+        const unsigned p0 = vst0 + (unsigned)(r * 256 + (hf * 2 + 0) * 2 * PLANE_B);
+        wy_split_store(va, vptr(p0), vptr(p0 + PLANE_B));
+        const unsigned p1 = vst0 + (unsigned)(r * 256 + (hf * 2 + 1) * 2 * PLANE_B);
+        wy_split_store(vb, vptr(p1), vptr(p1 + PLANE_B));
+    };
+    auto store_one = [&](int r, int hf, int vr, const f32x4& v) {
+        const unsigned p0 = vst0 + (unsigned)(r * 256 + (hf * 2 + vr) * 2 * PLANE_B);
+        wy_split_store(v, vptr(p0), vptr(p0 + PLANE_B));
+    };
+    auto store_v0 = [&](int r) { store_one(r, 0, 0, d[r][0] - d[r][2]); };          // (half B, piece 1) position 0 out; d0 is dead from here
+    auto store_v1 = [&](int r) {                                                     // (half B, piece 2) position 1 out, positions 2, 3 kept in place
+        store_one(r, 0, 1, d[r][1] + d[r][2]);
+        const f32x4 v2 = d[r][2] - d[r][1], v3 = d[r][1] - d[r][3];
+        d[r][0] = v2;
+        d[r][1] = v3;
+    };
+    auto store_v01 = [&](int r) { store_v0(r); store_v1(r); };
+    auto store_v23 = [&](int r) { store_pair(r, 1, d[r][0], d[r][1]); };      // (half A)
+    // the tail columns: lane l < 32 holds row l / 8 of column 128 + l % 8; the partner row comes by a cross-lane move.
+    //   positions 0, 1: lanes 0-7 (d0) take d2 from lane ^ 16 -> V0 = own - other; lanes 8-15 (d1) take d2 from lane ^ 24 -> V1 = own + other
+    //   positions 2, 3: lanes 16-23 (d2) take d1 from lane ^ 24 -> V2 = own - other; lanes 8-15 (d1) take d3 from lane ^ 16 -> V3 = own - other
+    const int grp = (lane >> 3) & 3;
+    auto tail_value = [&](int hf) -> f32x4 {
+        const int partner = hf == 0 ? (grp == 0 ? lane ^ 16 : lane ^ 24) : (grp == 2 ? lane ^ 24 : lane ^ 16);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = __shfl(dx[j], partner, 64);
+        return (hf == 0 && grp == 1) ? dx + o : dx - o;
+    };
+    auto tail_store = [&](int hf, const f32x4& v) {
+        const bool mine = lane < 32 && (hf == 0 ? grp < 2 : (grp == 2 || grp == 1));
+        const int vr = hf == 0 ? grp : (grp == 2 ? 0 : 1);
+        if (mine) {
+            const unsigned pp = vst_t + (unsigned)((hf * 2 + vr) * 2 * PLANE_B);
+            wy_split_store(v, vptr(pp), vptr(pp + PLANE_B));
+        }
+    };
+    auto store_vt01 = [&]() {                                 // (half B) positions 0, 1 out; dx <- this lane's value of positions 2, 3
+        const f32x4 v01 = tail_value(0), v23 = tail_value(1);
+        tail_store(0, v01);
+        dx = v23;
+    };
+    auto store_vt23 = [&]() { tail_store(1, dx); };           // (half A)
+    // weight slab half hf of the cursor's phase: 24 pieces of 1 KiB, 3 per wave, straight into LDS (the packed image IS the LDS image)
+    bf16x8* wlds = smem + 8 * V_WAVE;
+    auto issue_w = [&](int j, int hf) {
+        const int piece = wave_s * 3 + j;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(wlds + hf * W_HALF + piece * 64));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(st_w + hf * W_HALF + piece * 64 + lane), "s"(dst) : "memory");
+    };
+
+    // Fragment registers: per step s = (position-in-half, kx) one activation pair (hi, lo) and per sub-step (s, t) one weight pair; both
+    // double-buffered one SUB-step (3 MFMAs) ahead -- a whole step's six fragments twice over (48 registers) do not fit beside the 128
+    // accumulator registers and the 36 staging registers.
+    struct FragA { bf16x8 ah, al; };
+    struct FragB { bf16x8 bh, bl; };
+    const bf16x8* vrd = vwave + half * IC + px;               // + plane * V_PLANE + kx
+    const bf16x8* wrd = wlds + lane;
+    auto load_b = [&](int hf, int s, FragB& fr) {             // s = vr * 3 + kx
+        const int vr = s / 3, kx = s - 3 * vr;
+        fr.bh = vrd[((hf * 2 + vr) * 2 + 0) * V_PLANE + kx];
+        fr.bl = vrd[((hf * 2 + vr) * 2 + 1) * V_PLANE + kx];
+    };
+    auto load_a = [&](int hf, int s, int t, FragA& fr) {
+        fr.ah = wrd[hf * W_HALF + ((s * 2 + t) * 2 + 0) * 64];
+        fr.al = wrd[hf * W_HALF + ((s * 2 + t) * 2 + 1) * 64];
+    };
+
+    int tile = blockIdx.x;
+    FragA fa[2];
+    FragB fb[2];
+    if (tile < total) {
+        // prologue: WA(0) by DMA, rows of phase 0 -> VA(0) (positions 0, 1); VB(0) and WB(0) follow in half A of phase 0 like in every phase
+        stage_begin_tile(decode(tile));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) issue_w(j, 0);
+        issue_d(0);
+        issue_d(1);
+        issue_dx();
+        store_v01(0);
+        store_v01(1);
+        store_vt01();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tile < total) { load_b(0, 0, fb[0]); load_a(0, 0, 0, fa[0]); }
+
+    for (; tile < total; tile += gridDim.x) {
+        const TileInfo cur = decode(tile);
+        const ConvParams& p = mp.c[cur.conv];
+        const int cob = cur.cob, x0 = cur.x0, y0 = cur.y0;
+        f32x16 acc[4][2];                                     // [position][output-channel block]
+#pragma unroll
+        for (int pz = 0; pz < 4; ++pz)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[pz][t][i] = 0.f;
+        const bool rows_in = __builtin_amdgcn_readfirstlane(y0 + 2 * wave < H ? 1 : 0) != 0;      // the pair's first row inside the image
+        for (int chunk = 0; chunk < mp.nchunk; ++chunk) {
+            auto phase = [&](auto mm) {
+                constexpr bool MM = decltype(mm)::value;      // false: both rows below the image -> no matrix work (everything else as usual)
+                // TS: the sub-step (0 / 1) of every step that carries this wave's staging work.  Waves 0-3 take the first, waves 4-7 the second: the
+                // two waves of a SIMD (w, w + 4) then alternate between a sub-step of 3 MFMAs + ~25 vector instructions and one of 3 bare MFMAs, so
+                // the matrix pipe is fed by one while the other issues its transform / split arithmetic (with the staging in the same sub-step of
+                // both, the pair ran 23 vector instructions per MFMA there and nothing in the other: -118 k of 303 k cycles without the stores).
+                // (a scalar test per sub-step, not a second instantiation of the loop: four copies of it cost hipcc's allocator 460 spilled registers)
+                // staging work of (half, step); see the header for the schedule
+                auto pieces = [&](int hf, int s) {
+                    if (hf == 0) {
+                        // half A: WB of THIS phase by DMA (all three pieces at once: they must be older than the row loads of the next phase, so that
+                        // the barrier's counted wait -- vmcnt(9) -- covers the DMAs and nothing else); positions {2, 3} of this phase out of d (split +
+                        // store only); then, into the registers just released, the rows of the NEXT phase: 7-9 steps ahead of their first use
+                        if (s == 0) { issue_w(0, 1); issue_w(1, 1); issue_w(2, 1); store_v23(0); stage_next(); issue_d(0); }
+                        if (s == 1) { store_v23(1); issue_d(1); }
+                        if (s == 2) { store_vt23(); issue_dx(); }
+                    } else {
+                        // half B (cursor already advanced): WA of the next phase by DMA, one piece per step; positions {0, 1} of the next phase
+                        if (s < 3) issue_w(s, 0);
+                        if (s == 1) store_v0(0);
+                        if (s == 2) store_v1(0);
+                        if (s == 3) store_v0(1);
+                        if (s == 4) store_v1(1);
+                        if (s == 5) store_vt01();
+                    }
+                };
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) {
+                        const int pz = hf * 2 + s / 3;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            // sub-step (s, t): prefetch the fragments of the sub-steps ahead, then 3 MFMAs with this sub-step's staging pieces between them
+                            if (t == 1 && s == 5) {
+                                // the weight half DMA'd during this half (for the NEXT half to run) has landed; publish it.  Half A: the 9 row loads of
+                                // the next phase (steps 0-2) are younger and may fly on; half B: the DMAs are the youngest operations.
+                                if (hf == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                __syncthreads();
+                            }
+                            if (WY_EXP & 1) {
+                                asm volatile("" : "+v"(fa[0].ah), "+v"(fa[1].ah), "+v"(fb[0].bh), "+v"(fb[1].bh));
+                            } else if (t == 0) {
+                                load_a(hf, s, 1, fa[1]);
+                                if (s + 1 < 6) load_b(hf, s + 1, fb[(s + 1) & 1]);      // (the next step's activation pair: two sub-steps ahead)
+                            } else {
+                                if (s + 1 < 6) load_a(hf, s + 1, 0, fa[0]);
+                                else { load_b(hf ^ 1, 0, fb[(s + 1) & 1]); load_a(hf ^ 1, 0, 0, fa[0]); }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            const FragA& a = fa[t];
+                            const FragB& b = fb[s & 1];
+                            if (MM) acc[pz][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.al, b.bh, acc[pz][t], 0, 0, 0);
+                            if (t == tsel) pieces(hf, s);
+                            if (MM) acc[pz][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.ah, b.bl, acc[pz][t], 0, 0, 0);
+                            if (MM) acc[pz][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.ah, b.bh, acc[pz][t], 0, 0, 0);
+#pragma unroll
+                            for (int i = 0; i < (MM ? 3 : 0); ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);     // up to 10 VALU
+                                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // up to one DS write
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            };
+            if (rows_in) phase(std::true_type{}); else phase(std::false_type{});
+        }
+
+        // ---- output transform (in registers): row 0 = M0 + M1 + M2 -> acc[0], row 1 = M1 - M2 - M3 -> acc[3] ------------------
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float m1 = acc[1][t][i], m2 = acc[2][t][i];
+                acc[0][t][i] = (acc[0][t][i] + m1) + m2;
+                acc[3][t][i] = (m1 - m2) - acc[3][t][i];
+            }
+
+        // ---- epilogue: as the direct kernel's (conv_mfma.hip): transpose through the wave's LDS slice 32 channels at a time, whole
+        // pixel records out, fused bias / activation / per-pixel mask / two residuals / global-average-pool partials.  Rows of wave w:
+        // y0 + 2 w + r.  Every load below is unconditional and used on every path (absent operands read 16 B of zeros).
+        const float* e_bias = p.bias;
+        const float* e_mul = p.mul_px;
+        const float* e_r1 = p.res1;
+        const float* e_r2 = p.res2;
+        float* e_out = p.out;
+        float* e_pool = p.pool;
+        int e_act = p.act, e_opix = p.out_pix, e_r1pix = p.res1_pix, e_r2pix = p.res2_pix;
+        float e_slope = p.slope, e_r2s = p.res2_scale;
+        asm volatile("" : "+s"(e_bias), "+s"(e_mul), "+s"(e_r1), "+s"(e_r2), "+s"(e_out), "+s"(e_pool));
+        asm volatile("" : "+s"(e_act), "+s"(e_opix), "+s"(e_r1pix), "+s"(e_r2pix), "+s"(e_slope), "+s"(e_r2s));
+        const bool act_as_max = e_act == SAVSR_ACT_NONE || e_act == SAVSR_ACT_RELU || (e_act == SAVSR_ACT_LRELU && e_slope >= 0.f && e_slope <= 1.f);
+        const float slope_eff = e_act == SAVSR_ACT_NONE ? 1.f : (e_act == SAVSR_ACT_RELU ? 0.f : e_slope);
+        float* ep_base = reinterpret_cast<float*>(smem + LDS_UNITS);
+        float* ep = ep_base + wave * (32 * EPS);
+        const int c4 = lane & 7;
+        const bool x_inside = x0 + TW <= W;
+        const float* zero16 = (const float*)g_wy_zero16;
+        const float* b_base = e_bias ? e_bias : zero16;
+        const unsigned b_off = e_bias ? 4u * (unsigned)(cob * COT + 4 * c4) : 0u, b_step = e_bias ? 128u : 0u;
+        f32x4 bias4[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bias4[t] = ldg4(b_base, b_off + (unsigned)t * b_step);
+        __builtin_amdgcn_sched_barrier(0);         // (the loads below must not be hoisted above the transform: all 128 accumulator registers are live there)
+        const float* r1_base = e_r1 ? e_r1 : zero16;
+        constexpr int RR = 2;                      // residual quads of two (row, channel-group) steps in flight (a ring): the first two go out together.
+        f32x4 rr[RR][4];                           // (all four at once, into the registers of the accumulator sets the transform has retired: 22 spilled registers)
+        auto load_r1 = [&](int r, int t, f32x4 (&dst)[4]) {
+            const int y = y0 + 2 * wave_s + r;
+            const int co = cob * COT + 32 * t + 4 * c4;
+            const unsigned off0 = 4u * (unsigned)((y * W + x0 + (lane >> 3)) * e_r1pix + co), ustride = 32u * (unsigned)e_r1pix;
+            const bool row_ok = e_r1 && y < H && !(WY_EXP & 1024);      // (timing knob: no residual loads: the zero block instead)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = row_ok && (x_inside || x0 + (lane >> 3) + 8 * i < W);
+                dst[i] = ldg4(r1_base, ok ? off0 + (unsigned)i * ustride : 0u);
+            }
+        };
+#pragma unroll
+        for (int gi = 0; gi < RR; ++gi) load_r1(gi / 2, gi % 2, rr[gi]);
+        f32x4 psum[2][2];
+#pragma unroll
+        for (int r = 0; r < ((WY_EXP & 16) ? 0 : 2); ++r) {
+            const int y = y0 + 2 * wave_s + r;
+            const int pbase = y * W + x0 + (lane >> 3);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                psum[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int gi = r * 2 + t;
+                if (y >= H) {
+                    asm volatile("" :: "v"(bias4[t]), "v"(rr[gi % RR][0]), "v"(rr[gi % RR][1]), "v"(rr[gi % RR][2]), "v"(rr[gi % RR][3]));
+                    if (gi + RR < 4) load_r1((gi + RR) / 2, (gi + RR) % 2, rr[gi % RR]);
+                    continue;
+                }
+                const f32x16& a = r == 0 ? acc[0][t] : acc[3][t];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(ep + px * EPS + 8 * g + 4 * half) = v;
+                }
+                const int co = cob * COT + 32 * t + 4 * c4;
+                const f32x4 b4 = bias4[t];
+                const unsigned ooff0 = 4u * (unsigned)(pbase * e_opix + co), ostride = 32u * (unsigned)e_opix;
+                f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ih = 0; ih < 2; ++ih) {                  // two units (pixels pbase + 16 ih, + 8) at a time: register budget
+                    const int p0 = pbase + 16 * ih;
+                    const bool ok0 = x_inside || x0 + (lane >> 3) + 16 * ih < W, ok1 = x_inside || x0 + (lane >> 3) + 16 * ih + 8 < W;
+                    f32x4 v[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ep + ((lane >> 3) + 16 * ih + 8 * i) * EPS + 4 * c4);
+                        v[i] = a4 + b4;
+                    }
+                    if (e_act == SAVSR_ACT_NONE) {
+                    } else if (act_as_max) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const f32x4 sv = v[i] * slope_eff;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[i][q] = vmax_raw(v[i][q], sv[q]);
+                        }
+                    } else if (e_act == SAVSR_ACT_LRELU) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[i][q] = v[i][q] > 0.f ? v[i][q] : v[i][q] * e_slope;
+                    } else if (e_act == SAVSR_ACT_SIGMOID) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[i][q] = sigmoidf_(v[i][q]);
+                    }
+                    if (e_mul) {
+                        const float m0 = ok0 ? ldg1(e_mul, (unsigned)p0) : 0.f, m1 = ok1 ? ldg1(e_mul, (unsigned)(p0 + 8)) : 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[0][q] *= m0; v[1][q] *= m1; }
+                    }
+                    v[0] += rr[gi % RR][2 * ih];
+                    v[1] += rr[gi % RR][2 * ih + 1];
+                    if (e_r2) {
+                        f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+                        if (ok0) ra = ldg4(e_r2, 4u * (unsigned)(p0 * e_r2pix + co));
+                        if (ok1) rb = ldg4(e_r2, 4u * (unsigned)((p0 + 8) * e_r2pix + co));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[0][q] += e_r2s * ra[q]; v[1][q] += e_r2s * rb[q]; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (i == 0 ? ok0 : ok1) {
+                            if (WY_EXP & 512) asm volatile("" :: "v"(v[i])); else       // (timing knob: no output stores)
+                            stg4(e_out, ooff0 + (unsigned)(2 * ih + i) * ostride, v[i]);
+                            if (e_pool) ps += v[i];
+                        }
+                    }
+                }
+                psum[r][t] = ps;
+                if (gi + RR < 4) load_r1((gi + RR) / 2, (gi + RR) % 2, rr[gi % RR]);       // the ring slot is free: next residual group out
+            }
+        }
+        if (WY_EXP & 16) {
+            asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][0][0]), "v"(acc[0][1][5]), "v"(acc[3][1][7]), "v"(bias4[0]), "v"(bias4[1]), "v"(rr[0][0]), "v"(rr[0][1]), "v"(rr[0][2]), "v"(rr[0][3]));
+        } else if (e_pool) {
+            // AdaptiveAvgPool2d(1) partials (savsr_arch.py:146,515): one row per 8-row band and 32-pixel column of the image, as the direct
+            // kernel writes them (same row numbering: savsr_conv_pool_blocks); band of wave w's rows = w / 4; waves summed in wave order
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) {
+                        psum[r][t][0] += __shfl_xor(psum[r][t][0], o, 64); psum[r][t][1] += __shfl_xor(psum[r][t][1], o, 64);
+                        psum[r][t][2] += __shfl_xor(psum[r][t][2], o, 64); psum[r][t][3] += __shfl_xor(psum[r][t][3], o, 64);
+                    }
+            __syncthreads();                         // every wave is done with its transpose slice
+            float* pl_ = ep_base;
+            if (lane < 8)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4*>(pl_ + (wave * 2 + r) * COT + 32 * t + 4 * lane) = psum[r][t];
+            __syncthreads();
+            if (tid < 2 * COT) {
+                const int bl = tid / COT, ch = tid - bl * COT;
+                float sacc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sacc += pl_[(bl * 8 + k) * COT + ch];       // waves 4 bl .. 4 bl + 3, rows r = 0, 1 each
+                const int band = cur.ty * 2 + bl;
+                if (band * 8 < H) stg1(e_pool, (unsigned)((band * mp.ntx + cur.tx) * p.pool_stride + cob * COT + ch), sacc);
+            }
+            __syncthreads();                         // the slices are reused by the next tile's epilogue
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last phases re-stage unconditionally: no LDS-DMA may be in flight when the LDS is released
+}
+
+int launch_conv_wy(const MultiConvParams& mp, hipStream_t st) {
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wy_kernel), (int)wy::LDS_BYTES, "conv_wy")) return rc;
+    const int total = mp.nconv * mp.ncob * mp.ntx * mp.nty;
+    const int grid = total < CONV_PERSISTENT_BLOCKS ? total : CONV_PERSISTENT_BLOCKS;
+    hipLaunchKernelGGL(conv_wy_kernel, dim3(grid), dim3(wy::NTHR), wy::LDS_BYTES, st, mp);
+    return check_launch("conv_wy_kernel");
+}
+int conv_wy_prepare_device() {
+    return ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wy_kernel), (int)wy::LDS_BYTES, "conv_wy");
+}
+
+}  // namespace savsr
+
+using namespace savsr;
+
+// Elements PER PART of the Winograd-y weight image: [cob][chunk][hf 2][s = vr * 3 + kx 6][t 2][part][512]: 12 taps instead of 9.
+extern "C" int64_t savsr_conv_wy_packed_elems(int cout, int cin) {
+    if (cout <= 0 || cout % 64 || cin <= 0 || cin % 16) return -1;
+    return (int64_t)(cout / 64) * (cin / 16) * 12 * 16 * 64;
+}
+// Position of U[pos][co][ci][kx] (pos = Winograd position 0..3) inside ONE part; the hi part of a (.., t) group of 512 elements is
+// followed by its lo part, as in savsr_conv_pack_index.
+extern "C" int64_t savsr_conv_wy_pack_index(int cout, int cin, int co, int ci, int pos, int kx) {
+    const int64_t nchunk = cin / 16;
+    const int cob = co / 64, col = co % 64, t = col / 32, row = col % 32;
+    const int chunk = ci / 16, cl = ci % 16, kh = cl / 8, j = cl % 8;
+    const int hf = pos / 2, vr = pos % 2, s = vr * 3 + kx;
+    const int64_t group = ((((int64_t)(cob * nchunk + chunk) * 2 + hf) * 6 + s) * 2 + t);
+    return group * 512 + (kh * 32 + row) * 8 + j;
+}

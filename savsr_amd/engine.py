@@ -105,6 +105,46 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return split_bf16_image(pack_conv_part(w))
 
 
+_WY_IDX_CACHE: Dict[tuple, tuple] = {}
+
+
+def conv_wy_pack_index(cout: int, cin: int):
+    """Index map [4 pos, cout, cin, 3 kx] -> position inside one part of the Winograd-y weight image (mirror of
+    savsr_conv_wy_pack_index): [cob][chunk][hf][s = vr * 3 + kx][t] groups of 512 = (kh * 32 + row) * 8 + j."""
+    key = (cout, cin)
+    if key not in _WY_IDX_CACHE:
+        if cout % 64 or cin % 16:
+            raise ValueError("Winograd-y conv image: cout must be a multiple of 64 and cin of 16")
+        nchunk = cin // 16
+        pos = np.arange(4, dtype=np.int64)[:, None, None, None]
+        co = np.arange(cout, dtype=np.int64)[None, :, None, None]
+        ci = np.arange(cin, dtype=np.int64)[None, None, :, None]
+        kx = np.arange(3, dtype=np.int64)[None, None, None, :]
+        cob, col = co // 64, co % 64
+        t, row = col // 32, col % 32
+        chunk, cl = ci // 16, ci % 16
+        kh, j = cl // 8, cl % 8
+        hf, vr = pos // 2, pos % 2
+        group = (((cob * nchunk + chunk) * 2 + hf) * 6 + (vr * 3 + kx)) * 2 + t
+        idx = group * 512 + (kh * 32 + row) * 8 + j
+        total = (cout // 64) * nchunk * 12 * 16 * 64
+        _WY_IDX_CACHE[key] = (np.ascontiguousarray(np.broadcast_to(idx, (4, cout, cin, 3))).reshape(-1), total)
+    return _WY_IDX_CACHE[key]
+
+
+def pack_conv_weight_wy(w: torch.Tensor) -> torch.Tensor:
+    """[cout, cin, 3, 3] -> split-bf16 Winograd-y weight image (SAVSR_CONV_WINOGRAD_Y): the F(2,3) weight transform over the tap ROWS
+    g_ky in float64 -- U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2, per kx -- rounded to fp32, then (hi, lo)."""
+    cout, cin, ks, _ = w.shape
+    assert ks == 3
+    g = w.detach().to("cpu", torch.float64).numpy()                       # [co][ci][ky][kx]
+    u = np.stack([g[:, :, 0], 0.5 * (g[:, :, 0] + g[:, :, 1] + g[:, :, 2]), 0.5 * (g[:, :, 0] - g[:, :, 1] + g[:, :, 2]), g[:, :, 2]], 0)   # [pos][co][ci][kx]
+    idx, total = conv_wy_pack_index(cout, cin)
+    part = np.zeros(total, dtype=np.float32)
+    part[idx] = u.astype(np.float32).reshape(-1)
+    return split_bf16_image(torch.from_numpy(part))
+
+
 def acc_row(r: int, half: int) -> int:
     """Row of register r of a 32x32 MFMA accumulator for lane half `half`."""
     return (r & 3) + 8 * (r >> 2) + 4 * half
@@ -151,6 +191,8 @@ class HipEngine:
         # SATU in the row-summed tail form (savsr_satu_hr_tail_q + savsr_tail_gather_q: 9 planes + seams between the HR stage and the
         # tail instead of 27 planes); SAVSR_SATU_Q=0: the 27-plane form
         self.satu_q = os.environ.get("SAVSR_SATU_Q", "1") != "0"
+        # static-weight 3x3 convs in the Winograd F(2,3)-along-y form (SAVSR_CONV_WINOGRAD_Y); SAVSR_CONV_WY=0: the direct kernel everywhere
+        self.conv_wy = os.environ.get("SAVSR_CONV_WY", "1") != "0"
         self.n_streams = max(1, int(os.environ.get("SAVSR_STREAMS", "3")))   # clips of a batch in flight concurrently
         self._siblings: List["HipEngine"] = []
         self._streams: List[torch.cuda.Stream] = []
@@ -175,7 +217,12 @@ class HipEngine:
 
     def _register(self, key: str, w: torch.Tensor, b: Optional[torch.Tensor]):
         cout, cin, ks, _ = w.shape
-        self.pw[key] = (self._dev(pack_conv_weight(w), torch.int16), None if b is None else self._dev(b), cout, cin, ks)
+        bias = None if b is None else self._dev(b)
+        if self.conv_wy and ks == 3 and cout % 64 == 0 and cin % 16 == 0:
+            # static 3x3 weights: the Winograd F(2,3)-along-y form (conv_wy.hip), 2/3 of the matrix work; the algo travels with the weights
+            self.pw[key] = (self._dev(pack_conv_weight_wy(w), torch.int16), bias, cout, cin, ks, _lib.CONV_WINOGRAD_Y)
+        else:
+            self.pw[key] = (self._dev(pack_conv_weight(w), torch.int16), bias, cout, cin, ks)
 
     def _add_conv(self, sd, key: str, bn: Optional[str] = None):
         w, b = self._fold(sd, key, bn)

@@ -115,6 +115,80 @@ def test_conv2d_batch_wide_tiles(eng):
         assert _maxerr(parts[k].sum(0).cpu() / (h * w), refs[k].mean(dim=(1, 2))) < 2e-5
 
 
+@pytest.mark.parametrize("cin,cout,nsrc,h,w", [
+    (64, 64, 1, 10, 12), (192, 64, 3, 9, 40), (128, 64, 2, 12, 33), (320, 128, 5, 8, 35), (16, 128, 1, 13, 31),
+    (128, 64, 1, 19, 11), (64, 64, 1, 50, 70), (128, 64, 2, 33, 65), (64, 64, 1, 1, 1), (64, 64, 1, 16, 32), (64, 64, 1, 17, 33)])
+def test_conv2d_winograd_y(eng, cin, cout, nsrc, h, w):
+    """SAVSR_CONV_WINOGRAD_Y (conv_wy.hip: F(2,3) along y on the split-bf16 matrix products) vs F.conv2d fp32 incl. the fused epilogue,
+    same bound as the direct kernel (3e-5 absolute on outputs of magnitude ~4), and vs the direct kernel on the same inputs."""
+    from savsr_amd import engine as E
+    from savsr_amd import _lib
+    from savsr_amd._lib import ACT_LRELU
+    g = np.random.RandomState(cin * 7 + cout + h)
+    wt = torch.from_numpy((g.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
+    bias = torch.from_numpy(g.standard_normal(cout).astype(np.float32))
+    x = torch.from_numpy(g.standard_normal((cin, h, w)).astype(np.float32))
+    res = torch.from_numpy(g.standard_normal((cout, h, w)).astype(np.float32))
+    res2 = torch.from_numpy(g.standard_normal((cout, h, w)).astype(np.float32))
+    mul = torch.from_numpy(g.uniform(0, 1, (h, w)).astype(np.float32))
+    ref = F.leaky_relu(F.conv2d(x[None].double(), wt.double(), bias.double(), padding=1), 0.2)[0] * mul.double() + res.double() + 0.9 * res2.double()
+    sch = cin // nsrc
+    xall = cl(x)
+    srcs = [eng.full(xall, sch, i * sch) for i in range(nsrc)]
+    errs = []
+    for weights in ((_dev(E.pack_conv_weight_wy(wt)), _dev(bias), cout, cin, 3, _lib.CONV_WINOGRAD_Y), (_dev(E.pack_conv_weight(wt)), _dev(bias), cout, cin, 3)):
+        wide = torch.full((h, w, cout + 4), float("nan"), device="cuda:0")
+        out = E.Src(wide, cout, cout + 4, 4)
+        eng.conv("test", srcs, out, h, w, ACT_LRELU, 0.2, mul_px=_dev(mul), res1=eng.full(cl(res)), res2=eng.full(cl(res2)), res2_scale=0.9, weights=weights)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(wide[..., :4]).all())                        # nothing written outside the channel slice
+        errs.append(float((pl(wide[..., 4:4 + cout]).double() - ref).abs().max()))
+    print('conv winograd-y', cin, cout, h, w, 'max-abs', errs[0], 'direct', errs[1])
+    assert errs[0] < 3e-5          # measured 1.0 - 2.3e-5 (direct: 0.8 - 1.8e-5) on outputs of magnitude ~4
+
+
+def test_conv2d_winograd_y_batch_and_pool(eng):
+    """A savsr_conv2d_batch of Winograd-y convs on a ragged image (90 x 330: partial last band and column, rows below the image):
+    each conv vs F.conv2d, bit-identical -- outputs AND fused pool rows -- to the same convs launched one by one, re-run bitwise
+    stable, and the pool rows sum to the output's channel means."""
+    from savsr_amd import engine as E
+    from savsr_amd import _lib
+    from savsr_amd._lib import ACT_LRELU
+    g = np.random.RandomState(78)
+    h, w, cin, cout, n = 90, 330, 128, 64, 4
+    rows = eng.pool_rows(h, w)
+    xs, descs, singles, outs, outs1, parts, parts1, refs = [], [], [], [], [], [], [], []
+    for k in range(n):
+        wt = torch.from_numpy((g.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
+        bias = torch.from_numpy(g.standard_normal(cout).astype(np.float32))
+        x = torch.from_numpy(g.standard_normal((cin, h, w)).astype(np.float32))
+        res = torch.from_numpy(g.standard_normal((cout, h, w)).astype(np.float32))
+        refs.append(F.leaky_relu(F.conv2d(x[None], wt, bias, padding=1), 0.2)[0] + res)
+        xall, rcl = cl(x), cl(res)
+        srcs = [eng.full(xall, 64, 0), eng.full(xall, 64, 64)]
+        weights = (_dev(E.pack_conv_weight_wy(wt)), _dev(bias), cout, cin, 3, _lib.CONV_WINOGRAD_Y)
+        xs.append((xall, rcl, weights))
+        for outl, partl, dl in ((outs, parts, descs), (outs1, parts1, singles)):
+            o = torch.full((h, w, cout), float("nan"), device="cuda:0")
+            pt = torch.full((rows, cout), float("nan"), device="cuda:0")
+            outl.append(o)
+            partl.append(pt)
+            dl.append(eng.conv_desc("t", srcs, eng.full(o), h, w, ACT_LRELU, 0.2, res1=eng.full(rcl), weights=weights, pool=(pt, 0, cout)))
+    eng.conv_launch(descs)
+    for d in singles:
+        eng.conv_launch([d])
+    torch.cuda.synchronize()
+    first = [o.clone() for o in outs]
+    for _ in range(20):
+        eng.conv_launch(descs)
+    torch.cuda.synchronize()
+    for k in range(n):
+        assert _maxerr(pl(outs[k]), refs[k]) < 3e-5
+        assert torch.equal(outs[k], outs1[k]) and torch.equal(outs[k], first[k])
+        assert torch.equal(parts[k], parts1[k])
+        assert _maxerr(parts[k].sum(0).cpu() / (h * w), refs[k].mean(dim=(1, 2))) < 2e-5
+
+
 def test_conv2d_rejects_bad_args(eng):
     from savsr_amd._lib import ConvDesc
     d = ConvDesc()

@@ -51,6 +51,34 @@ def test_pack_index_matches_c_abi():
             assert view[a, b, c] == lib.savsr_conv_pack_index(co, ci, ks, a, b, c)
 
 
+def test_winograd_y_pack_index_and_transform():
+    """The Winograd-y weight image (SAVSR_CONV_WINOGRAD_Y): the host packer's index map mirrors savsr_conv_wy_pack_index, and the
+    packed U satisfy F(2,3)'s identity -- for any four input rows d, (d0 - d2) U0 + (d1 + d2) U1 + (d2 - d1) U2 = d0 g0 + d1 g1 + d2 g2 and
+    (d1 + d2) U1 - (d2 - d1) U2 - (d1 - d3) U3 = d1 g0 + d2 g1 + d3 g2 -- to the split-bf16 precision."""
+    lib = _lib.load()
+    rng = np.random.RandomState(1)
+    for (co, ci) in [(64, 64), (64, 192), (128, 16), (128, 320)]:
+        idx, total = E.conv_wy_pack_index(co, ci)
+        assert total == lib.savsr_conv_wy_packed_elems(co, ci)
+        assert len(np.unique(idx)) == len(idx) and idx.max() < total and len(idx) == total        # 12 taps, no padding
+        view = idx.reshape(4, co, ci, 3)
+        for _ in range(40):
+            a, b, c, e = rng.randint(4), rng.randint(co), rng.randint(ci), rng.randint(3)
+            assert view[a, b, c, e] == lib.savsr_conv_wy_pack_index(co, ci, b, c, a, e)
+    assert lib.savsr_conv_wy_packed_elems(32, 64) == -1 and lib.savsr_conv_wy_packed_elems(64, 24) == -1
+    w = torch.from_numpy(rng.standard_normal((64, 32, 3, 3)).astype(np.float32))
+    img = E.pack_conv_weight_wy(w).view(torch.bfloat16).view(-1, 2, 512).double()
+    idx, total = E.conv_wy_pack_index(64, 32)
+    u = (img[:, 0] + img[:, 1]).reshape(-1)[torch.from_numpy(idx)].reshape(4, 64, 32, 3)              # [pos][co][ci][kx]
+    g = w.double()
+    d = torch.from_numpy(rng.standard_normal(4))
+    y0 = (d[0] - d[2]) * u[0] + (d[1] + d[2]) * u[1] + (d[2] - d[1]) * u[2]
+    y1 = (d[1] + d[2]) * u[1] - (d[2] - d[1]) * u[2] - (d[1] - d[3]) * u[3]
+    r0 = d[0] * g[:, :, 0] + d[1] * g[:, :, 1] + d[2] * g[:, :, 2]
+    r1 = d[1] * g[:, :, 0] + d[2] * g[:, :, 1] + d[3] * g[:, :, 2]
+    assert float((y0 - r0).abs().max()) < 1e-4 and float((y1 - r1).abs().max()) < 1e-4
+
+
 def test_invalid_arguments_are_rejected_without_gpu():
     lib = _lib.load()
     assert lib.savsr_conv2d(None, None) == -1

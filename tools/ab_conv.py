@@ -44,12 +44,14 @@ def main():
     ap.add_argument("--h", type=int, default=180)
     ap.add_argument("--w", type=int, default=320)
     ap.add_argument("--throughput", action="store_true", help="algo = CONV_DIRECT_THROUGHPUT (16-row tiles from 100 tiles up)")
+    ap.add_argument("--only-wy", action="store_true", help="with --wy: the first library's direct form, then only the Winograd-y forms")
+    ap.add_argument("--wy", action="store_true", help="also time every library's Winograd-y form (SAVSR_CONV_WINOGRAD_Y) of the same convs")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     eng = E.HipEngine(synth.synth_state_dict(), SAVSR().cfg, dev)
     if a.throughput:
         eng.conv_algo = _lib.CONV_DIRECT_THROUGHPUT
-    libs = [(os.path.basename(p), bind(os.path.join(ROOT, p) if not os.path.isabs(p) else p)) for p in a.libs]
+    libs_in = [(os.path.basename(p), bind(os.path.join(ROOT, p) if not os.path.isabs(p) else p)) for p in a.libs]
     probe_stream = torch.cuda.Stream(device=dev)
     probe_buf = torch.zeros(16, dtype=torch.int64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
@@ -58,7 +60,7 @@ def main():
         nb, cin = (int(v) for v in shape.split("x"))
         g = torch.Generator().manual_seed(0)
         nsrc = max(1, cin // 64)
-        keep, descs, outs = [], [], []
+        keep, descs, descs_wy, outs = [], [], [], []
         for k in range(nb):                                   # distinct inputs / weights per conv, bias + LeakyReLU + residual
             wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
             weights = (E.pack_conv_weight(wt).to(dev), torch.randn(cout, generator=g).to(dev), cout, cin, 3)
@@ -67,11 +69,22 @@ def main():
             keep.append((weights, xs, res))
             outs.append(out)
             descs.append(eng.conv_desc("bench", [eng.full(x) for x in xs], eng.full(out), h, w, ACT_LRELU, 0.2, res1=eng.full(res), weights=weights))
-        arr = (ConvDesc * nb)(*descs)
+            if a.wy:
+                wy = (E.pack_conv_weight_wy(wt).to(dev), weights[1], cout, cin, 3, _lib.CONV_WINOGRAD_Y)
+                keep.append(wy)
+                descs_wy.append(eng.conv_desc("bench", [eng.full(x) for x in xs], eng.full(out), h, w, ACT_LRELU, 0.2, res1=eng.full(res), weights=wy))
+        arr0 = (ConvDesc * nb)(*descs)
+        variants = [(n, l, arr0) for n, l in libs_in]
+        if a.wy:
+            arr1 = (ConvDesc * nb)(*descs_wy)
+            variants += [(n + " [winograd-y]", l, arr1) for n, l in libs_in]
+            if a.only_wy:
+                variants = variants[:1] + variants[len(libs_in):]
+        libs = [(n, (l, ar)) for n, l, ar in variants]
         times = {n: [] for n, _ in libs}
         clocks = {n: [] for n, _ in libs}
         ref, diffs = None, {}
-        for name, lib in libs:
+        for name, (lib, arr) in libs:
             rc = lib.savsr_conv2d_batch(arr, nb, st)
             assert rc == 0, (name, rc, lib.savsr_last_error())
             torch.cuda.synchronize()
@@ -82,7 +95,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for r in range(a.rounds):
             order = libs if r % 2 == 0 else libs[::-1]
-            for name, lib in order:
+            for name, (lib, arr) in order:
                 for _ in range(3):
                     lib.savsr_conv2d_batch(arr, nb, st)
                 torch.cuda.synchronize()

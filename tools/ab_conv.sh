@@ -10,7 +10,7 @@ i=0
 for fl in "$@"; do
   i=$((i+1))
   if [ ! -f "savsr_amd/csrc/libsavsr_hip_exp_v$i.so" ] || [ "${AB_REBUILD:-1}" = "1" ]; then
-    EXTRA_FLAGS="$fl" EXTRA_ONLY="conv_mfma.hip" OBJDIR=exp_v$i OUT=libsavsr_hip_exp_v$i.so bash savsr_amd/csrc/build.sh >/dev/null || exit 1
+    EXTRA_FLAGS="$fl" EXTRA_ONLY="${AB_ONLY:-conv_mfma.hip}" OBJDIR=exp_v$i OUT=libsavsr_hip_exp_v$i.so bash savsr_amd/csrc/build.sh >/dev/null || exit 1
   fi
   echo "variant v$i: $fl"
   LIBS="$LIBS savsr_amd/csrc/libsavsr_hip_exp_v$i.so"
