@@ -54,6 +54,15 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 __device__ __attribute__((aligned(16))) const float g_wy_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // what padding lanes load
 
+#if WY_EXP & 2048
+// instrumented experiment build: per (workgroup, wave) accumulated s_memtime of 8 sections (savsr_debug_read_wy_stamps):
+// 0 half A steps 0-4 | 1 half A wait + barrier | 2 half A step 5 rest | 3 half B steps 0-4 | 4 half B wait + barrier | 5 half B step 5 rest | 6 transform + epilogue | 7 total
+__device__ long long g_wy_stamps[256 * 8 * 8];
+#define WY_MARK(i) do { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); wy_sec[i] += t_now - wy_prev; wy_prev = t_now; } while (0)
+#else
+#define WY_MARK(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void wy_split_store(const f32x4& v, bf16x4* hi_dst, bf16x4* lo_dst) {
 #if WY_EXP & 32
     { union { f32x4 f; bf16x4 h[2]; } u; u.f = v; *hi_dst = u.h[0]; *lo_dst = u.h[1]; return; }      // timing: raw bits, no split arithmetic
@@ -82,15 +91,12 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     bf16x8* smem = reinterpret_cast<bf16x8*>(smem_raw);       // [8 waves][V_WAVE] | [2][W_HALF] | epilogue slices
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-#ifndef WY_TSEL
-#define WY_TSEL 0
+#ifndef WY_PRIO
+#define WY_PRIO 1
 #endif
-#if WY_TSEL
-    const int tsel = wave_s >> 2;                             // the sub-step of every step that carries this wave's staging work (see the phase body)
-#else
-    constexpr int tsel = 0;
-#endif
+#if WY_PRIO
     if (wave_s >= 4) __builtin_amdgcn_s_setprio(1);           // static priority for the younger half (conv_mfma.hip, CONV_PRIO)
+#endif
     const int tiles_per_cob = mp.ntx * mp.nty;
     const int total = mp.nconv * mp.ncob * tiles_per_cob;
     const int H = mp.h, W = mp.w;
@@ -164,13 +170,14 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
                                            : (const SAVSR_GLOBAL float*)g_wy_zero16;
         return *(const SAVSR_GLOBAL f32x4*)src;
     };
-    auto issue_d = [&](int r) {                               // round r of the cursor's phase: rows d0..d3 of this lane's column
+    auto issue_row = [&](int r, int i) {                      // round r of the cursor's phase, row d_i of this lane's column
+        if ((WY_EXP & 256) && (i == 0 || i == 3)) { asm volatile("" : "+v"(d[r][i])); return; }     // timing knob: rows d0, d3 are not loaded (5 instead of 9 loads; vmcnt counts then over-wait)
+        const bool row_ok = st_row0 + i >= 0 && st_row0 + i < H && !(WY_EXP & 4096);                 // timing knob 4096: every row load reads the 16-B zero block (L1 hits)
+        d[r][i] = load_at(st_pxb[r] + i * W, row_ok && st_pxb[r] != INVALID);
+    };
+    auto issue_d = [&](int r) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ii = (WY_EXP & 256) ? (i == 0 ? 1 : (i == 3 ? 2 : i)) : i;      // timing knob: only the wave's own two rows are fetched (wrong results)
-            const bool row_ok = st_row0 + ii >= 0 && st_row0 + ii < H;          // scalar
-            d[r][i] = load_at(st_pxb[r] + ii * W, row_ok && st_pxb[r] != INVALID);
-        }
+        for (int i = 0; i < 4; ++i) issue_row(r, i);
     };
     auto issue_dx = [&]() { dx = load_at(st_pxt, st_pxt != INVALID); };
     // LDS byte offsets of this lane's staging stores inside a (hf, vr, part) plane of its wave's V region
@@ -255,6 +262,11 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     };
 
     int tile = blockIdx.x;
+#if WY_EXP & 2048
+    long long wy_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long wy_prev = (long long)__builtin_amdgcn_s_memtime();
+    const long long wy_t0 = wy_prev;
+#endif
     FragA fa[2];
     FragB fb[2];
     if (tile < total) {
@@ -288,20 +300,23 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
         for (int chunk = 0; chunk < mp.nchunk; ++chunk) {
             auto phase = [&](auto mm) {
                 constexpr bool MM = decltype(mm)::value;      // false: both rows below the image -> no matrix work (everything else as usual)
-                // TS: the sub-step (0 / 1) of every step that carries this wave's staging work.  Waves 0-3 take the first, waves 4-7 the second: the
-                // two waves of a SIMD (w, w + 4) then alternate between a sub-step of 3 MFMAs + ~25 vector instructions and one of 3 bare MFMAs, so
-                // the matrix pipe is fed by one while the other issues its transform / split arithmetic (with the staging in the same sub-step of
-                // both, the pair ran 23 vector instructions per MFMA there and nothing in the other: -118 k of 303 k cycles without the stores).
-                // (a scalar test per sub-step, not a second instantiation of the loop: four copies of it cost hipcc's allocator 460 spilled registers)
-                // staging work of (half, step); see the header for the schedule
+                // Staging work of (half, step).  Two rules, both from the section stamps (WY_EXP 2048):
+                //  * at most TWO vector-memory instructions per wave and step: with the three DMAs and the nine row loads of a phase in steps 0-2 the
+                //    eight waves queued 96 KB on the CU's address path at once and every wave stalled at issue in front of its MFMAs (half A 5.1 k
+                //    cycles per phase against 3.2 k for half B, which carries more arithmetic);
+                //  * the transform / split arithmetic of a step is spread over all SIX of its MFMAs (one scheduling region per step, sched_group_barrier
+                //    pipeline below): placed in one 3-MFMA sub-step it ran 28 vector instructions beside 3 MFMAs in BOTH waves of a SIMD at once.
                 auto pieces = [&](int hf, int s) {
                     if (hf == 0) {
-                        // half A: WB of THIS phase by DMA (all three pieces at once: they must be older than the row loads of the next phase, so that
-                        // the barrier's counted wait -- vmcnt(9) -- covers the DMAs and nothing else); positions {2, 3} of this phase out of d (split +
-                        // store only); then, into the registers just released, the rows of the NEXT phase: 7-9 steps ahead of their first use
-                        if (s == 0) { issue_w(0, 1); issue_w(1, 1); issue_w(2, 1); store_v23(0); stage_next(); issue_d(0); }
-                        if (s == 1) { store_v23(1); issue_d(1); }
-                        if (s == 2) { store_vt23(); issue_dx(); }
+                        // half A: WB of THIS phase by DMA first (the three pieces must be older than the row loads of the next phase, so that the barrier's
+                        // counted wait -- vmcnt(8) -- covers the DMAs and nothing else); positions {2, 3} of this phase out of d (split + store only);
+                        // then, into the registers just released, the rows of the NEXT phase
+                        if (s == 0) { issue_w(0, 1); issue_w(1, 1); store_v23(0); }
+                        if (s == 1) { issue_w(2, 1); stage_next(); issue_row(0, 0); }
+                        if (s == 2) { store_v23(1); issue_row(0, 1); issue_row(0, 2); }
+                        if (s == 3) { store_vt23(); issue_row(0, 3); issue_row(1, 0); }
+                        if (s == 4) { issue_row(1, 1); issue_row(1, 2); }
+                        if (s == 5) issue_row(1, 3);              // (sub-step (5, 0); the tail load follows the barrier)
                     } else {
                         // half B (cursor already advanced): WA of the next phase by DMA, one piece per step; positions {0, 1} of the next phase
                         if (s < 3) issue_w(s, 0);
@@ -309,49 +324,72 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
                         if (s == 2) store_v1(0);
                         if (s == 3) store_v0(1);
                         if (s == 4) store_v1(1);
-                        if (s == 5) store_vt01();
+                        if (s == 5) store_vt01();                 // (sub-step (5, 0))
+                    }
+                };
+                auto mma3 = [&](int pz, int t, int sb) {
+                    const FragA& a = fa[t];
+                    const FragB& b = fb[sb];
+                    if (MM) {
+                        acc[pz][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.al, b.bh, acc[pz][t], 0, 0, 0);
+                        acc[pz][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.ah, b.bl, acc[pz][t], 0, 0, 0);
+                        acc[pz][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.ah, b.bh, acc[pz][t], 0, 0, 0);
                     }
                 };
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-                    for (int s = 0; s < 6; ++s) {
+                    for (int s = 0; s < 5; ++s) {
+                        // step s < 5, one scheduling region: fragments of sub-step (s, 1) and the next step's activation pair first, 3 MFMAs, the
+                        // next step's first weight pair (into the registers the first three MFMAs have read), 3 MFMAs; the staging work between them
                         const int pz = hf * 2 + s / 3;
+                        if (!(WY_EXP & 1)) { load_a(hf, s, 1, fa[1]); load_b(hf, s + 1, fb[(s + 1) & 1]); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma3(pz, 0, s & 1);
+                        pieces(hf, s);
+                        if (!(WY_EXP & 1)) load_a(hf, s + 1, 0, fa[0]);
+                        mma3(pz, 1, s & 1);
+                        if (MM) {
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            // sub-step (s, t): prefetch the fragments of the sub-steps ahead, then 3 MFMAs with this sub-step's staging pieces between them
-                            if (t == 1 && s == 5) {
-                                // the weight half DMA'd during this half (for the NEXT half to run) has landed; publish it.  Half A: the 9 row loads of
-                                // the next phase (steps 0-2) are younger and may fly on; half B: the DMAs are the youngest operations.
-                                if (hf == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                __syncthreads();
-                            }
-                            if (WY_EXP & 1) {
-                                asm volatile("" : "+v"(fa[0].ah), "+v"(fa[1].ah), "+v"(fb[0].bh), "+v"(fb[1].bh));
-                            } else if (t == 0) {
-                                load_a(hf, s, 1, fa[1]);
-                                if (s + 1 < 6) load_b(hf, s + 1, fb[(s + 1) & 1]);      // (the next step's activation pair: two sub-steps ahead)
-                            } else {
-                                if (s + 1 < 6) load_a(hf, s + 1, 0, fa[0]);
-                                else { load_b(hf ^ 1, 0, fb[(s + 1) & 1]); load_a(hf ^ 1, 0, 0, fa[0]); }
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            const FragA& a = fa[t];
-                            const FragB& b = fb[s & 1];
-                            if (MM) acc[pz][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.al, b.bh, acc[pz][t], 0, 0, 0);
-                            if (t == tsel) pieces(hf, s);
-                            if (MM) acc[pz][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.ah, b.bl, acc[pz][t], 0, 0, 0);
-                            if (MM) acc[pz][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.ah, b.bh, acc[pz][t], 0, 0, 0);
-#pragma unroll
-                            for (int i = 0; i < (MM ? 3 : 0); ++i) {
+                            for (int i = 0; i < 6; ++i) {
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);     // up to 10 VALU
+                                if (i == 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two weight-fragment reads for the next step, behind the third MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // up to 6 VALU
                                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // up to one DS write
+                                if (i == 1 || i == 4) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // one vector-memory instruction
                             }
-                            __builtin_amdgcn_sched_barrier(0);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    {   // step 5: sub-step (5, 0), then the barrier that publishes the other weight half, then (5, 1) on the next half's first fragments
+                        const int pz = hf * 2 + 1;
+                        if (!(WY_EXP & 1)) load_a(hf, 5, 1, fa[1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma3(pz, 0, 1);
+                        pieces(hf, 5);
+                        if (MM) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        WY_MARK(hf * 3 + 0);
+                        // the weight half DMA'd during this half (for the NEXT half to run) has landed; publish it.  Half A: the 8 row loads of the
+                        // next phase (steps 1-5) are younger and may fly on; half B: the DMAs are the youngest operations.
+                        if (hf == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        WY_MARK(hf * 3 + 1);
+                        if (!(WY_EXP & 1)) { load_b(hf ^ 1, 0, fb[0]); load_a(hf ^ 1, 0, 0, fa[0]); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma3(pz, 1, 1);
+                        if (hf == 0) issue_dx();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    WY_MARK(hf * 3 + 2);
                 }
             };
             if (rows_in) phase(std::true_type{}); else phase(std::false_type{});
@@ -521,7 +559,13 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
             }
             __syncthreads();                         // the slices are reused by the next tile's epilogue
         }
+        WY_MARK(6);
     }
+#if WY_EXP & 2048
+    wy_sec[7] = (long long)__builtin_amdgcn_s_memtime() - wy_t0;
+    if (lane == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 8; ++i) g_wy_stamps[(blockIdx.x * 8 + wave) * 8 + i] = wy_sec[i];
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last phases re-stage unconditionally: no LDS-DMA may be in flight when the LDS is released
 }
 
@@ -539,6 +583,12 @@ int conv_wy_prepare_device() {
 }  // namespace savsr
 
 using namespace savsr;
+
+#if WY_EXP & 2048
+extern "C" int savsr_debug_read_wy_stamps(long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wy_stamps), sizeof(long long) * 256 * 8 * 8);
+}
+#endif
 
 // Elements PER PART of the Winograd-y weight image: [cob][chunk][hf 2][s = vr * 3 + kx 6][t 2][part][512]: 12 taps instead of 9.
 extern "C" int64_t savsr_conv_wy_packed_elems(int cout, int cin) {

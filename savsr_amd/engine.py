@@ -180,6 +180,7 @@ class HipEngine:
         if cfg["slid_win"] != 3 or cfg["num_in_ch"] != 3:
             raise RuntimeError("the input-window packing is specialised for slid_win == 3, num_in_ch == 3")
         self.pw: Dict[str, tuple] = {}      # conv key -> (wimage, bias, cout, cin, ks)
+        self.pw_wy: Dict[str, torch.Tensor] = {}      # conv key -> Winograd-y weight image (static 3x3 convs with cout % 64 == 0)
         self.osc: Dict[str, dict] = {}      # osconv key -> tensors
         self.se: Dict[str, tuple] = {}
         self._keep: List[torch.Tensor] = []
@@ -193,6 +194,8 @@ class HipEngine:
         self.satu_q = os.environ.get("SAVSR_SATU_Q", "1") != "0"
         # static-weight 3x3 convs in the Winograd F(2,3)-along-y form (SAVSR_CONV_WINOGRAD_Y); SAVSR_CONV_WY=0: the direct kernel everywhere
         self.conv_wy = os.environ.get("SAVSR_CONV_WY", "1") != "0"
+        self.wy_min_tiles = int(os.environ.get("SAVSR_WY_MIN_TILES", "200"))          # launches with at least this many 16-row tiles take the Winograd form ...
+        self.wy_min_tiles_tp = int(os.environ.get("SAVSR_WY_MIN_TILES_TP", "100"))    # ... or this many with several clips in flight (throughput tiling)
         self.n_streams = max(1, int(os.environ.get("SAVSR_STREAMS", "3")))   # clips of a batch in flight concurrently
         self._siblings: List["HipEngine"] = []
         self._streams: List[torch.cuda.Stream] = []
@@ -218,11 +221,11 @@ class HipEngine:
     def _register(self, key: str, w: torch.Tensor, b: Optional[torch.Tensor]):
         cout, cin, ks, _ = w.shape
         bias = None if b is None else self._dev(b)
+        self.pw[key] = (self._dev(pack_conv_weight(w), torch.int16), bias, cout, cin, ks)
         if self.conv_wy and ks == 3 and cout % 64 == 0 and cin % 16 == 0:
-            # static 3x3 weights: the Winograd F(2,3)-along-y form (conv_wy.hip), 2/3 of the matrix work; the algo travels with the weights
-            self.pw[key] = (self._dev(pack_conv_weight_wy(w), torch.int16), bias, cout, cin, ks, _lib.CONV_WINOGRAD_Y)
-        else:
-            self.pw[key] = (self._dev(pack_conv_weight(w), torch.int16), bias, cout, cin, ks)
+            # static 3x3 weights also as the Winograd F(2,3)-along-y image (conv_wy.hip: 2/3 of the matrix work); which form a launch takes is
+            # decided per launch in conv_launch (the 16-row Winograd tiles need a launch that fills the chip)
+            self.pw_wy[key] = self._dev(pack_conv_weight_wy(w), torch.int16)
 
     def _add_conv(self, sd, key: str, bn: Optional[str] = None):
         w, b = self._fold(sd, key, bn)
@@ -433,6 +436,7 @@ class HipEngine:
         e = HipEngine.__new__(HipEngine)
         e.lib, e.dev, e.cfg, e.nf = self.lib, self.dev, self.cfg, self.nf
         e.pw, e.se, e._keep = self.pw, self.se, self._keep
+        e.pw_wy, e.conv_wy, e.wy_min_tiles, e.wy_min_tiles_tp = self.pw_wy, self.conv_wy, self.wy_min_tiles, self.wy_min_tiles_tp
         e.satu_t, e.satu_w, e.tail_w, e.tail_b, e.gamma, e.n_l2 = self.satu_t, self.satu_w, self.tail_w, self.tail_b, self.gamma, self.n_l2
         e.iter_win, e.fwd_idx, e.bwd_idx = self.iter_win, self.fwd_idx, self.bwd_idx
         e.satu_tail_t, e.satu_w_tail = self.satu_tail_t, self.satu_w_tail
@@ -546,6 +550,7 @@ class HipEngine:
         wpk, bias, cout, cin, ks, *rest = weights if weights is not None else self.pw[key]
         d = ConvDesc()
         d.algo = rest[0] if rest else self.conv_algo
+        d._wy = self.pw_wy[key].data_ptr() if (weights is None and key in self.pw_wy) else None      # (a Python attribute, not a field of the C struct)
         assert len(srcs) <= _lib.MAX_SRC and all(s.ch == srcs[0].ch for s in srcs)
         assert cin == len(srcs) * srcs[0].ch, (key, cin, len(srcs), srcs[0].ch)
         assert out.ch == cout, (key, out.ch, cout)
@@ -570,13 +575,21 @@ class HipEngine:
         st = self._stream()
         for i in range(0, len(descs), 6):
             chunk = descs[i:i + 6]
+            # Winograd-y form when every conv of the launch has the image and its 16-row x 32-px x 64-channel tiles fill the chip: measured on
+            # 180x320 (tools/ab_conv.py --wy): 6 x 128->64 -10 %, 6 x 64->64 -7..-9 %; a lone 64->64 conv (120 tiles) +35 % against the 8-row
+            # direct tiling, -4 % against the 16-row direct tiling of the throughput mode
+            d0 = chunk[0]
+            if all(getattr(c, "_wy", None) for c in chunk) and d0.algo in (_lib.CONV_DIRECT, _lib.CONV_DIRECT_THROUGHPUT):
+                tiles = len(chunk) * (d0.cout // 64) * ((d0.h + 15) // 16) * ((d0.w + 31) // 32)
+                if tiles >= (self.wy_min_tiles_tp if d0.algo == _lib.CONV_DIRECT_THROUGHPUT else self.wy_min_tiles):
+                    for c in chunk:
+                        c.wpacked, c.algo = c._wy, _lib.CONV_WINOGRAD_Y
             arr = (ConvDesc * len(chunk))(*chunk)
             _lib.check(self.lib.savsr_conv2d_batch(arr, len(chunk), st), f"savsr_conv2d_batch[{label}]")
 
     def conv(self, key, srcs: List[Src], out: Src, h: int, w: int, act=ACT_NONE, slope=0.0,
              mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None, pool=None):
-        d = self.conv_desc(key, srcs, out, h, w, act, slope, mul_px, res1, res2, res2_scale, weights, pool)
-        _lib.check(self.lib.savsr_conv2d(C.byref(d), self._stream()), f"savsr_conv2d[{key}]")
+        self.conv_launch([self.conv_desc(key, srcs, out, h, w, act, slope, mul_px, res1, res2, res2_scale, weights, pool)], key)
         return out
 
     def channel_sums(self, srcs: List[Src], npx: int, partial: torch.Tensor) -> int:

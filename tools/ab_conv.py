@@ -114,6 +114,20 @@ def main():
                     clocks[name].append(win[len(win) // 2])
                     if r == 1:
                         print(f"    [{name}] probe windows MHz: " + " ".join(f"{v:.0f}" for v in (100.0 * c / rt for c, rt in probe_buf.cpu().view(8, 2).tolist() if rt > 0)))
+        for name, (lib, arr) in libs:                          # instrumented Winograd builds (-DWY_EXP=2048): section cycles per wave
+            if hasattr(lib, "savsr_debug_read_wy_stamps") and "winograd" in name:
+                import numpy as np
+                for _ in range(5):
+                    lib.savsr_conv2d_batch(arr, nb, st)
+                torch.cuda.synchronize()
+                buf = (C.c_longlong * (256 * 8 * 8))()
+                lib.savsr_debug_read_wy_stamps(buf)
+                stt = np.array(buf[:], dtype=np.int64).reshape(256, 8, 8)
+                med = np.median(stt, axis=0)                   # [wave][section]
+                names = ["A s0-4", "A wait+bar", "A s5", "B s0-4", "B wait+bar", "B s5", "epilogue", "total"]
+                print(f"    [{name}] median cycles per wave over the launch (sections: " + ", ".join(names) + ")")
+                for wv in (0, 3, 4, 7):
+                    print(f"      wave {wv}: " + "  ".join(f"{int(v):7d}" for v in med[wv]))
         flop = 3 * 2.0 * nb * cin * cout * 9 * h * w
         print(f"== {nb} x conv3x3 {cin}->{cout} at {h}x{w} (distinct inputs, bias + LeakyReLU + residual){' [throughput tiling]' if a.throughput else ''}")
         base = statistics.median(times[libs[0][0]][1:])
