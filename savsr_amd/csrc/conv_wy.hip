@@ -37,6 +37,12 @@
 #ifndef WY_EXP
 #define WY_EXP 0
 #endif
+#ifndef WY_NT_ROWS
+#define WY_NT_ROWS 0              // 1: the row loads carry the nt (streaming) hint: +17 % time -- two waves load each input row and the second one's loads are L1 hits
+#endif
+#ifndef WY_VALU
+#define WY_VALU 6                 // vector instructions the scheduler may put behind every MFMA of a step
+#endif
 
 namespace savsr {
 
@@ -92,10 +98,10 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 #ifndef WY_PRIO
-#define WY_PRIO 1
-#endif
+#define WY_PRIO 0             // 1: static issue priority for waves 4-7 as in the direct kernel (CONV_PRIO): +2 % time here (A/B in one process, 7 rounds:
+#endif                        // 6 x 128->64 138.0 -> 135.1 us without it) -- the prioritised waves finish each half early and idle at its barrier
 #if WY_PRIO
-    if (wave_s >= 4) __builtin_amdgcn_s_setprio(1);           // static priority for the younger half (conv_mfma.hip, CONV_PRIO)
+    if (wave_s >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
     const int tiles_per_cob = mp.ntx * mp.nty;
     const int total = mp.nconv * mp.ncob * tiles_per_cob;
@@ -168,7 +174,11 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     auto load_at = [&](int pixel, bool ok) -> f32x4 {
         const SAVSR_GLOBAL float* src = ok ? (const SAVSR_GLOBAL float*)st_base + (pixel * st_pix + st_cb + 4 * q4)
                                            : (const SAVSR_GLOBAL float*)g_wy_zero16;
+#if WY_NT_ROWS
+        return __builtin_nontemporal_load((const SAVSR_GLOBAL f32x4*)src);
+#else
         return *(const SAVSR_GLOBAL f32x4*)src;
+#endif
     };
     auto issue_row = [&](int r, int i) {                      // round r of the cursor's phase, row d_i of this lane's column
         if ((WY_EXP & 256) && (i == 0 || i == 3)) { asm volatile("" : "+v"(d[r][i])); return; }     // timing knob: rows d0, d3 are not loaded (5 instead of 9 loads; vmcnt counts then over-wait)
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
                             for (int i = 0; i < 6; ++i) {
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
                                 if (i == 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two weight-fragment reads for the next step, behind the third MFMA
-                                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // up to 6 VALU
+                                __builtin_amdgcn_sched_group_barrier(0x002, WY_VALU, 0);      // up to WY_VALU vector instructions
                                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // up to one DS write
                                 if (i == 1 || i == 4) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // one vector-memory instruction
                             }
