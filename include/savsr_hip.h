@@ -16,7 +16,10 @@
  *   - LR feature maps are fp32 channel-last ([h][w][C]); the clip, the SATU output and the result
  *     are channel-planar ([C][h][w]);
  *   - output sizes H, W are computed by the CALLER with Python round() so that get_HW
- *     (savsr_arch.py:745-751) stays bit-exact.
+ *     (savsr_arch.py:745-751) stays bit-exact;
+ *   - specialisation: the SATU entry points (savsr_satu_*) and savsr_pack_windows are built for the shipped configuration of the
+ *     reference constructor (savsr_arch.py:576-589): num_feat = 64, slid_win = 3, num_in_ch = 3.  The conv / OSConv entry points
+ *     take any channel counts that are multiples of 16 (32 for 1x1).  A checkpoint trained with another num_feat does not run.
  */
 #ifndef SAVSR_HIP_H
 #define SAVSR_HIP_H
