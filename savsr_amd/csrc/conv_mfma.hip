@@ -53,9 +53,6 @@
 #ifndef CONV_EXP
 #define CONV_EXP 0
 #endif
-#ifndef CONV_1X1_WIDE
-#define CONV_1X1_WIDE 1           // 16-row tiles for the 1x1 convs too (experiment switch)
-#endif
 #ifndef EPI_PREFETCH
 #define EPI_PREFETCH 1            // the epilogue's first global loads (bias quads, first residual group) are issued in front of the tile's LAST phase
 #endif
@@ -525,15 +522,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         float e_slope = p.slope, e_r2s = p.res2_scale;
         asm volatile("" : "+s"(e_bias), "+s"(e_mul), "+s"(e_r1), "+s"(e_r2), "+s"(e_out), "+s"(e_pool));
         asm volatile("" : "+s"(e_act), "+s"(e_opix), "+s"(e_r1pix), "+s"(e_r2pix), "+s"(e_slope), "+s"(e_r2s));
-#ifdef CONV_EPI_SIMPLE          // experiment: the common epilogue only (no per-pixel mask, no second residual, max-form activation)
-        e_mul = nullptr; e_r2 = nullptr;
-#endif
         const int COUT = mp.cout;
-#ifdef CONV_EPI_SIMPLE
-        const bool act_as_max = true;
-#else
         const bool act_as_max = e_act == SAVSR_ACT_NONE || e_act == SAVSR_ACT_RELU || (e_act == SAVSR_ACT_LRELU && e_slope >= 0.f && e_slope <= 1.f);
-#endif
         const float slope_eff = e_act == SAVSR_ACT_NONE ? 1.f : (e_act == SAVSR_ACT_RELU ? 0.f : e_slope);
         float* ep_base = reinterpret_cast<float*>(EP_ALIAS ? smem + (buf ^ 1) * B_UNITS : smem + 2 * B_UNITS + 2 * W_UNITS);
         float* ep = ep_base + wave * (32 * EPS);
@@ -835,9 +825,7 @@ int conv_prepare_device() {
     if (int rc = conv_attr<3, 2, 1>()) return rc;
     if (int rc = conv_attr<3, 1, 1>()) return rc;
     if (int rc = conv_attr<1, 2, 1>()) return rc;
-#if CONV_1X1_WIDE
     if (int rc = conv_attr<1, 2, 2>()) return rc;
-#endif
     if (int rc = conv_attr<1, 1, 1>()) return rc;
     return conv_wy_prepare_device();
 }
@@ -973,7 +961,6 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
         return launch_conv<3, 2, 1>(mp, st);
     }
     if (d->ksize == 3) return launch_conv<3, 1, 1>(mp, st);
-#if CONV_1X1_WIDE
     if (wide && d->cout % 64 == 0) {               // 1x1: 16-row tiles from the same tile counts up (half the barriers and fragment reads per pixel)
         const int nty2 = (d->h + 2 * CONV_TH - 1) / (2 * CONV_TH);
         if (n * mp.ncob * mp.ntx * nty2 >= (d->algo == SAVSR_CONV_DIRECT_THROUGHPUT ? CONV_WIDE_MIN_TILES_TP : CONV_WIDE_MIN_TILES)) {
@@ -981,7 +968,6 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
             return launch_conv<1, 2, 2>(mp, st);
         }
     }
-#endif
     return wide ? launch_conv<1, 2, 1>(mp, st) : launch_conv<1, 1, 1>(mp, st);
 }
 

@@ -25,17 +25,8 @@
 #ifndef LR_EXP
 #define LR_EXP 0
 #endif
-#ifndef LR_INTERLEAVE
-#define LR_INTERLEAVE 1
-#endif
 #ifndef LR_XPREFETCH
 #define LR_XPREFETCH 1
-#endif
-#ifndef LR_PRIO
-#define LR_PRIO 0                 // s_setprio experiments in the 8-wave LR kernel: 1 static for waves 4-7, 2 alternating per tap, 3 per group
-#endif
-#ifndef LR_STREAM
-#define LR_STREAM 1               // product launch: satu_lr_stream_kernel (barrier inside the phase, MFMA stream across phase boundaries); 0: satu_lr_kernel
 #endif
 #ifndef LR_ST
 #define LR_ST 0                   // LRcat stores of satu_lr_stream_kernel: 0 plain, 1 nt, 2 sc1 (write-through), 3 sc0 sc1
@@ -52,9 +43,6 @@
 #ifndef LRS_EXP
 #define LRS_EXP 0                 // timing experiments on satu_lr_stream_kernel (results invalid; never set in a shipped build): 1 no fragment
 #endif                            // re-reads, 2 no x / bias reads, 4 no LeakyReLU * x arithmetic, 16 no slab DMAs inside the loop
-#ifndef LR_PACKED
-#define LR_PACKED 0               // LeakyReLU * x accumulation with v_pk_mul / v_pk_fma (1) or plain v_mul / v_max / v_fmac (0)
-#endif
 
 namespace savsr {
 
@@ -157,287 +145,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, const void* lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
-template <bool DIAG, int NB>      // DIAG: instrumented build (section stamps), launched only while savsr_debug_satu_stamps is on
-__global__ __launch_bounds__(512, 2) void satu_lr_kernel(const LrParams p) {
-    constexpr int REC = rec_floats(NB);
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xt = smem;                                                   // [432][36]: replicate-padded x tile of one channel group
-    bf16x8* wbuf = reinterpret_cast<bf16x8*>(smem + LR_NPX * LR_XS);    // [2][LR_PHASE]: weight slabs of a kernel row, double buffered
-    float* kbl = smem + LR_NPX * LR_XS + 2 * LR_PHASE * 4;              // [25][64] kernel_conv bias
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
-    const int x0 = blockIdx.x * LR_TW, y0 = blockIdx.y * LR_TH;
-    const int gy = y0 + wave, gx = x0 + px;
-    const bool valid = gy < p.h && gx < p.w;
-    const int cy = gy < p.h ? gy : p.h - 1, cx = gx < p.w ? gx : p.w - 1;
-    const long long cpix = ((long long)cy * p.row_px + cx) * p.pix + 8 * half;
-
-#if SATU_HAS_STAMPS
-    const int stamps_on = DIAG ? __builtin_amdgcn_readfirstlane(g_satu_stamps_on) & 1 : 0;
-#else
-    static_assert(!DIAG, "DIAG kernels exist in the instrumented library only");
-    const int stamps_on = 0;
-#endif
-    long long tacc[SSTAMP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long t_prev = stamps_on ? SATU_T() : 0;
-    [[maybe_unused]] const long long t_begin = t_prev;
-    [[maybe_unused]] const long long t_lr0 = (LR_EXP & 8) ? SATU_T() : 0;
-#define LR_MARK(i) do { if (stamps_on) { const long long t_now = SATU_T(); tacc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
-
-    const bf16x8* kw = reinterpret_cast<const bf16x8*>(p.wt.kconv_w);
-    // weight slabs of phase ph (= channel group ph / 5, kernel row ph % 5) -> LDS buffer b: 40 pieces of 1 KiB, 5 per wave
-    auto dma_phase = [&](int ph, int b) {
-        const int cg = ph / 5, ky = ph - 5 * cg;
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            glds16(kw + (long long)((ky * 5 + i) * 2 + cg) * LR_SLAB + wave * 64 + lane, wbuf + b * LR_PHASE + i * LR_SLAB + wave * 64);
-    };
-    // replicate-padded x tile of channel group cg (F.pad replicate, :302): global -> registers ...
-    constexpr int XT_IT = (LR_NPX * 8 + 511) / 512;                    // 7 float4 per thread
-    f32x4 xv[XT_IT];
-    auto xt_load = [&](int cg) {
-#pragma unroll
-        for (int i = 0; i < XT_IT; ++i) {
-            const int e = tid + i * 512;
-            const int pl = (e < LR_NPX * 8 ? e : 0) >> 3, c4 = e & 7;
-            const int r = pl / LR_XC, c = pl - r * LR_XC;
-            int sy = y0 - LR_HALO + r, sx = x0 - LR_HALO + c;
-            sy = sy < 0 ? 0 : (sy > p.h - 1 ? p.h - 1 : sy);
-            sx = sx < 0 ? 0 : (sx > p.w - 1 ? p.w - 1 : sx);
-            xv[i] = *reinterpret_cast<const f32x4*>(p.x + ((long long)sy * p.row_px + sx) * p.pix + 32 * cg + 4 * c4);
-        }
-    };
-    auto xt_store = [&]() {                                             // ... -> LDS
-#pragma unroll
-        for (int i = 0; i < XT_IT; ++i) {
-            const int e = tid + i * 512;
-            if (e < LR_NPX * 8) *reinterpret_cast<f32x4*>(xt + (e >> 3) * LR_XS + 4 * (e & 7)) = xv[i];
-        }
-    };
-
-    // ---- prologue ---------------------------------------------------------------------------------------------
-    dma_phase(0, 0);
-    xt_load(0);
-    // B operand of the kernel-prediction GEMM: st[16 ks + 8 half + j][pixel], resident for all 50 tiles
-    bf16x8 sth[4], stl[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const f32x4* g = reinterpret_cast<const f32x4*>(p.st + cpix + 16 * ks);
-        split8v(g[0], g[1], sth[ks], stl[ks]);
-    }
-    for (int e = tid; e < 25 * 64 / 4; e += 512) reinterpret_cast<f32x4*>(kbl)[e] = reinterpret_cast<const f32x4*>(p.wt.kconv_b)[e];
-    xt_store();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    LR_MARK(0);                                       // prologue: first slabs, x tile, st fragments
-
-    struct AFrag { bf16x8 ah[4], al[4]; };
-    f32x16 sta[2];
-    const int prio_grp = __builtin_amdgcn_readfirstlane(wave >> 2);     // the SIMD's second-dispatched wave (waves 4 .. 7)
-    if (LR_PRIO == 1 && prio_grp) __builtin_amdgcn_s_setprio(1);        // static priority for the younger half (MI355X_MICROARCH.md, "Two waves per SIMD" item 4)
-#pragma unroll
-    for (int cg = 0; cg < 2; ++cg) {                  // unrolled: sta[cg] must stay in registers
-        f32x16 sacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll 1
-        for (int ky = 0; ky < 5; ++ky) {
-            const int ph = cg * 5 + ky, buf = ph & 1;
-            // staged under this phase: the next kernel row's slabs; at the end of a channel group also the next x tile;
-            // under the very last phase the projection weights (same 40 KB) and the centre pixel's x
-            if (ph + 1 < 10) dma_phase(ph + 1, buf ^ 1);
-            if (LR_XPREFETCH && ph == 4) xt_load(1);   // the second channel group's x tile: its loads fly under this phase (28 registers; written to LDS behind the barrier)
-            if (ph + 1 >= 10) {                                    // projection image: (2 NB + 1) x 8 KB
-#pragma unroll
-                for (int i = 0; i < 2 * NB + 1; ++i)
-                    glds16(reinterpret_cast<const bf16x8*>(p.wt.proj_w) + (i * 8 + wave) * 64 + lane, wbuf + (buf ^ 1) * LR_PHASE + (i * 8 + wave) * 64);
-            }
-
-            const bf16x8* wl = wbuf + buf * LR_PHASE + lane;
-            auto load_frag = [&](int kx, AFrag& f) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) { f.ah[ks] = wl[kx * LR_SLAB + (ks * 2 + 0) * 64]; f.al[ks] = wl[kx * LR_SLAB + (ks * 2 + 1) * 64]; }
-            };
-            // LDS operands of the VALU work are read ONE group ahead of their use (a read next to its use exposes the LDS
-            // latency in every group: the wave cannot issue its next MFMAs while it waits)
-            auto bias_read = [&](int kx, int g) -> f32x4 {       // kernel_conv bias (the initial accumulator), quad g
-                return *reinterpret_cast<const f32x4*>(kbl + (ky * 5 + kx) * 64 + cg * 32 + 4 * half + 8 * g);
-            };
-            auto x_read = [&](int kx, int g) -> f32x4 {          // x_pad at tap (ky, kx), channel quad g of this half
-                return *reinterpret_cast<const f32x4*>(xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half + 8 * g);
-            };
-            auto lrelu_x = [&](int g, const f32x16& acc, const f32x4 xq) {   // sta += LeakyReLU_0.1(K) * x_pad   (:228, :297-313)
-                // 2 vector instructions per element: v_pk_mul (0.1 k), v_max (one: fmaxf costs two, NaN canonicalisation), v_pk_fma.
-                // The max and the accumulation are VOLATILE asm: pure arithmetic has no ordering against the sched_barriers
-                // between the MFMA groups, and hipcc's DAG scheduler collected all of a phase's LeakyReLU * x work (260
-                // instructions) into one clump behind the barrier, serial to the phase's 60 MFMAs (ISA listing).
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-#if !LR_PACKED
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {         // plain VALU: packed fp32 instructions are an anti-lever beside MFMAs (MI355X_MICROARCH.md)
-                    // the FIRST reader of an MFMA result must be a compiler-generated instruction (hipcc inserts the wait states an
-                    // accumulator read needs; it does not look inside an asm block)
-                    float sv = sacc[4 * g + q], m_tmp = 0.1f * acc[4 * g + q];        // (scalar: satu.hip is built with -fno-slp-vectorize)
-                    asm volatile("v_max_f32 %0, %2, %0\n\tv_fmac_f32 %1, %0, %3" : "+v"(m_tmp), "+v"(sv) : "v"(acc[4 * g + q]), "v"(xq[q]));
-                    sacc[4 * g + q] = sv;
-                }
-                return;
-#endif
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const f32x2 k = {acc[4 * g + 2 * h2], acc[4 * g + 2 * h2 + 1]};
-                    const f32x2 t = k * f32x2{0.1f, 0.1f};
-                    float m0, m1;
-                    asm volatile("v_max_f32 %0, %2, %3\n\tv_max_f32 %1, %4, %5" : "=&v"(m0), "=&v"(m1) : "v"(k[0]), "v"(t[0]), "v"(k[1]), "v"(t[1]));
-                    f32x2 sv = {sacc[4 * g + 2 * h2], sacc[4 * g + 2 * h2 + 1]};
-                    const f32x2 m = {m0, m1}, x2 = {xq[2 * h2], xq[2 * h2 + 1]};
-                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(sv) : "v"(m), "v"(x2));
-                    sacc[4 * g + 2 * h2] = sv[0];
-                    sacc[4 * g + 2 * h2 + 1] = sv[1];
-                }
-            };
-            AFrag fr;                                 // ONE fragment set: a k-step's pair is reloaded for the next tap as soon as its
-            f32x16 acc[2];                            // MFMAs are issued (they have consumed their operands); two sets spill
-            load_frag(0, fr);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = bias_read(0, g);
-                acc[0][4 * g] = b4[0]; acc[0][4 * g + 1] = b4[1]; acc[0][4 * g + 2] = b4[2]; acc[0][4 * g + 3] = b4[3];
-            }
-            f32x4 b_pf = bias_read(1, 0), x_pf = b_pf;
-            // 20 groups of 3 MFMAs (tap kx = G / 4, k-step ks = G % 4).  The VALU work of the previous tap and the next tap's
-            // bias go BETWEEN the groups: both waves of a SIMD run in lockstep, so VALU work placed after a tap's 12 MFMAs is
-            // serial to them (7.9 k cycles per phase for 4.0 k of MFMAs, stamps).
-#pragma unroll
-            for (int G = 0; G < 20; ++G) {
-                const int kx = G / 4, ks = G % 4;
-                __builtin_amdgcn_sched_barrier(0);
-                if (LR_PRIO == 2 && ks == 0) { if (((kx ^ prio_grp) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-                if (LR_PRIO == 3) { if (((G ^ prio_grp) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-                acc[kx & 1] = mma3(fr.ah[ks], fr.al[ks], sth[ks], stl[ks], acc[kx & 1]);
-#if !LR_INTERLEAVE
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-                if (!(LR_EXP & 1) && kx + 1 < 5) { fr.ah[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 0) * 64]; fr.al[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 1) * 64]; }
-                if (kx > 0) lrelu_x(ks, acc[(kx - 1) & 1], x_pf);
-                if (kx + 1 < 5) {
-                    f32x16& an = acc[(kx + 1) & 1];
-                    an[4 * ks] = b_pf[0]; an[4 * ks + 1] = b_pf[1]; an[4 * ks + 2] = b_pf[2]; an[4 * ks + 3] = b_pf[3];
-                }
-                const int G1 = G + 1, kx1 = G1 / 4, ks1 = G1 % 4;
-                if (G1 < 20 && !(LR_EXP & 2)) {
-                    if (kx1 > 0) x_pf = x_read(kx1 - 1, ks1);
-                    if (kx1 + 1 < 5) b_pf = bias_read(kx1 + 1, ks1);
-                }
-#if LR_INTERLEAVE
-                // the group is one basic block: ~5 vector instructions and one LDS read behind each of its 3 MFMAs
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                }
-#endif
-            }
-            {
-                f32x4 xq[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) xq[g] = x_read(4, g);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) lrelu_x(g, acc[0], xq[g]);
-            }
-            LR_MARK(1);                               // 5 taps: fragment reads, 60 MFMAs, LeakyReLU * x
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the staged slabs (and x loads) have landed
-            LR_MARK(2);
-            __syncthreads();
-            if (ky == 4 && cg == 0) {                 // every wave is done with the old x tile: swap it (once per workgroup)
-                if (!LR_XPREFETCH) xt_load(1);
-                xt_store();
-                __syncthreads();
-            }
-            LR_MARK(3);                               // barrier(s)
-        }
-        sta[cg] = sacc;
-    }
-
-    // ---- LR-side projections (bf16x3): proj image = A [t < NB][kidx 4][part][lane] | B [t < NB][ks 4][part][lane] | C [ks 4][part][lane],
-    // now in LDS buffer 0 (phase 9 ran from buffer 1)
-    const bf16x8* pa = wbuf + lane;
-    const bf16x8* pb = pa + NB * 4 * 2 * 64;
-    const bf16x8* pc = pb + NB * 4 * 2 * 64;
-    f32x4 xc[8];                                      // the centre pixel's x: B operand of the Wb / C projections
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const f32x4* g = reinterpret_cast<const f32x4*>(p.x + cpix + 16 * ks);
-        xc[2 * ks] = g[0];
-        xc[2 * ks + 1] = g[1];
-    }
-    f32x16 accA[NB], accB[NB], accC;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-#pragma unroll
-        for (int t = 0; t < NB; ++t) { accA[t][r] = 0.f; accB[t][r] = 0.f; }
-        accC[r] = 0.f;
-    }
-#pragma unroll
-    for (int cg = 0; cg < 2; ++cg)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            // accumulator regs 8s..8s+7 are rows 16 s + 8 (j >> 2) + 4 half + (j & 3): the k order of this step
-            const f32x4 lo4 = {sta[cg][8 * s], sta[cg][8 * s + 1], sta[cg][8 * s + 2], sta[cg][8 * s + 3]};
-            const f32x4 hi4 = {sta[cg][8 * s + 4], sta[cg][8 * s + 5], sta[cg][8 * s + 6], sta[cg][8 * s + 7]};
-            bf16x8 bh, bl;
-            split8v(lo4, hi4, bh, bl);
-            const int kidx = cg * 2 + s;
-#pragma unroll
-            for (int t = 0; t < NB; ++t)
-                accA[t] = mma3(pa[((t * 4 + kidx) * 2 + 0) * 64], pa[((t * 4 + kidx) * 2 + 1) * 64], bh, bl, accA[t]);
-        }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 xh, xl;
-        split8v(xc[2 * ks], xc[2 * ks + 1], xh, xl);
-#pragma unroll
-        for (int t = 0; t < NB; ++t)
-            accB[t] = mma3(pb[((t * 4 + ks) * 2 + 0) * 64], pb[((t * 4 + ks) * 2 + 1) * 64], xh, xl, accB[t]);
-        accC = mma3(pc[(ks * 2 + 0) * 64], pc[(ks * 2 + 1) * 64], xh, xl, accC);
-    }
-    LR_MARK(4);                                        // projections
-#if SATU_HAS_STAMPS
-    if ((LR_EXP & 8) && !DIAG && __builtin_amdgcn_readfirstlane(tid) == 0) {      // (scalar branch: all of wave 0 stores)
-        const int b = blockIdx.x + gridDim.x * blockIdx.y;
-        if (b < SSTAMP_BLOCKS) g_satu_stamps[b * SSTAMP_N + 7] = SATU_T() - t_lr0;
-    }
-    if (stamps_on && tid == 0) {
-        const int b = blockIdx.x + gridDim.x * blockIdx.y;
-        if (b < SSTAMP_BLOCKS) {
-            for (int i = 0; i < 7; ++i) g_satu_stamps[b * SSTAMP_N + i] = tacc[i];
-            g_satu_stamps[b * SSTAMP_N + 7] = SATU_T() - t_begin;
-        }
-    }
-#endif
-    if (!valid) return;
-    float* recf = p.lrcat + ((long long)gy * p.w + gx) * REC;
-    f32x4* rec = reinterpret_cast<f32x4*>(recf + half * 32 * NB);
-#pragma unroll
-    for (int t = 0; t < NB; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 a = {accA[t][4 * g], accA[t][4 * g + 1], accA[t][4 * g + 2], accA[t][4 * g + 3]};
-            f32x4 b = {accB[t][4 * g], accB[t][4 * g + 1], accB[t][4 * g + 2], accB[t][4 * g + 3]};
-            rec[t * 4 + g] = a;
-            rec[4 * NB + t * 4 + g] = b;
-        }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 c = {accC[4 * g], accC[4 * g + 1], accC[4 * g + 2], accC[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(recf + 64 * NB + 8 * g + 4 * half) = c;     // rows 8g + 4 half + {0..3} = C-stack channels
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// LR stage, STREAMING form (round 3; the product launch when LR_STREAM is 1).  Same arithmetic, same tile, same LDS image as
-// satu_lr_kernel above -- what changes is where the per-phase barrier sits.  There, a phase is [5 DMAs | first fragment
+// LR stage, STREAMING form (round 3).  Same arithmetic, same tile, same LDS image as the round-2 kernel (satu_lr_kernel, archived as
+// tools/experiments/satu_lr_round2_kernel.patch) -- what changed is where the per-phase barrier sits.  There, a phase was [5 DMAs | first fragment
 // reads | 20 MFMA groups | last tap's LeakyReLU * x | vmcnt(0) | barrier]: both waves of a SIMD leave the barrier in
 // lockstep, so every phase boundary drains the matrix pipe for ~1 k cycles (MFMA latency + 48 vector instructions + barrier
 // skew + DMA issue + fragment latency) of a ~5.8 k-cycle phase.  Here the MFMA stream never stops inside a channel group:
@@ -567,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
         auto x_read = [&](int ky, int kx, int g) -> f32x4 {          // x_pad at tap (ky, kx), channel quad g of this half
             return *reinterpret_cast<const f32x4*>(xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half + 8 * g);
         };
-        auto lrelu_x = [&](int g, const f32x16& a, const f32x4 xq) {   // sacc += LeakyReLU_0.1(K) * x_pad   (:228, :297-313); see satu_lr_kernel
+        auto lrelu_x = [&](int g, const f32x16& a, const f32x4 xq) {   // sacc += LeakyReLU_0.1(K) * x_pad   (:228, :297-313)
 #if LRS_LRELU == 1
             // LeakyReLU_0.1(k) = 0.55 k + 0.45 |k|: two INDEPENDENT accumulations per element (sum x k, sum x |k|; combined once per
             // channel group) instead of the dependent mul -> max -> fmac chain.  The first reader of the MFMA result is the
@@ -1590,7 +1300,7 @@ extern "C" int savsr_satu_hr_rows_per_wave_tile(int tail_form) { return tail_for
 extern "C" int savsr_debug_satu_occupancy(int which, int lds_bytes) {
     int n = -1;
     hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_hr_kernel<false, 1, 0>, 64 * (hr_compute_waves(0) + hr_producer_waves(0)), (size_t)lds_bytes)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_kernel<false, 1>, 512, (size_t)lds_bytes);
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, satu_lr_stream_kernel<1>, 512, (size_t)lds_bytes);
     return e == hipSuccess ? n : -(int)e;
 }
 
@@ -1624,13 +1334,8 @@ static_assert(LR_LDS_BYTES <= 160 * 1024, "LR stage LDS budget");
 namespace savsr {
 // every product instantiation's dynamic-LDS attribute on the current device (savsr_prepare_device)
 int satu_prepare_device() {
-#if LR_STREAM
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_stream_kernel<1>), (int)LR_LDS_BYTES, "satu_lr_stage")) return rc;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_stream_kernel<2>), (int)LR_LDS_BYTES, "satu_lr_stage")) return rc;
-#else
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_kernel<false, 1>), (int)LR_LDS_BYTES, "satu_lr_stage")) return rc;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_kernel<false, 2>), (int)LR_LDS_BYTES, "satu_lr_stage")) return rc;
-#endif
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 1, 0>), 160 * 1024, "satu_hr")) return rc;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 1, 1>), 160 * 1024, "satu_hr")) return rc;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_hr_kernel<false, 1, 2>), 160 * 1024, "satu_hr")) return rc;
@@ -1654,22 +1359,9 @@ static int lr_stage(const savsr_satu_weights* wt, const float* x, const float* s
     p.wt = *wt; p.x = x; p.st = st; p.pix = pix; p.row_px = row_px; p.h = h; p.w = w; p.lrcat = lrcat;
     constexpr size_t lds = LR_LDS_BYTES;
     dim3 grid((w + LR_TW - 1) / LR_TW, (h + LR_TH - 1) / LR_TH);
-#if defined(SAVSR_DIAG) && !LR_STREAM
-    if (NB == 1 && g_satu_diag_host) {
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_kernel<true, 1>), (int)lds, "satu_lr_stage")) return rc;
-        hipLaunchKernelGGL((satu_lr_kernel<true, 1>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
-        return check_launch("satu_lr_kernel");
-    }
-#endif
-#if LR_STREAM
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_stream_kernel<NB>), (int)lds, "satu_lr_stage")) return rc;
     hipLaunchKernelGGL((satu_lr_stream_kernel<NB>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
     return check_launch("satu_lr_stream_kernel");
-#else
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&satu_lr_kernel<false, NB>), (int)lds, "satu_lr_stage")) return rc;
-    hipLaunchKernelGGL((satu_lr_kernel<false, NB>), grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
-    return check_launch("satu_lr_kernel");
-#endif
 }
 
 extern "C" int savsr_satu_lr_stage(const savsr_satu_weights* wt, const float* x, const float* st, int32_t pix, int32_t row_px, int h,
