@@ -194,6 +194,7 @@ class HipEngine:
         self.satu_q = os.environ.get("SAVSR_SATU_Q", "1") != "0"
         # static-weight 3x3 convs in the Winograd F(2,3)-along-y form (SAVSR_CONV_WINOGRAD_Y); SAVSR_CONV_WY=0: the direct kernel everywhere
         self.conv_wy = os.environ.get("SAVSR_CONV_WY", "1") != "0"
+        self.reuse_buffers = os.environ.get("SAVSR_REUSE_BUFFERS", "1") != "0"      # liveness-planned LR buffers (release()); 0: every name its own memory
         self.wy_min_tiles = int(os.environ.get("SAVSR_WY_MIN_TILES", "200"))          # launches with at least this many 16-row tiles take the Winograd form ...
         self.wy_min_tiles_tp = int(os.environ.get("SAVSR_WY_MIN_TILES_TP", "100"))    # ... or this many with several clips in flight (throughput tiling)
         self.n_streams = max(1, int(os.environ.get("SAVSR_STREAMS", "3")))   # clips of a batch in flight concurrently
@@ -437,6 +438,7 @@ class HipEngine:
         e.lib, e.dev, e.cfg, e.nf = self.lib, self.dev, self.cfg, self.nf
         e.pw, e.se, e._keep = self.pw, self.se, self._keep
         e.pw_wy, e.conv_wy, e.wy_min_tiles, e.wy_min_tiles_tp = self.pw_wy, self.conv_wy, self.wy_min_tiles, self.wy_min_tiles_tp
+        e.reuse_buffers = self.reuse_buffers
         e.satu_t, e.satu_w, e.tail_w, e.tail_b, e.gamma, e.n_l2 = self.satu_t, self.satu_w, self.tail_w, self.tail_b, self.gamma, self.n_l2
         e.iter_win, e.fwd_idx, e.bwd_idx = self.iter_win, self.fwd_idx, self.bwd_idx
         e.satu_tail_t, e.satu_w_tail = self.satu_tail_t, self.satu_w_tail
@@ -463,7 +465,7 @@ class HipEngine:
     # pinning every size it has ever seen (the reference frees everything per frame, video_base_model.py:72-74).
     def _init_caches(self):
         from collections import OrderedDict
-        self.max_shapes = max(1, int(os.environ.get("SAVSR_CACHE_SHAPES", "4")))
+        self.max_shapes = max(1, int(os.environ.get("SAVSR_CACHE_SHAPES", "12")))     # (0.57 GB per 180x320 shape and stream with the liveness plan: 12 shapes = what 4 cost before it)
         self.max_scales = max(1, int(os.environ.get("SAVSR_CACHE_SCALES", "48")))
         self._ctx: "OrderedDict[tuple, dict]" = OrderedDict()
         self._axes: "OrderedDict[tuple, dict]" = OrderedDict()
@@ -516,14 +518,41 @@ class HipEngine:
             for d in shape:
                 n *= int(d)
             nbytes = (4 * n + 255) & ~255
-            arena = owner.setdefault("arena", [])
-            if not arena or arena[-1][1] + nbytes > arena[-1][0].numel():
-                arena.append([torch.empty(max(nbytes, owner.get("chunk", self.ARENA_CHUNK)), device=self.dev, dtype=torch.uint8), 0])
-            chunk, off = arena[-1]
-            t = chunk[off:off + 4 * n].view(torch.float32).view(shape)
-            arena[-1][1] = off + nbytes
+            free = owner.get("free", {}).get(nbytes) if not owner.get("sealed") else None
+            if free:
+                raw = free.pop()                          # a slot whose previous owner's last reader is already enqueued (release())
+            else:
+                arena = owner.setdefault("arena", [])
+                if not arena or arena[-1][1] + nbytes > arena[-1][0].numel():
+                    arena.append([torch.empty(max(nbytes, owner.get("chunk", self.ARENA_CHUNK)), device=self.dev, dtype=torch.uint8), 0])
+                chunk, off = arena[-1]
+                raw = chunk[off:off + nbytes]
+                arena[-1][1] = off + nbytes
+            t = raw[:4 * n].view(torch.float32).view(shape)
             store[key] = t
+            owner.setdefault("raw", {})[t.data_ptr()] = raw
         return t
+
+    # Buffer liveness.  The launch sequence of a clip shape is static, so the assignment of named buffers to memory is decided ONCE, on the
+    # context's first frame: release(x) there returns x's slot to a per-size free list (every reader of x has been enqueued on the one
+    # stream of this engine, and the stream is in-order, so a later writer cannot overtake them), and the next new name of that size takes
+    # it.  After the first frame the context is sealed: names keep their slots (captured hipGraphs hold the pointers), release() does
+    # nothing, and a name first seen later gets fresh memory.  What is released, and where: the network pieces below.
+    def release(self, *xs) -> None:
+        owner = self._cur
+        if owner.get("sealed") or not self.reuse_buffers:
+            return
+        raws = owner.get("raw", {})
+        for x in xs:
+            t = x.t if isinstance(x, Src) else x
+            raw = raws.get(t.data_ptr()) if t is not None else None
+            if raw is not None and not any(raw.data_ptr() == r.data_ptr() for r in owner.setdefault("free", {}).setdefault(raw.numel(), [])):
+                owner["free"][raw.numel()].append(raw)
+
+    def seal_buffers(self) -> None:
+        """End of a context's first frame: the name -> memory assignment is final."""
+        self._cur["sealed"] = True
+        self._cur.pop("free", None)
 
     def buf(self, name: str, *shape: int) -> torch.Tensor:
         """Named LR-sized buffer of the current clip shape."""
@@ -674,6 +703,8 @@ class HipEngine:
             d2 += [self.conv_desc(f"{pfx}.conv2.{i}", [base, x1[i]], o[i], hp, wp, L, 0.2, res1=xs[i]) for i in range(len(xs))]
             outs.append(o)
         self.conv_launch(d2, "conv2")
+        for x1, base in zip(x1s, bases):                 # the block's temporaries are dead (their last readers are enqueued)
+            self.release(*x1, base)
         return outs
 
     def residual_block(self, pfx: str, xs: List[Src], hp: int, wp: int, scale, use_osconv: bool, tag: str) -> List[Src]:
@@ -688,8 +719,15 @@ class HipEngine:
                           for (pfx, win, _, _, _), h in zip(units, hcs)], "win")
         feats = [[self.full(h, nf, 0), self.full(h, nf, nf), past] for (_, _, past, _, _), h in zip(units, hcs)]
         for k in range(self.cfg["w1_num_block"]):
+            prev = feats
             feats = self.residual_blocks([(f"{u[0]}.blocks.{k}", f, f"{u[4]}.b{k}") for u, f in zip(units, feats)], hp, wp, scale, k >= 1)
+            if k >= 1:                                   # the previous block's outputs (this block's inputs / residuals) are dead
+                for f in prev:
+                    self.release(*f)
         self.conv_launch([self.conv_desc(u[0] + ".merge", f, u[3], hp, wp) for u, f in zip(units, feats)], "merge")
+        for f in feats:
+            self.release(*f)
+        self.release(*hcs)
         return [u[3] for u in units]
 
     def rcab(self, pfx: str, x: Src, out: Src, hp: int, wp: int, tag: str) -> Src:
@@ -965,6 +1003,7 @@ class HipEngine:
             cur_b, cur_f = T - 1 - sw // 2 - idx, idx + sw // 2
             hb, hf = self.windows_l1([("f2p_win", win_b(cur_b), hb, self.full(hpair[steps - 1 - idx], nf, 0), "f2p"),
                                       ("p2f_win", win_f(cur_f), hf, self.full(hpair[idx], nf, nf), "p2f")], hp, wp, scale)
+        self.release(zero, *([wins] if cfg["interval"] == 0 else packs))             # (liveness: dead once the recurrence is through)
         # pyramid fusion (:616-618, :485-501, :721-722)
         level: List[Src] = [self.full(t) for t in hpair]
         for i in range(self.n_l2):
@@ -972,12 +1011,19 @@ class HipEngine:
             ws = steps - 2 * i
             hfs = [self.full(self.buf(f"l2.{i}.hf{j}", hp, wp, nf)) for j in range(ws)]       # :488: ws independent convs, one launch
             self.conv_launch([self.conv_desc(f"{u}.conv_h.{j}", [level[j]], hfs[j], hp, wp, ACT_LRELU, 0.2) for j in range(ws)], "conv_h")
+            self.release(*level)                         # this level's inputs (hpair at level 0) are dead
             nxt: List[Src] = []
             for j in range(ws - fw + 1):
                 swf = hfs[j:j + fw]
                 for k in range(cfg["w2_num_block"]):
+                    prev = swf
                     swf = self.residual_block(f"{u}.blocks.{k}", swf, hp, wp, scale, True, f"l2.{i}.{j}.b{k}")
+                    if k >= 1:
+                        self.release(*prev)
                 nxt.append(self.conv(u + ".merge", swf, self.full(self.buf(f"l2.{i}.o{j}", hp, wp, 2 * nf)), hp, wp))
+                if cfg["w2_num_block"] >= 1:
+                    self.release(*swf)
+            self.release(*hfs)                           # (the windows of a level overlap: released once all of them are through)
             level = nxt
         align = self.conv("h_win_conv_h", [level[0]], self.full(self.buf("align", hp, wp, nf)), hp, wp, ACT_LRELU, 0.2)   # :723
         share = align
@@ -991,6 +1037,7 @@ class HipEngine:
                            pool=(self.pool_buf(f"adapt.{g}.adapt", hp, wp, nf), 0, nf))      # OSAdapt's OSConv pools this tensor
             hcur = self.osadapt(g, rg, share, self.full(self.buf(f"rg.h{g & 1}", hp, wp, nf)), hp, wp, scale, pooled=True)
         hfeat = self.conv("conv_last", [hcur], self.full(self.buf("hfeat", hp, wp, nf)), hp, wp, res1=share)   # :733-734
+        self.seal_buffers()                              # the LR buffer plan of this shape is final (align / hfeat / SATU buffers are never shared)
         H, W = get_hw(h_in, w_in, scale)
         plane = self.hr_plane(H, W)
         d = dict(align=align, hfeat=hfeat, wp=wp, h=h_in, w=w_in, H=H, W=W, plane=plane, p27=self.sbuf("satu.p27", _lib.TAIL_PLANES, plane))

@@ -126,3 +126,45 @@ def test_full_size_satu_linearity(net):
     rel = float((y3 - lin).abs().max() / y3.abs().max())
     print("satu linearity rel err", rel)
     assert rel < 5e-5
+
+
+def test_buffer_liveness_plan_bitwise_and_footprint(synth_sd):
+    """The liveness-planned LR buffers (HipEngine.release / seal_buffers): outputs bit for bit those of an engine in which every named
+    buffer has its own memory (SAVSR_REUSE_BUFFERS=0), over several frames (the plan is made on a shape's first frame and replayed),
+    on two shapes and with the graphs off as well; and the footprint of a 180x320 shape is a third of the unshared one."""
+    import os
+    import savsr_amd
+
+    def build(reuse, graphs="1"):
+        os.environ["SAVSR_REUSE_BUFFERS"], os.environ["SAVSR_GRAPHS"] = reuse, graphs
+        try:
+            n = savsr_amd.build_network(dict(type="SAVSR")).eval()
+            n.load_state_dict(synth_sd, strict=True)
+            n = n.to("cuda:0")
+            n.engine()                                        # (the engine reads the switches when it is built)
+            return n
+        finally:
+            os.environ.pop("SAVSR_REUSE_BUFFERS", None)
+            os.environ.pop("SAVSR_GRAPHS", None)
+    nets = {"shared": build("1"), "own": build("0"), "shared_eager": build("1", "0")}
+    for (h, w, sc) in ((36, 40, (2.5, 3.5)), (21, 50, (4, 4)), (36, 40, (2.5, 3.5))):
+        outs = {}
+        for name, n in nets.items():
+            n.set_scale(sc)
+            frames = [n(synth.synth_clip(7, 3, h, w, seed=s).to("cuda:0")).clone() for s in (0, 1, 0)]
+            torch.cuda.synchronize()
+            assert torch.equal(frames[0], frames[2])
+            outs[name] = frames
+        for k in range(3):
+            assert torch.equal(outs["shared"][k], outs["own"][k]) and torch.equal(outs["shared_eager"][k], outs["own"][k])
+    big = {}
+    for name in ("shared", "own"):
+        n = nets[name]
+        n.set_scale((4, 4))
+        n(synth.synth_clip(7, 3, 180, 320, seed=0).to("cuda:0"))
+        torch.cuda.synchronize()
+        eng = n.engine()
+        ctx = eng._ctx[(7, 3, 180, 320)] if (7, 3, 180, 320) in eng._ctx else list(eng._ctx.values())[-1]
+        big[name] = sum(a[1] for a in ctx.get("arena", []))     # bytes bump-allocated for this shape's LR buffers
+    print("LR buffer bytes per 180x320 shape: shared %.3f GB, own %.3f GB" % (big["shared"] / 1e9, big["own"] / 1e9))
+    assert big["shared"] < 0.45 * big["own"]
