@@ -106,6 +106,10 @@ class VideoTestDataset:
         """Global frame indices owned by `rank` (contiguous per-folder blocks) -- and from here on this dataset object
         only ever decodes / uploads / synthesises the frames those windows read."""
         owned = block_partition(self.folder_sizes(), rank, world)
+        if world <= 1:                                   # the whole dataset again (undoes an earlier shard): every frame loadable
+            self._need = None
+            self._resident.clear()
+            return owned
         self._need = {}
         base = 0
         for name, paths in self.imgs_gt.items():
@@ -121,10 +125,17 @@ class VideoTestDataset:
         need = getattr(self, "_need", None)
         return list(range(len(self.imgs_gt[folder]))) if need is None else need[folder]
 
+    def _read_lists(self, folder: str) -> List[List[str]]:
+        """The path lists _load_folder really reads for `folder` (GT always; the LR files only when the LR frames come from disk)."""
+        lists = [self.imgs_gt[folder]]
+        if not self._synthesise() and self.imgs_lq[folder] is not self.imgs_gt[folder]:
+            lists.append(self.imgs_lq[folder])
+        return lists
+
     def prefetch(self, folder: str) -> None:
         """Start decoding the needed files of `folder` in the background (the validation loop calls this one folder ahead)."""
         store = sio.frame_store()
-        for paths in {id(self.imgs_gt[folder]): self.imgs_gt[folder], id(self.imgs_lq[folder]): self.imgs_lq[folder]}.values():
+        for paths in self._read_lists(folder):
             store.request([paths[i] for i in self.needed(folder)])
 
     # ---- per-folder residency -----------------------------------------------------------------------------------
@@ -211,6 +222,9 @@ class ASVideoTestDataset(VideoTestDataset):
         if self.opt.get("cache_data"):
             return True
         return bool(self.opt["use_arbitrary_scale_downsampling"])
+
+    def _read_lists(self, folder: str) -> List[List[str]]:
+        return [self.imgs_gt[folder]]                    # GT only: without synthesis the GT frames ARE the network input (video_test_dataset.py:308-313)
 
     def _load_folder(self, folder: str) -> dict:
         scale = self.opt["scale"]

@@ -153,14 +153,48 @@ class FrameStore:
             self.stats["decoded"] += 1
         return img
 
+    def _evict_host(self, keep) -> None:
+        """(under the lock) Drop decoded arrays, oldest first, until the host cap holds; in-flight decodes are skipped, not a stop sign."""
+        if self._host_bytes <= self.host_cap:
+            return
+        for ok in list(self._host.keys()):
+            if self._host_bytes <= self.host_cap:
+                break
+            ov = self._host[ok]
+            if ok == keep or isinstance(ov, Future):
+                continue
+            self._host.pop(ok)
+            self._host_bytes -= ov.nbytes
+
+    def _settle(self, k, fut: Future) -> None:
+        """A decode has finished (worker thread or the waiting caller, whoever comes first): the array replaces its Future and is
+        counted against SAVSR_DECODE_CACHE_GB; a failed decode is dropped so that the next request tries again."""
+        with self._lock:
+            if self._host.get(k) is not fut:
+                return
+            if fut.cancelled() or fut.exception() is not None:
+                self._host.pop(k, None)
+                return
+            img = fut.result()
+            self._host[k] = img
+            self._host_bytes += img.nbytes
+            self._shape[k] = (int(img.shape[0]), int(img.shape[1]))
+            self._evict_host(k)
+
     def request(self, paths: Iterable[str]) -> None:
-        """Start decoding `paths` in the background (no-op for files already decoded or in flight)."""
+        """Start decoding `paths` in the background (no-op for files already decoded or in flight).  At most 8 files per worker are in
+        flight: what is beyond that is decoded when it is asked for (host()), so a folder prefetch cannot pile up undecoded work or
+        arrays nobody has counted yet."""
         for p in paths:
             k = self._key(p)
             with self._lock:
                 if k in self._host or self._dev_files.get(k, 0) > 0:
                     continue
-                self._host[k] = self._pool.submit(self._decode, p)
+                if sum(1 for v in self._host.values() if isinstance(v, Future)) >= 8 * self.workers:
+                    return
+                fut = self._pool.submit(self._decode, p)
+                self._host[k] = fut
+            fut.add_done_callback(lambda f, k=k: self._settle(k, f))
 
     def host(self, path: str) -> np.ndarray:
         """HWC RGB uint8 of one file (blocks until its decode is done; decodes here when nobody requested it)."""
@@ -175,18 +209,13 @@ class FrameStore:
                 self._host.move_to_end(k)
                 self._shape[k] = (int(ent.shape[0]), int(ent.shape[1]))
                 return ent
-        img = ent.result()
+        try:
+            img = ent.result()
+        except Exception:
+            self._settle(k, ent)                        # (drops the failed entry)
+            raise
+        self._settle(k, ent)
         self._shape[k] = (int(img.shape[0]), int(img.shape[1]))
-        with self._lock:
-            if isinstance(self._host.get(k), Future):
-                self._host[k] = img
-                self._host_bytes += img.nbytes
-                while self._host_bytes > self.host_cap and len(self._host) > 1:
-                    ok, ov = next(iter(self._host.items()))
-                    if ok == k or isinstance(ov, Future):
-                        break
-                    self._host.pop(ok)
-                    self._host_bytes -= ov.nbytes
         return img
 
     def host_shape(self, path: str) -> Tuple[int, int]:

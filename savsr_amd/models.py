@@ -155,7 +155,12 @@ class VideoBaseModel(BaseModel):
             while k1 < len(mine) and folders_all[mine[k1]] == f0:
                 k1 += 1
             g_f = group if k1 - k >= 4 * group else (min(group, 2) if k1 - k >= 6 else 1)
-            chunks += [(a, min(a + g_f, k1)) for a in range(k, k1, g_f)]
+            fc = [(a, min(a + g_f, k1)) for a in range(k, k1, g_f)]
+            if g_f > 1 and len(fc) >= 2 and fc[-1][1] - fc[-1][0] == 1:
+                # a lone leftover frame (34 or 40 frames over 3 streams) would go through test() = the one-clip graphs, a second set of
+                # captures per (folder, scale) for a single frame: it joins the previous group instead (forward_many takes any count)
+                fc[-2:] = [(fc[-2][0], fc[-1][1])]
+            chunks += fc
             k = k1
         for k0, k_end in chunks:
             f0 = folders_all[mine[k0]]

@@ -97,3 +97,46 @@ def test_frame_store_decodes_each_file_once(tmp_path):
     for p in paths:
         small.host(p)
     assert small._host_bytes <= 700 + 14 * 12 * 3
+
+
+def test_frame_store_host_cap_counts_prefetched_files(tmp_path):
+    """SAVSR_DECODE_CACHE_GB is enforced for prefetched files too: a decode started by request() is counted when it completes (not only
+    when somebody waits for it), the eviction loop steps over decodes still in flight, a failed decode does not stay cached, and
+    request() keeps a bounded number of decodes in flight."""
+    import time
+    rng = np.random.RandomState(3)
+    paths = []
+    for i in range(12):
+        p = str(tmp_path / f"{i:03d}.png")
+        io.imwrite(rng.randint(0, 255, (32, 48, 3), dtype=np.uint8), p)
+        paths.append(p)
+    one = 32 * 48 * 3
+    store = io.FrameStore(host_bytes=3 * one, device_bytes=1 << 30, workers=2)
+    store.request(paths)
+    from concurrent.futures import Future
+    for _ in range(500):                                   # the pool finishes without anybody calling host()
+        with store._lock:
+            busy = any(isinstance(v, Future) for v in store._host.values())
+        if store.stats["decoded"] == len(paths) and not busy:
+            break
+        time.sleep(0.01)
+    assert store.stats["decoded"] == len(paths)
+    assert store._host_bytes <= 3 * one and store._host_bytes == sum(v.nbytes for v in store._host.values() if isinstance(v, np.ndarray))
+    assert len(store._host) <= 3
+    a = store.host(paths[-1])                              # still there (newest) or decoded again: same pixels either way
+    assert a.shape == (32, 48, 3)
+    bad = str(tmp_path / "broken.png")
+    open(bad, "wb").write(b"not a png")
+    store.request([bad])
+    for _ in range(500):
+        if store._key(bad) not in store._host:
+            break
+        time.sleep(0.01)
+    assert store._key(bad) not in store._host              # the failed decode was dropped ...
+    with pytest.raises(Exception):
+        store.host(bad)                                    # ... and asking for the file raises (again) instead of serving a poisoned entry
+    assert store._key(bad) not in store._host
+    big = io.FrameStore(host_bytes=1 << 30, device_bytes=1 << 30, workers=1)
+    big.request(paths)                                     # at most 8 per worker in flight; the rest is decoded on demand
+    assert len(big._host) <= 8
+    assert all(big.host(p).shape == (32, 48, 3) for p in paths)
