@@ -360,6 +360,33 @@ def test_satu_large_offsets_and_borders(eng, synth_sd):
         assert e < 3e-5
 
 
+def test_satu_lr_stage_adversarial_kernel_outputs(eng, synth_sd):
+    """satu_lr_stream_kernel accumulates LeakyReLU_0.1(K) * x as 0.55 sum(x K) + 0.45 sum(x |K|) (LRS_LRELU 1: two independent FMA
+    chains instead of mul / max / fmac per element, savsr_arch.py:297-313).  Where the predicted kernels K are mostly NEGATIVE and large the
+    two sums nearly cancel (result ~0.1 sum x K): the absolute error is ~eps * sum |x K|, up to ~10 x the relative error of the per-element
+    form.  This drives exactly that regime -- kernel_conv with a large negative bias and amplified weights -- and holds the WHOLE SATU
+    output to an explicit bound relative to the magnitude of the dynamic-filter term."""
+    from savsr_amd.engine import HipEngine
+    from savsr_amd.archs.savsr_arch import SAVSR
+    sd = dict(synth_sd)
+    sd["upsample.kernel_conv.0.weight"] = sd["upsample.kernel_conv.0.weight"] * 4.0
+    sd["upsample.kernel_conv.0.bias"] = sd["upsample.kernel_conv.0.bias"] - 3.0
+    e2 = HipEngine(sd, SAVSR().cfg, torch.device("cuda:0"))
+    x = rnd((1, 64, 11, 13), 61, 1.0)
+    st = rnd((1, 64, 11, 13), 62, 0.6)
+    with torch.no_grad():
+        k = F.conv2d(st, sd["upsample.kernel_conv.0.weight"], sd["upsample.kernel_conv.0.bias"])
+    assert float((k < 0).float().mean()) > 0.8 and float(k.abs().mean()) > 2.0            # mostly negative, large: the cancelling regime
+    for sc in [(4, 4), (2.5, 1.3)]:
+        out = _run_satu(e2, x, st, sc)
+        with torch.no_grad():
+            ref = O.sta_upsample(sd, "upsample", x, sc, st)[0]
+        mag = float(ref.abs().max())
+        e = _maxerr(out, ref)
+        print('adversarial kernel_conv', sc, 'max-abs', e, 'output magnitude', mag)
+        assert e < 2e-5 * max(1.0, mag)         # measured: see the printed value; the default-weights bound is 2e-5 on magnitude ~4
+
+
 def test_satu_strided_crop(eng, synth_sd):
     """SATU reads crops of padded tensors through strides (savsr_arch.py:737)."""
     from savsr_amd.engine import get_hw

@@ -3,7 +3,9 @@
 #   bench_stats.csv      rocprofv3 --kernel-trace --stats of the DRIVER's command (python3 bench.py --gpus 1 --steps 20 --warmup 5)
 #   satu_stats.csv       ... of the SATU launches alone (tools/time_satu.py, HR plan forced)
 #   satu_pmc.csv         7 PMC passes over the SATU launches (tools/pmc_satu.sh)
-#   conv_pmc.csv         7 PMC passes over the dominant conv launch (6 x 128->64)
+#   conv_wy_pmc.csv      7 PMC passes over the dominant conv launch (6 x 128->64) in the form the product runs (Winograd-y)
+#   conv_pmc.csv         ... and in the direct form
+#   satu_traffic.json    profiles/satu_traffic.json regenerated from satu_pmc.csv, stamped with the library's SATU source hash
 #   bench_line.json      the bench line of the same lease, un-profiled
 set -u
 OUT=${1:-gpurun_out/r03_prof}
@@ -24,5 +26,7 @@ for d in bench_prof satu_prof; do
   rm -rf "$OUT/$d"
 done
 bash tools/pmc_satu.sh "$OUT/pmc_satu" && cp "$OUT/pmc_satu/summary.csv" "$OUT/satu_pmc.csv"
+PMC_TARGET="conv 128 64 3 --batch 6 --distinct --wy" bash tools/pmc_satu.sh "$OUT/pmc_conv_wy" && cp "$OUT/pmc_conv_wy/summary.csv" "$OUT/conv_wy_pmc.csv"
 PMC_TARGET="conv 128 64 3 --batch 6 --distinct" bash tools/pmc_satu.sh "$OUT/pmc_conv" && cp "$OUT/pmc_conv/summary.csv" "$OUT/conv_pmc.csv"
+python3 tools/make_satu_traffic.py "$OUT/satu_pmc.csv" --source "profiles/r04_satu_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/time_satu.py with the HR plan forced, tools/pmc_satu.sh; FETCH_SIZE x 2 per MI355X_MICROARCH.md; KiB)" > "$OUT/satu_traffic.json"
 ls -la "$OUT"
