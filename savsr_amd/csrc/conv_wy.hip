@@ -405,16 +405,6 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
             if (rows_in) phase(std::true_type{}); else phase(std::false_type{});
         }
 
-        // ---- output transform (in registers): row 0 = M0 + M1 + M2 -> acc[0], row 1 = M1 - M2 - M3 -> acc[3] ------------------
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float m1 = acc[1][t][i], m2 = acc[2][t][i];
-                acc[0][t][i] = (acc[0][t][i] + m1) + m2;
-                acc[3][t][i] = (m1 - m2) - acc[3][t][i];
-            }
-
         // ---- epilogue: as the direct kernel's (conv_mfma.hip): transpose through the wave's LDS slice 32 channels at a time, whole
         // pixel records out, fused bias / activation / per-pixel mask / two residuals / global-average-pool partials.  Rows of wave w:
         // y0 + 2 w + r.  Every load below is unconditional and used on every path (absent operands read 16 B of zeros).
@@ -440,7 +430,6 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
         f32x4 bias4[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) bias4[t] = ldg4(b_base, b_off + (unsigned)t * b_step);
-        __builtin_amdgcn_sched_barrier(0);         // (the loads below must not be hoisted above the transform: all 128 accumulator registers are live there)
         const float* r1_base = e_r1 ? e_r1 : zero16;
         constexpr int RR = 2;                      // residual quads of two (row, channel-group) steps in flight (a ring): the first two go out together.
         f32x4 rr[RR][4];                           // (all four at once, into the registers of the accumulator sets the transform has retired: 22 spilled registers)
@@ -457,6 +446,16 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
         };
 #pragma unroll
         for (int gi = 0; gi < RR; ++gi) load_r1(gi / 2, gi % 2, rr[gi]);
+        // ---- output transform (in registers), under the round trip of the loads above: row 0 = M0 + M1 + M2 -> acc[0], row 1 = M1 - M2 - M3 -> acc[3]
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float m1 = acc[1][t][i], m2 = acc[2][t][i];
+                acc[0][t][i] = (acc[0][t][i] + m1) + m2;
+                acc[3][t][i] = (m1 - m2) - acc[3][t][i];
+            }
         f32x4 psum[2][2];
 #pragma unroll
         for (int r = 0; r < ((WY_EXP & 16) ? 0 : 2); ++r) {
