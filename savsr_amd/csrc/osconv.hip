@@ -294,6 +294,165 @@ __global__ __launch_bounds__(512) void osconv_aggregate_kernel(const OscBatch bt
     img[group * 128 + 64 + ln] = lo;
 }
 
+// The same weight generation for a conv that runs in the Winograd F(2,3)-along-y form (conv_wy.hip, SAVSR_CONV_WINOGRAD_Y): per (co, ci, kx) the three
+// aggregated and gated taps g_ky = fa[co] ca[ci] sa[ky, kx] sum_k ka[k] W[k][co][ci][ky][kx] -- the spatial gate sa is applied BEFORE the transform, it
+// depends on ky -- then U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2, split and written in the order of
+// savsr_conv_wy_pack_index.  One thread = one float4 half of an 8-element lane unit of (cob, chunk, kx, t): 3 x knum x 16 B of bank data per thread.
+__global__ __launch_bounds__(512) void osconv_aggregate_wy_kernel(const OscBatch bt) {
+    const savsr_osconv_attn_desc& d = bt.d[blockIdx.y];
+    extern __shared__ float sm[];
+    float* v2 = sm;                        // [cin]
+    float* a = v2 + d.cin;                 // [hidden]
+    float* gates = a + d.hidden;           // [cin + cout + 9 + knum]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int OSC_MAX_KNUM = 8;
+    const int nt = 2, nchunk = d.cin / 16;                       // cout % 64 == 0 (checked by the launcher)
+    const long long item = (long long)blockIdx.x * 512 + tid;   // ((((cob * nchunk + chunk) * 3 + kx) * nt + t) * 64 + ln) * 2 + h4
+    const long long nitems = (long long)(d.cout / 64) * nchunk * 3 * nt * 64 * 2;
+    const bool live = item < nitems;
+    const int h4 = (int)(item & 1);
+    const long long u = item >> 1;
+    const int ln = (int)(u & 63);
+    long long g2 = u >> 6;
+    const int t = (int)(g2 % nt); g2 /= nt;
+    const int kx = (int)(g2 % 3); g2 /= 3;
+    const int chunk = (int)(g2 % nchunk);
+    const int cob = (int)(g2 / nchunk);
+    // bank loads first: they do not depend on the gates and land under the attention heads below
+    f32x4 bw[3][OSC_MAX_KNUM];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const long long unit = ((((long long)(cob * nchunk + chunk) * 9 + (ky * 3 + kx)) * nt + t) << 6) + ln;     // the direct image's unit of this tap
+#pragma unroll
+        for (int k = 0; k < OSC_MAX_KNUM; ++k) {
+            bw[ky][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (live && k < d.knum) bw[ky][k] = reinterpret_cast<const f32x4*>(d.bank + ((long long)k * d.nunits + unit) * 8)[h4];
+        }
+    }
+    // ... and so do the head weights of this wave / thread (hidden <= 32 and cin <= 320, checked by the launcher):
+    //   fc rows wave, wave + 8, .. (<= 4 rows x 5 column slices) and ONE gate row per thread (ngate <= 512 covers
+    //   cin + cout + 9 + knum of every OSConv of the network; larger ones loop below)
+    constexpr int FC_ROWS = 4, FC_J = 5, GH = 32;
+    float fw[FC_ROWS][FC_J];
+#pragma unroll
+    for (int j = 0; j < FC_ROWS; ++j)
+#pragma unroll
+        for (int q = 0; q < FC_J; ++q) {
+            const int r = wave + 8 * j, c = lane + 64 * q;
+            fw[j][q] = (r < d.hidden && c < d.cin) ? d.fc_w[(long long)r * d.cin + c] : 0.f;
+        }
+    const int ngate = d.cin + d.cout + 9 + d.knum;
+    auto gate_row = [&](int i, float& bias) -> const float* {
+        int j = i;
+        if (j < d.cin) { bias = d.ch_b[j]; return d.ch_w + (long long)j * d.hidden; }
+        if ((j -= d.cin) < d.cout) { bias = d.fl_b[j]; return d.fl_w + (long long)j * d.hidden; }
+        if ((j -= d.cout) < 9) { bias = d.sp_b[j]; return d.sp_w + (long long)j * d.hidden; }
+        j -= 9;
+        bias = d.kn_b[j];
+        return d.kn_w + (long long)j * d.hidden;
+    };
+    float gw[GH], gbias = 0.f;
+    {
+        const float* wr = tid < ngate ? gate_row(tid, gbias) : nullptr;
+#pragma unroll
+        for (int k = 0; k < GH; ++k) gw[k] = (wr && k < d.hidden) ? wr[k] : 0.f;
+    }
+    for (int i = tid; i < d.cin; i += 512) v2[i] = d.v2[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FC_ROWS; ++j) {
+        const int r = wave + 8 * j;
+        float acc = 0.f;                              // per lane in column order, then across the wave: the order of wave_dot
+#pragma unroll
+        for (int q = 0; q < FC_J; ++q) {
+            const int c = lane + 64 * q;
+            if (c < d.cin) acc += fw[j][q] * v2[c];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0 && r < d.hidden) a[r] = fmaxf(acc * d.bn_scale[r] + d.bn_shift[r], 0.f);
+    }
+    __syncthreads();
+    if (tid < ngate) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < GH; ++k)
+            if (k < d.hidden) acc += gw[k] * a[k];
+        acc += gbias;
+        gates[tid] = (tid < d.cin + d.cout + 9) ? sigmoidf_(acc) : acc;   // kernel logits stay raw here
+    }
+    for (int i = tid + 512; i < ngate; i += 512) {
+        float bias;
+        const float* wr = gate_row(i, bias);
+        float acc = 0.f;
+        for (int k = 0; k < d.hidden; ++k) acc += wr[k] * a[k];
+        acc += bias;
+        gates[i] = (i < d.cin + d.cout + 9) ? sigmoidf_(acc) : acc;
+    }
+    __syncthreads();
+    float* ka = gates + d.cin + d.cout + 9;
+    if (tid == 0) {                        // softmax over the kernels, temperature 1 (:88)
+        float m = ka[0];
+        for (int k = 1; k < d.knum; ++k) m = fmaxf(m, ka[k]);
+        float s = 0.f;
+        for (int k = 0; k < d.knum; ++k) { ka[k] = expf(ka[k] - m); s += ka[k]; }
+        for (int k = 0; k < d.knum; ++k) ka[k] = ka[k] / s;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && d.att)
+        for (int i = tid; i < ngate; i += 512) d.att[i] = gates[i];
+
+    if (!live) return;
+    const int row = ln & 31, kh = ln >> 5;
+    const int co = cob * 64 + 32 * t + row;
+    const int ci0 = chunk * 16 + kh * 8 + 4 * h4;
+    const float* ka_ = gates + d.cin + d.cout + 9;
+    const float* ca = gates + ci0;
+    f32x4 g[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < OSC_MAX_KNUM; ++k)
+            if (k < d.knum) {
+                const float kk = ka_[k];
+                s0[0] += kk * bw[ky][k][0]; s0[1] += kk * bw[ky][k][1]; s0[2] += kk * bw[ky][k][2]; s0[3] += kk * bw[ky][k][3];
+            }
+        for (int k = OSC_MAX_KNUM; k < d.knum; ++k) {
+            const long long unit = ((((long long)(cob * nchunk + chunk) * 9 + (ky * 3 + kx)) * nt + t) << 6) + ln;
+            const f32x4 w0 = reinterpret_cast<const f32x4*>(d.bank + ((long long)k * d.nunits + unit) * 8)[h4];
+            const float kk = ka_[k];
+            s0[0] += kk * w0[0]; s0[1] += kk * w0[1]; s0[2] += kk * w0[2]; s0[3] += kk * w0[3];
+        }
+        const float gco = gates[d.cin + co] * gates[d.cin + d.cout + ky * 3 + kx];      // same product order as the direct kernel: (fa sa) ca
+        s0[0] *= gco * ca[0]; s0[1] *= gco * ca[1]; s0[2] *= gco * ca[2]; s0[3] *= gco * ca[3];
+        g[ky] = s0;
+    }
+    f32x4 uu[4];
+    uu[0] = g[0];
+    uu[3] = g[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float sgl = g[0][j] + g[2][j];
+        uu[1][j] = 0.5f * (sgl + g[1][j]);
+        uu[2][j] = 0.5f * (sgl - g[1][j]);
+    }
+    bf16x4* img = reinterpret_cast<bf16x4*>(d.wimg_out);
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+        const int hf = pos >> 1, vr = pos & 1;
+        const long long group = ((((long long)(cob * nchunk + chunk) * 2 + hf) * 6 + (vr * 3 + kx)) * nt + t);
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 hh = (__bf16)uu[pos][j];
+            hi[j] = hh;
+            lo[j] = (__bf16)(uu[pos][j] - (float)hh);
+        }
+        img[(group * 128 + ln) * 2 + h4] = hi;                 // units of 16 B = two bf16x4
+        img[(group * 128 + 64 + ln) * 2 + h4] = lo;
+    }
+}
+
 // RCAN ChannelAttention MLP (savsr_arch.py:514-520); one workgroup of 1024 threads (latency-bound: the pooled-sum
 // reduction runs as 16 short interleaved row slices per channel).
 constexpr int SE_PARTS = 16;
@@ -458,8 +617,8 @@ extern "C" int savsr_osconv_weights_batch(const savsr_osconv_attn_desc* descs, i
         const int rc = check_osconv_desc(descs + i);
         if (rc) return rc;
         if (descs[i].cin != descs[0].cin || descs[i].cout != descs[0].cout || descs[i].hidden != descs[0].hidden ||
-            descs[i].knum != descs[0].knum || descs[i].nunits != descs[0].nunits)
-            return fail_arg("osconv_weights: all OSConvs of a batch must share cin / cout / hidden / knum");
+            descs[i].knum != descs[0].knum || descs[i].nunits != descs[0].nunits || (descs[i].wy != 0) != (descs[0].wy != 0))
+            return fail_arg("osconv_weights: all OSConvs of a batch must share cin / cout / hidden / knum / wy");
         bt.d[i] = descs[i];
     }
     for (int i = n; i < OSC_MAX_BATCH; ++i) bt.d[i] = descs[0];
@@ -472,6 +631,12 @@ extern "C" int savsr_osconv_weights_batch(const savsr_osconv_attn_desc* descs, i
     rc = check_launch("osconv_l2_kernel");
     if (rc) return rc;
     const size_t lds = sizeof(float) * ((size_t)d->cin + d->hidden + d->cin + d->cout + 9 + d->knum);
+    if (d->wy) {
+        if (d->cout % 64 || d->cin % 16) return fail_arg("osconv_weights: the Winograd-y image needs cout % 64 == 0 and cin % 16 == 0");
+        const long long nitems = (long long)(d->cout / 64) * (d->cin / 16) * 3 * 2 * 64 * 2;
+        hipLaunchKernelGGL(osconv_aggregate_wy_kernel, dim3((unsigned)((nitems + 511) / 512), n), dim3(512), lds, st, bt);
+        return check_launch("osconv_aggregate_wy_kernel");
+    }
     hipLaunchKernelGGL(osconv_aggregate_kernel, dim3((unsigned)((d->nunits + 511) / 512), n), dim3(512), lds, st, bt);
     return check_launch("osconv_aggregate_kernel");
 }

@@ -263,7 +263,8 @@ class HipEngine:
                    kn_w=g(a + ".kernel_fc.weight"), kn_b=g(a + ".kernel_fc.bias"),
                    v1=torch.empty(2 * cin, device=self.dev), v2=torch.empty(cin, device=self.dev),
                    att=torch.empty(cin + cout + 9 + knum, device=self.dev),
-                   wdyn=torch.empty(2 * elems, device=self.dev, dtype=torch.int16))
+                   wdyn=torch.empty(2 * elems, device=self.dev, dtype=torch.int16),
+                   wdyn_wy=torch.empty(2 * (elems * 4 // 3) if cout % 64 == 0 else 0, device=self.dev, dtype=torch.int16))     # (12 taps instead of 9)
         self.osc[key] = ent
 
     def _pack_satu(self, sd):
@@ -446,7 +447,7 @@ class HipEngine:
         e.osc = {}
         for k, ent in self.osc.items():
             c = dict(ent)
-            for name in ("v1", "v2", "att", "wdyn"):
+            for name in ("v1", "v2", "att", "wdyn", "wdyn_wy"):
                 c[name] = torch.empty_like(ent[name])
             e.osc[k] = c
         e.se_gate = torch.empty_like(self.se_gate)
@@ -638,7 +639,14 @@ class HipEngine:
         savsr_channel_sums workgroup."""
         return self.buf("pool." + key, max(self.pool_rows(h, w), MAX_SUM_BLOCKS) * cin)
 
-    def osconv_desc(self, key: str, srcs: List[Src], h: int, w: int, scale, pooled: bool = False) -> OSConvAttnDesc:
+    def osconv_wy(self, n_convs: int, cout: int, h: int, w: int) -> bool:
+        """Whether the dynamic convs of a launch of `n_convs` OSConvs run in the Winograd-y form (the rule of conv_launch)."""
+        if not self.conv_wy or cout % 64:
+            return False
+        tiles = n_convs * (cout // 64) * ((h + 15) // 16) * ((w + 31) // 32)
+        return tiles >= (self.wy_min_tiles_tp if self.conv_algo == _lib.CONV_DIRECT_THROUGHPUT else self.wy_min_tiles)
+
+    def osconv_desc(self, key: str, srcs: List[Src], h: int, w: int, scale, pooled: bool = False, wy: bool = False) -> OSConvAttnDesc:
         """Descriptor of one OSConv's weight generation (pool -> routing/attention -> aggregated split-bf16 image,
         savsr_arch.py:143-163).  pooled=True: the producing convs already wrote the pool partials (fused epilogue);
         otherwise the pooling kernel is launched here."""
@@ -653,7 +661,8 @@ class HipEngine:
         for k in ("l1_w", "l1_b", "l2_w", "l2_b", "fc_w", "bn_scale", "bn_shift", "ch_w", "ch_b", "fl_w", "fl_b",
                   "sp_w", "sp_b", "kn_w", "kn_b", "v1", "v2", "bank", "att"):
             setattr(d, k, e[k].data_ptr())
-        d.wimg_out = e["wdyn"].data_ptr()
+        d.wy = 1 if wy else 0
+        d.wimg_out = (e["wdyn_wy"] if wy else e["wdyn"]).data_ptr()
         return d
 
     def osconv_launch(self, keys: List[str], descs: List[OSConvAttnDesc]):
@@ -664,10 +673,11 @@ class HipEngine:
             chunk = descs[i:i + 6]
             arr = (OSConvAttnDesc * len(chunk))(*chunk)
             _lib.check(self.lib.savsr_osconv_weights_batch(arr, len(chunk), st), f"savsr_osconv_weights_batch[{keys[i]}]")
-        return [(self.osc[k]["wdyn"], None, self.osc[k]["cout"], self.osc[k]["cin"], 3) for k in keys]
+        return [(self.osc[k]["wdyn_wy"], None, self.osc[k]["cout"], self.osc[k]["cin"], 3, _lib.CONV_WINOGRAD_Y) if dsc.wy else
+                (self.osc[k]["wdyn"], None, self.osc[k]["cout"], self.osc[k]["cin"], 3) for k, dsc in zip(keys, descs)]
 
-    def osconv_weights(self, key: str, srcs: List[Src], h: int, w: int, scale, pooled: bool = False):
-        return self.osconv_launch([key], [self.osconv_desc(key, srcs, h, w, scale, pooled)])[0]
+    def osconv_weights(self, key: str, srcs: List[Src], h: int, w: int, scale, pooled: bool = False, wy: bool = False):
+        return self.osconv_launch([key], [self.osconv_desc(key, srcs, h, w, scale, pooled, wy)])[0]
 
     # ------------------------------------------------------------------ network pieces
     def residual_blocks(self, groups: List[Tuple[str, List[Src], str]], hp: int, wp: int, scale, use_osconv: bool) -> List[List[Src]]:
@@ -688,7 +698,8 @@ class HipEngine:
         bases, d1 = [], []
         if use_osconv:                                   # the groups' OSConvs are independent: one batched weight generation
             keys = [pfx + ".osconv" for pfx, _, _ in groups]
-            wds = self.osconv_launch(keys, [self.osconv_desc(k, x1, hp, wp, scale, pooled=True) for k, x1 in zip(keys, x1s)])
+            wy = self.osconv_wy(len(groups), nf, hp, wp)      # the dynamic convs below go out as ONE launch: its form decides the image's
+            wds = self.osconv_launch(keys, [self.osconv_desc(k, x1, hp, wp, scale, pooled=True, wy=wy) for k, x1 in zip(keys, x1s)])
         for gi, ((pfx, xs, tag), x1) in enumerate(zip(groups, x1s)):
             base = self.full(self.buf(f"{tag}.base", hp, wp, nf))
             if use_osconv:
@@ -760,7 +771,7 @@ class HipEngine:
         _lib.check(self.lib.savsr_upsample2x(m4.ptr, m5.data_ptr(), c4, h2, w2, st), "savsr_upsample2x")
         mask = self.buf("ad.mask", hp, wp, 1)
         self.conv(m + ".11", [self.full(m5)], self.full(mask), hp, wp, ACT_SIGMOID)
-        wd = self.osconv_weights(f"adapt.{g}.adapt", [x], hp, wp, scale, pooled=pooled)
+        wd = self.osconv_weights(f"adapt.{g}.adapt", [x], hp, wp, scale, pooled=pooled, wy=self.osconv_wy(1, self.nf, hp, wp))
         return self.conv(f"adapt.{g}.adapt", [x], out, hp, wp, ACT_NONE, mul_px=mask, res1=x, res2=share,
                          res2_scale=self.gamma, weights=wd)
 

@@ -263,6 +263,37 @@ def test_osconv_vs_golden(eng, golden, synth_sd, tag, pfx, cin):
         assert _maxerr(att, ref_att) < 1e-5
 
 
+@pytest.mark.parametrize("pfx,cin", [("f2p_win.blocks.1.osconv", 192), ("h_win.0.blocks.0.osconv", 320), ("adapt.0.adapt", 64)])
+def test_osconv_winograd_image(eng, synth_sd, pfx, cin):
+    """OSConv weight generation straight into the Winograd-y image (osconv_aggregate_wy_kernel, savsr_osconv_attn_desc.wy): the decoded image is
+    the F(2,3) transform over the tap rows of the decoded DIRECT image of the same launch (the spatial gate applied per tap, before the
+    transform), and the dynamic conv run in the Winograd form agrees with the direct form within the per-kernel bound."""
+    from savsr_amd import engine as E
+    h, w, sc = 18, 40, (2.5, 3.5)
+    x = rnd((1, cin, h, w), 71 + cin, 0.7)
+    nsrc = cin // 64
+    xall = cl(x[0])
+    srcs = [eng.full(xall, 64, i * 64) for i in range(nsrc)]
+    outs = {}
+    for wy in (False, True):
+        wd = eng.osconv_weights(pfx, srcs, h, w, sc, wy=wy)
+        assert (len(wd) == 6) == wy
+        o = torch.empty(h, w, 64, device="cuda:0")
+        eng.conv(pfx, srcs, eng.full(o), h, w, weights=wd)
+        torch.cuda.synchronize()
+        outs[wy] = o
+    ent = eng.osc[pfx]
+    dec = lambda img: (lambda v: (v[:, 0] + v[:, 1]).reshape(-1))(img.view(torch.bfloat16).view(-1, 2, 512).double().cpu())
+    g = dec(ent["wdyn"])[torch.from_numpy(E.conv_pack_index(64, cin, 3)[0])].reshape(64, cin, 3, 3)           # [co][ci][ky][kx]
+    u = dec(ent["wdyn_wy"])[torch.from_numpy(E.conv_wy_pack_index(64, cin)[0])].reshape(4, 64, cin, 3)       # [pos][co][ci][kx]
+    ref = torch.stack([g[:, :, 0], 0.5 * (g[:, :, 0] + g[:, :, 1] + g[:, :, 2]), 0.5 * (g[:, :, 0] - g[:, :, 1] + g[:, :, 2]), g[:, :, 2]], 0)
+    scale_ = float(g.abs().max())
+    assert float((u - ref).abs().max()) < 2e-5 * scale_                      # both images are (hi, lo) splits of fp32 values: ~2^-16 each
+    e = _maxerr(outs[True], outs[False])
+    print(pfx, "osconv winograd vs direct max-abs", e, "of", float(outs[False].abs().max()))
+    assert e < 3e-5
+
+
 def test_conv_fused_pool(eng):
     """Fused AdaptiveAvgPool2d(1) partials of the conv epilogue == mean of the stored tensor."""
     from savsr_amd import engine as E
