@@ -47,9 +47,14 @@
 namespace savsr {
 
 namespace wy {
-constexpr int TH = 16, TW = 32, IC = TW + 2, NTHR = 512, COT = 64;
-constexpr int V_PLANE = 2 * IC;                    // 16-B units of one (half, row, part) plane: [q 2][px IC]
-constexpr int V_WAVE = 2 * 2 * 2 * V_PLANE;        // [hf][vr][part] planes per wave = 544 units
+constexpr int TH = 16, TW = 32, NTHR = 512, COT = 64;
+[[maybe_unused]] constexpr int IC = TW + 2;         // pixels of a staged row: the 32 of the tile + one halo column on each side
+#ifndef WY_ICP
+#define WY_ICP 36                                  // LDS pitch (16-B units) of one channel-octet row of a plane: 34 pixels + 2 pad.  With the natural 34 the
+#endif                                             // staging stores of the two octets of a pixel quad-set fall 136 dwords apart = 8 banks: a 2-way conflict in every pass
+constexpr int ICP = WY_ICP;
+constexpr int V_PLANE = 2 * ICP;                   // 16-B units of one (half, row, part) plane: [q 2][px ICP]
+constexpr int V_WAVE = 2 * 2 * 2 * V_PLANE;        // [hf][vr][part] planes per wave = 576 units
 constexpr int W_HALF = 6 * 2 * 2 * 64;             // [s = vr * 3 + kx][t][part][lane] = 1536 units = 24 KiB
 constexpr int W_PHASE = 2 * W_HALF;                // 48 KiB per (cob, chunk)
 constexpr int EPS = 36;                            // floats per pixel in an epilogue slice
@@ -194,8 +199,8 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     bf16x8* vwave = smem + wave * V_WAVE;
     constexpr int PLANE_B = V_PLANE * 16;                     // bytes per plane; plane index = (hf * 2 + vr) * 2 + part
     // (byte offsets into the dynamic LDS block, not pointers: every access below is formed as smem_raw + offset, so hipcc keeps them LDS accesses)
-    const unsigned vst0 = (unsigned)(wave * V_WAVE + (q4 >> 1) * IC + (lane >> 2)) * 16u + (unsigned)(q4 & 1) * 8u;      // round r: + r * 16 px * 16 B
-    const unsigned vst_t = (unsigned)(wave * V_WAVE + (q4 >> 1) * IC + 32 + ((lane & 7) >> 2)) * 16u + (unsigned)(q4 & 1) * 8u;
+    const unsigned vst0 = (unsigned)(wave * V_WAVE + (q4 >> 1) * ICP + (lane >> 2)) * 16u + (unsigned)(q4 & 1) * 8u;      // round r: + r * 16 px * 16 B
+    const unsigned vst_t = (unsigned)(wave * V_WAVE + (q4 >> 1) * ICP + 32 + ((lane & 7) >> 2)) * 16u + (unsigned)(q4 & 1) * 8u;
     auto vptr = [&](unsigned off) { return reinterpret_cast<bf16x4*>(smem_raw + off); };
     // Transform + split + store.  Half B of a phase builds positions {0, 1} of the NEXT phase from the rows in d / dx (V0 = d0 - d2, V1 = d1 + d2) and, in
     // place, the fp32 values of positions {2, 3} (V2 = d2 - d1 -> d[r][0], V3 = d1 - d3 -> d[r][1]: the other two row registers are dead from
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     // accumulator registers and the 36 staging registers.
     struct FragA { bf16x8 ah, al; };
     struct FragB { bf16x8 bh, bl; };
-    const bf16x8* vrd = vwave + half * IC + px;               // + plane * V_PLANE + kx
+    const bf16x8* vrd = vwave + half * ICP + px;               // + plane * V_PLANE + kx
     const bf16x8* wrd = wlds + lane;
     auto load_b = [&](int hf, int s, FragB& fr) {             // s = vr * 3 + kx
         const int vr = s / 3, kx = s - 3 * vr;

@@ -1111,7 +1111,9 @@ class HipEngine:
         stage can be bracketed by HIP events).  The ~1400 launches of a frame cost ~11 us of host time
         each when issued from Python; captured once per (shape, scale) they replay in tens of us.
         throughput=True (several clips in flight on different streams): the convs are launched as
-        SAVSR_CONV_DIRECT_THROUGHPUT -- same results bit for bit, its own captured graphs."""
+        SAVSR_CONV_DIRECT_THROUGHPUT -- the direct kernel's results bit for bit, its own captured graphs.  (Round 4: a launch's conv FORM --
+        direct or Winograd-y -- depends on its tile count and on this mode (conv_launch), so a frame in throughput mode can differ from the
+        one-clip flow by the two forms' rounding, ~1e-5; each mode is bitwise reproducible.)"""
         sc = self._select(lq.shape, scale)
         if sc["graphs"] is None:
             sc["graphs"] = {}

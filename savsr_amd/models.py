@@ -132,7 +132,8 @@ class VideoBaseModel(BaseModel):
         # Frames are independent units (the hidden state restarts per window, savsr_arch.py:705-706): instead of one frame at a
         # time (video_base_model.py:51-53) this rank's frames go through the network `group` at a time, each on its own HIP
         # stream (SAVSR.forward_many) -- the launch-latency-bound parts of one frame run under another's convolutions
-        # (+12 % frames/s at 180x320 x4).  Per-frame results are bitwise those of the one-at-a-time flow (`test()`).
+        # (+12 % frames/s at 180x320 x4).  Per-frame results are those of the one-at-a-time flow (`test()`) -- bit for bit where every conv
+        # launch takes the same form in both modes (small frames), within the rounding of the direct vs Winograd-y conv forms (~1e-5) otherwise.
         net = self.net_g.module if hasattr(self.net_g, "module") else self.net_g
         group = max(1, int(getattr(net.engine(), "n_streams", 1))) if hasattr(net, "forward_many") else 1
         folders_all = dataset.data_info["folder"]
