@@ -17,3 +17,16 @@ def test_random_sizes_and_scales_vs_oracle():
     tail = "\n".join(r.stdout.strip().splitlines()[-5:])
     assert r.returncode == 0, tail + r.stderr[-2000:]
     assert "32 cases, worst max-abs" in tail
+
+
+def test_random_sizes_and_scales_vs_oracle_winograd_everywhere():
+    """The same sweep (another seed) with EVERY eligible conv launch forced into the Winograd F(2,3)-along-y form (SAVSR_WY_MIN_TILES=1: at
+    these small sizes the engine would otherwise pick the direct kernel for all of them): the static 3x3 convs and the OSConv dynamic convs
+    through conv_wy.hip / osconv_aggregate_wy_kernel on ragged shapes -- tiles with rows below the image, partial columns, one-chunk and
+    20-chunk convs."""
+    env = dict(os.environ, SAVSR_WY_MIN_TILES="1", SAVSR_WY_MIN_TILES_TP="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_network.py"), "--cases", "20", "--seed", "11", "--max-side", "48"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    tail = "\n".join(r.stdout.strip().splitlines()[-5:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    assert "20 cases, worst max-abs" in tail
