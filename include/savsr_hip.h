@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 24
+#define SAVSR_ABI_VERSION 25
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -177,6 +177,9 @@ typedef struct savsr_osconv_attn_desc {
     int32_t wy;                              /* != 0: wimg_out receives the Winograd-y image (savsr_conv_wy_pack_index order, 4/3 of the direct size;
                                                 cout % 64 == 0) for a conv launched with algo SAVSR_CONV_WINOGRAD_Y: the spatial gate sa[ky, kx] is
                                                 applied per tap, then the F(2,3) weight transform over ky */
+    int32_t fused;                           /* != 0: ONE launch -- every aggregation workgroup runs the scale routing (pooled mean, layers 1 and 2) itself
+                                                instead of two launches in front of it; v2 comes out bit-identical (v1 is not written).  Measured SLOWER
+                                                than the three launches on MI355X; the engine leaves it off */
 } savsr_osconv_attn_desc;
 int savsr_osconv_weights(const savsr_osconv_attn_desc* d, void* stream);
 /* n (1..6) independent OSConvs of identical cin / cout / hidden / knum in one set of launches (the two

@@ -18,7 +18,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 24
+ABI_VERSION = 25
 CONV_DIRECT, CONV_DIRECT_THROUGHPUT, CONV_WINOGRAD_Y = 0, 2, 3
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
@@ -56,7 +56,7 @@ class OSConvAttnDesc(C.Structure):
         ("sp_w", fptr), ("sp_b", fptr), ("kn_w", fptr), ("kn_b", fptr),
         ("v1", fptr), ("v2", fptr),
         ("bank", fptr), ("nunits", C.c_int64), ("wimg_out", fptr),
-        ("att", fptr), ("wy", C.c_int32),
+        ("att", fptr), ("wy", C.c_int32), ("fused", C.c_int32),
     ]
 
 

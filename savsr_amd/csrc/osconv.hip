@@ -150,6 +150,86 @@ __global__ __launch_bounds__(512) void osconv_l2_kernel(const OscBatch bt) {
     if (lane == 0) d.v2[r] = fmaxf(acc + d.l2_b[r], 0.f);
 }
 
+// Scale routing inside ONE workgroup (savsr_osconv_attn_desc.fused): pooled mean -> layer 1 (all 2 cin rows) -> layer 2 (all cin rows) -> v2 in LDS, with
+// exactly the summation orders of osconv_l1_kernel / osconv_l2_kernel (bit-identical v2).  Every aggregation workgroup repeats it (~0.8 MB of
+// L2-resident reads per workgroup at cin = 192) instead of waiting for two more launches: the chain was three latency-bound launches of a few dozen
+// workgroups each (12.6 + 5.1 + 15 us per OSConv set, 21 sets per frame); no inter-workgroup hand-off, so nothing to synchronise.
+// scr: [4 + cin | OSC_PARTS x cin | 2 cin] floats of LDS scratch (v0 with its two scale entries at +2, the partial-sum slices, v1).
+__device__ __forceinline__ void osconv_route_in_workgroup(const savsr_osconv_attn_desc& d, float* scr, float* v2) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* v0 = scr + 2;
+    float* part = scr + 4 + d.cin;
+    float* v1 = part + OSC_PARTS * d.cin;
+    if (tid == 0) { v0[0] = d.inv_sh; v0[1] = d.inv_sw; }
+    const int c4n = d.cin / 4;
+    const f32x4* part4 = reinterpret_cast<const f32x4*>(d.partial);
+    for (int i = tid; i < c4n * OSC_PARTS; i += 512) {
+        const int c4 = i % c4n, pt = i / c4n;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int b = pt; b < d.nblk; b += OSC_PARTS) {
+            const f32x4 v = part4[(long long)b * c4n + c4];
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+        *reinterpret_cast<f32x4*>(part + pt * d.cin + 4 * c4) = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < d.cin; c += 512) {
+        float s = 0.f;
+#pragma unroll
+        for (int pt = 0; pt < OSC_PARTS; ++pt) s += part[pt * d.cin + c];
+        v0[2 + c] = s * d.inv_n;
+    }
+    __syncthreads();
+    constexpr int MAXJ = 6;                               // cin + 2 <= 322 columns (checked by the launcher)
+    for (int r0 = wave; r0 < 2 * d.cin; r0 += 32) {       // four rows per wave and pass: their loads go out together
+        float wv[4][MAXJ];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < MAXJ; ++q) {
+                const int r = r0 + 8 * j, c = lane + 64 * q;
+                wv[j][q] = (r < 2 * d.cin && c < d.cin + 2) ? d.l1_w[(long long)r * (d.cin + 2) + c] : 0.f;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + 8 * j;
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < MAXJ; ++q) {
+                const int c = lane + 64 * q;
+                if (c < d.cin + 2) acc += wv[j][q] * v0[c];
+            }
+            acc = wave_sum(acc);
+            if (lane == 0 && r < 2 * d.cin) v1[r] = fmaxf(acc + d.l1_b[r], 0.f);
+        }
+    }
+    __syncthreads();
+    for (int r0 = wave; r0 < d.cin; r0 += 16) {           // two rows per wave and pass (2 cin <= 640 = 10 x 64 columns)
+        float wv[2][10];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                const int r = r0 + 8 * j, c = lane + 64 * q;
+                wv[j][q] = (r < d.cin && c < 2 * d.cin) ? d.l2_w[(long long)r * (2 * d.cin) + c] : 0.f;
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = r0 + 8 * j;
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                const int c = lane + 64 * q;
+                if (c < 2 * d.cin) acc += wv[j][q] * v1[c];
+            }
+            acc = wave_sum(acc);
+            if (lane == 0 && r < d.cin) v2[r] = fmaxf(acc + d.l2_b[r], 0.f);
+        }
+    }
+    __syncthreads();
+}
+
 // ScaleAttention heads (savsr_arch.py:91-96, 69-89) recomputed per workgroup (a few k MACs),
 // then  W''[co][ci][tap] = fa[co] ca[ci] sa[tap] sum_k ka[k] W[k][co][ci][tap]  (:156-163,171
 // folded, :148-149) for this workgroup's slice, split to (hi, lo) bf16 and written in the conv
@@ -205,8 +285,13 @@ __global__ __launch_bounds__(512) void osconv_aggregate_kernel(const OscBatch bt
 #pragma unroll
         for (int k = 0; k < GH; ++k) gw[k] = (wr && k < d.hidden) ? wr[k] : 0.f;
     }
-    for (int i = tid; i < d.cin; i += 512) v2[i] = d.v2[i];
-    __syncthreads();
+    if (d.fused) {
+        osconv_route_in_workgroup(d, gates + (d.cin + d.cout + 9 + d.knum), v2);     // (LDS scratch behind the gates; ends with a barrier)
+        if (blockIdx.x == 0 && d.v2) for (int i = tid; i < d.cin; i += 512) d.v2[i] = v2[i];      // (kept observable for tests / tools)
+    } else {
+        for (int i = tid; i < d.cin; i += 512) v2[i] = d.v2[i];
+        __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < FC_ROWS; ++j) {
         const int r = wave + 8 * j;
@@ -357,8 +442,13 @@ __global__ __launch_bounds__(512) void osconv_aggregate_wy_kernel(const OscBatch
 #pragma unroll
         for (int k = 0; k < GH; ++k) gw[k] = (wr && k < d.hidden) ? wr[k] : 0.f;
     }
-    for (int i = tid; i < d.cin; i += 512) v2[i] = d.v2[i];
-    __syncthreads();
+    if (d.fused) {
+        osconv_route_in_workgroup(d, gates + (d.cin + d.cout + 9 + d.knum), v2);     // (LDS scratch behind the gates; ends with a barrier)
+        if (blockIdx.x == 0 && d.v2) for (int i = tid; i < d.cin; i += 512) d.v2[i] = v2[i];      // (kept observable for tests / tools)
+    } else {
+        for (int i = tid; i < d.cin; i += 512) v2[i] = d.v2[i];
+        __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < FC_ROWS; ++j) {
         const int r = wave + 8 * j;
@@ -617,20 +707,25 @@ extern "C" int savsr_osconv_weights_batch(const savsr_osconv_attn_desc* descs, i
         const int rc = check_osconv_desc(descs + i);
         if (rc) return rc;
         if (descs[i].cin != descs[0].cin || descs[i].cout != descs[0].cout || descs[i].hidden != descs[0].hidden ||
-            descs[i].knum != descs[0].knum || descs[i].nunits != descs[0].nunits || (descs[i].wy != 0) != (descs[0].wy != 0))
-            return fail_arg("osconv_weights: all OSConvs of a batch must share cin / cout / hidden / knum / wy");
+            descs[i].knum != descs[0].knum || descs[i].nunits != descs[0].nunits || (descs[i].wy != 0) != (descs[0].wy != 0) ||
+            (descs[i].fused != 0) != (descs[0].fused != 0))
+            return fail_arg("osconv_weights: all OSConvs of a batch must share cin / cout / hidden / knum / wy / fused");
         bt.d[i] = descs[i];
     }
     for (int i = n; i < OSC_MAX_BATCH; ++i) bt.d[i] = descs[0];
     const savsr_osconv_attn_desc* d = descs;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(osconv_l1_kernel, dim3((2 * d->cin + OSC_L1_ROWS - 1) / OSC_L1_ROWS, n), dim3(512), sizeof(float) * ((OSC_PARTS + 1) * d->cin + 4), st, bt);
-    int rc = check_launch("osconv_l1_kernel");
-    if (rc) return rc;
-    hipLaunchKernelGGL(osconv_l2_kernel, dim3((d->cin + 7) / 8, n), dim3(512), sizeof(float) * 2 * d->cin, st, bt);
-    rc = check_launch("osconv_l2_kernel");
-    if (rc) return rc;
-    const size_t lds = sizeof(float) * ((size_t)d->cin + d->hidden + d->cin + d->cout + 9 + d->knum);
+    int rc = 0;
+    if (!d->fused) {
+        hipLaunchKernelGGL(osconv_l1_kernel, dim3((2 * d->cin + OSC_L1_ROWS - 1) / OSC_L1_ROWS, n), dim3(512), sizeof(float) * ((OSC_PARTS + 1) * d->cin + 4), st, bt);
+        rc = check_launch("osconv_l1_kernel");
+        if (rc) return rc;
+        hipLaunchKernelGGL(osconv_l2_kernel, dim3((d->cin + 7) / 8, n), dim3(512), sizeof(float) * 2 * d->cin, st, bt);
+        rc = check_launch("osconv_l2_kernel");
+        if (rc) return rc;
+    }
+    // (fused: + the routing scratch [4 + cin | OSC_PARTS x cin | 2 cin] behind the gates: 46 KB at cin = 320)
+    const size_t lds = sizeof(float) * ((size_t)d->cin + d->hidden + d->cin + d->cout + 9 + d->knum + (d->fused ? 4 + (size_t)(OSC_PARTS + 3) * d->cin : 0));
     if (d->wy) {
         if (d->cout % 64 || d->cin % 16) return fail_arg("osconv_weights: the Winograd-y image needs cout % 64 == 0 and cin % 16 == 0");
         const long long nitems = (long long)(d->cout / 64) * (d->cin / 16) * 3 * 2 * 64 * 2;

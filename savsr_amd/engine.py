@@ -194,6 +194,10 @@ class HipEngine:
         self.satu_q = os.environ.get("SAVSR_SATU_Q", "1") != "0"
         # static-weight 3x3 convs in the Winograd F(2,3)-along-y form (SAVSR_CONV_WINOGRAD_Y); SAVSR_CONV_WY=0: the direct kernel everywhere
         self.conv_wy = os.environ.get("SAVSR_CONV_WY", "1") != "0"
+        # OSConv weight generation as ONE launch (savsr_osconv_attn_desc.fused: the routing recomputed in every aggregation workgroup; bit-identical).
+        # OFF: measured slower -- one clip 8.96 -> 9.77 ms, three in flight 120.3 -> 118.0 HR Mpixel/s (A/B/A on one lease): a workgroup pulling
+        # the 0.8 MB of routing weights + pool partials through ONE CU takes ~40 us longer than the two extra launches it saves
+        self.osconv_fused = os.environ.get("SAVSR_OSCONV_FUSED", "0") != "0"
         self.reuse_buffers = os.environ.get("SAVSR_REUSE_BUFFERS", "1") != "0"      # liveness-planned LR buffers (release()); 0: every name its own memory
         self.wy_min_tiles = int(os.environ.get("SAVSR_WY_MIN_TILES", "200"))          # launches with at least this many 16-row tiles take the Winograd form ...
         self.wy_min_tiles_tp = int(os.environ.get("SAVSR_WY_MIN_TILES_TP", "100"))    # ... or this many with several clips in flight (throughput tiling)
@@ -439,7 +443,7 @@ class HipEngine:
         e.lib, e.dev, e.cfg, e.nf = self.lib, self.dev, self.cfg, self.nf
         e.pw, e.se, e._keep = self.pw, self.se, self._keep
         e.pw_wy, e.conv_wy, e.wy_min_tiles, e.wy_min_tiles_tp = self.pw_wy, self.conv_wy, self.wy_min_tiles, self.wy_min_tiles_tp
-        e.reuse_buffers = self.reuse_buffers
+        e.reuse_buffers, e.osconv_fused = self.reuse_buffers, self.osconv_fused
         e.satu_t, e.satu_w, e.tail_w, e.tail_b, e.gamma, e.n_l2 = self.satu_t, self.satu_w, self.tail_w, self.tail_b, self.gamma, self.n_l2
         e.iter_win, e.fwd_idx, e.bwd_idx = self.iter_win, self.fwd_idx, self.bwd_idx
         e.satu_tail_t, e.satu_w_tail = self.satu_tail_t, self.satu_w_tail
@@ -662,6 +666,7 @@ class HipEngine:
                   "sp_w", "sp_b", "kn_w", "kn_b", "v1", "v2", "bank", "att"):
             setattr(d, k, e[k].data_ptr())
         d.wy = 1 if wy else 0
+        d.fused = 1 if self.osconv_fused else 0
         d.wimg_out = (e["wdyn_wy"] if wy else e["wdyn"]).data_ptr()
         return d
 

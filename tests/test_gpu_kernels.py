@@ -294,6 +294,33 @@ def test_osconv_winograd_image(eng, synth_sd, pfx, cin):
     assert e < 3e-5
 
 
+@pytest.mark.parametrize("pfx,cin", [("f2p_win.blocks.1.osconv", 192), ("h_win.0.blocks.0.osconv", 320), ("adapt.0.adapt", 64)])
+def test_osconv_weights_one_launch_bitwise(eng, pfx, cin):
+    """savsr_osconv_attn_desc.fused: the scale routing recomputed inside every aggregation workgroup (one launch) gives bit for bit the weight
+    image, v2 and attention vector of the three-launch chain, in both image orders."""
+    h, w, sc = 22, 36, (1.7, 3.75)
+    x = rnd((1, cin, h, w), 91 + cin, 0.7)
+    xall = cl(x[0])
+    srcs = [eng.full(xall, 64, i * 64) for i in range(cin // 64)]
+    ent = eng.osc[pfx]
+    keep = eng.osconv_fused
+    try:
+        for wy in (False, True):
+            got = {}
+            for fused in (False, True):
+                eng.osconv_fused = fused
+                for k in ("v2", "att", "wdyn", "wdyn_wy"):
+                    ent[k].fill_(0)
+                eng.osconv_weights(pfx, srcs, h, w, sc, wy=wy)
+                torch.cuda.synchronize()
+                got[fused] = {k: ent[k].clone() for k in ("v2", "att", "wdyn_wy" if wy else "wdyn")}
+            for k in got[True]:
+                assert torch.equal(got[True][k], got[False][k]), (pfx, wy, k)
+            assert float(got[True]["v2"].abs().max()) > 0
+    finally:
+        eng.osconv_fused = keep
+
+
 def test_conv_fused_pool(eng):
     """Fused AdaptiveAvgPool2d(1) partials of the conv epilogue == mean of the stored tensor."""
     from savsr_amd import engine as E
