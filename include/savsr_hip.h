@@ -54,7 +54,7 @@ int savsr_prepare_device(void);
 /* First 16 hex digits of the sha256 over the kernel sources, headers and compile flags this library was built from (build.sh):
  * lets a measurement file name the build it was taken on (profiles/satu_traffic.json; bench.py drops `traffic` when it differs). */
 const char* savsr_source_hash(void);
-const char* savsr_source_hash_satu(void);     /* the same over the SATU + tail kernel sources only (satu.hip, tail.hip, common.hpp, this header) */
+const char* savsr_source_hash_satu(void);     /* the same over the SATU + tail kernel sources only (satu.hip, tail.hip, common.hpp) */
 /* Measurement aid (bench.py `clock_mhz`): ONE wave spins through `windows` (1 .. 64) consecutive windows of `window_ticks` ticks of the
  * 100 MHz s_memrealtime counter each and writes out[2 i] = s_memtime delta (shader cycles), out[2 i + 1] = s_memrealtime delta of window i:
  * shader clock = out[2 i] / out[2 i + 1] x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  Launched on a side stream beside other

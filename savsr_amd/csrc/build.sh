@@ -25,7 +25,7 @@ mkdir -p "$OBJDIR"
 # savsr_source_hash(): sha256 over the kernel sources + headers + flags this library is built from (first 16 hex digits), compiled into
 # api.cpp, so that a measurement file (profiles/satu_traffic.json) can name the build it was taken on and bench.py can tell a stale one
 SRC_HASH=$( (cat conv_mfma.hip conv_wy.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip api.cpp common.hpp conv_common.hpp ../../include/savsr_hip.h; printf '%s' "$BASE_FLAGS ${EXTRA_FLAGS:-} ${EXTRA_ONLY:-}") | sha256sum | cut -c1-16)
-SATU_HASH=$( (cat satu.hip tail.hip common.hpp ../../include/savsr_hip.h; printf '%s' "$BASE_FLAGS ${EXTRA_FLAGS:-} ${EXTRA_ONLY:-}") | sha256sum | cut -c1-16)   # the SATU + tail kernels alone
+SATU_HASH=$( (cat satu.hip tail.hip common.hpp; printf '%s' "$BASE_FLAGS -fno-slp-vectorize") | sha256sum | cut -c1-16)   # the SATU + tail kernels alone (not the header: it changes with every other kernel's interface)
 
 # per-file flags: satu.hip and conv_wy.hip keep their scalar fp32 arithmetic scalar -- packed fp32 instructions (v_pk_mul / v_pk_fma) are an
 # anti-lever beside MFMAs on gfx950 (MI355X_MICROARCH.md); the explicit 2-vector code of the HR stage is unaffected
