@@ -69,8 +69,13 @@ __device__ __attribute__((aligned(16))) const float g_wy_zero16[4] = {0.f, 0.f, 
 // instrumented experiment build: per (workgroup, wave) accumulated s_memtime of 8 sections (savsr_debug_read_wy_stamps):
 // 0 half A steps 0-4 | 1 half A wait + barrier | 2 half A step 5 rest | 3 half B steps 0-4 | 4 half B wait + barrier | 5 half B step 5 rest | 6 transform + epilogue | 7 total
 __device__ long long g_wy_stamps[256 * 8 * 8];
+#define WY_KSEC(i) ((WY_EXP & 8192) ? 0 : (i))
 #define WY_MARK(i) do { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); wy_sec[i] += t_now - wy_prev; wy_prev = t_now; } while (0)
+#if WY_EXP & 8192             // the epilogue in pieces instead of the K-loop halves: sections 0 = K loop, 1 = epilogue loads issued + output transform, 2..5 = the four groups
+#define WY_EMARK(i) WY_MARK(i)
+#endif
 #else
+#define WY_KSEC(i) (i)
 #define WY_MARK(i) do { } while (0)
 #endif
 
@@ -391,20 +396,20 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        WY_MARK(hf * 3 + 0);
+                        WY_MARK(WY_KSEC(hf * 3 + 0));
                         // the weight half DMA'd during this half (for the NEXT half to run) has landed; publish it.  Half A: the 8 row loads of the
                         // next phase (steps 1-5) are younger and may fly on; half B: the DMAs are the youngest operations.
                         if (hf == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __syncthreads();
-                        WY_MARK(hf * 3 + 1);
+                        WY_MARK(WY_KSEC(hf * 3 + 1));
                         if (!(WY_EXP & 1)) { load_b(hf ^ 1, 0, fb[0]); load_a(hf ^ 1, 0, 0, fa[0]); }
                         __builtin_amdgcn_sched_barrier(0);
                         mma3(pz, 1, 1);
                         if (hf == 0) issue_dx();
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    WY_MARK(hf * 3 + 2);
+                    WY_MARK(WY_KSEC(hf * 3 + 2));
                 }
             };
             if (rows_in) phase(std::true_type{}); else phase(std::false_type{});
@@ -462,6 +467,10 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
                 acc[3][t][i] = (m1 - m2) - acc[3][t][i];
             }
         f32x4 psum[2][2];
+#ifdef WY_EMARK
+        asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][1][15]));
+        WY_EMARK(1);
+#endif
 #pragma unroll
         for (int r = 0; r < ((WY_EXP & 16) ? 0 : 2); ++r) {
             const int y = y0 + 2 * wave_s + r;
@@ -538,6 +547,9 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
                     }
                 }
                 psum[r][t] = ps;
+#ifdef WY_EMARK
+                WY_EMARK(2 + gi);
+#endif
                 if (gi + RR < 4) load_r1((gi + RR) / 2, (gi + RR) % 2, rr[gi % RR]);       // the ring slot is free: next residual group out
             }
         }

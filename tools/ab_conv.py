@@ -125,6 +125,8 @@ def main():
                 stt = np.array(buf[:], dtype=np.int64).reshape(256, 8, 8)
                 med = np.median(stt, axis=0)                   # [wave][section]
                 names = ["A s0-4", "A wait+bar", "A s5", "B s0-4", "B wait+bar", "B s5", "epilogue", "total"]
+                if "8192" in os.environ.get("AB_STAMP_MODE", ""):
+                    names = ["K loop", "epi loads + transform", "group 0", "group 1", "group 2", "group 3", "pool / rest", "total"]
                 print(f"    [{name}] median cycles per wave over the launch (sections: " + ", ".join(names) + ")")
                 for wv in (0, 3, 4, 7):
                     print(f"      wave {wv}: " + "  ".join(f"{int(v):7d}" for v in med[wv]))
