@@ -39,33 +39,13 @@
 
 #include <type_traits>
 
-#ifndef CONV_INTERLEAVE
-#define CONV_INTERLEAVE 1
-#endif
-#ifndef CONV_IL_VALU
-#define CONV_IL_VALU 3
-#endif
-// Timing experiments on the PRODUCT kernel (results invalid; never set in a shipped build): 1 = no staging in the steps,
-// 2 = no fragment reads in the steps, 4 = no epilogue body, 16 = epilogue without its global stores, 32 = without its
-// residual loads, 64 = without the LDS transpose (values straight from the accumulators); 8 = every workgroup records its entry / exit s_memtime in
-// stamp slots 0 / 4 (clock-independent totals: the experiments change the power draw and with it the shader clock).  The run-time switches of the instrumented build cost it
-// its straight-line steps and read s_memtime (an lgkmcnt(0) wait) in every section, so small effects drown there.
-#ifndef CONV_EXP
-#define CONV_EXP 0
-#endif
-#ifndef EPI_PREFETCH
-#define EPI_PREFETCH 1            // the epilogue's first global loads (bias quads, first residual group) are issued in front of the tile's LAST phase
-#endif
-#ifndef CONV_PRIO
-#define CONV_PRIO 1               // issue priority of the two waves of a SIMD: 0 = alternating per step (rounds 1-3: a scalar branch around s_setprio in
-                                  // every step, which also cut every step into its own basic block), 1 = static (waves 4-7 at priority 1 for the whole
-                                  // kernel, no branch in the steps: the 9 steps of a phase are three basic blocks), 2 = none.  A/B/A/B in one process
-                                  // (tools/ab_conv.py, round 4): 6 x 128->64 150.6 -> 147.6 (1) / 148.4 (2) us, 6 x 64->64 88.6 -> 87.8 / 87.5, 64->64 18.2 -> 17.7 / 17.5
-#endif
-#ifndef ROWS_SKIP
-#define ROWS_SKIP 1               // 0: one phase body, MFMAs on zeros below the image; 1: a wave with NO row inside the image runs a body without MFMAs;
-                                  // 2: also a one-row body for waves with one row of two inside (three bodies: 69 spilled VGPRs in the 16-row kernel)
-#endif
+// Settled build-time choices (their A/B numbers are in DESIGN.md sections 4 / 10; the switches themselves -- CONV_INTERLEAVE, CONV_IL_VALU,
+// EPI_PREFETCH, CONV_PRIO, ROWS_SKIP and the CONV_EXP timing knobs -- are archived as tools/experiments/conv_mfma_switches.patch):
+//  * straight-line steps with a sched_group_barrier pipeline: up to 3 vector instructions and one DS write behind every MFMA;
+//  * the epilogue's first global loads (bias quads, first residual group) are issued in front of the tile's LAST phase (3x3 kernels);
+//  * static issue priority: waves 4-7 at priority 1 for the whole kernel (rounds 1-3 alternated per step: a scalar branch around s_setprio in every
+//    step, which cut each step into its own basic block; A/B in one process, round 4: 6 x 128->64 150.6 -> 147.6 us, 6 x 64->64 88.6 -> 87.8);
+//  * a wave with NO row inside the image runs a phase body without MFMAs (a third, one-row body spilled 69 VGPRs in the 16-row kernel).
 
 namespace savsr {
 
@@ -74,7 +54,7 @@ namespace savsr {
 // [blk][6] = entry, after the first staging, after the first K phase, after the first tile's K loop,
 // kernel end (stores drained), s_memrealtime at entry.
 [[maybe_unused]] constexpr int STAMP_BLOCKS = 1024, STAMP_N = 6;
-#if defined(SAVSR_DIAG) || (CONV_EXP & 8)
+#if defined(SAVSR_DIAG)
 #define CONV_HAS_STAMPS 1
 __device__ long long g_conv_stamps[STAMP_BLOCKS * STAMP_N];
 __device__ int g_conv_stamps_on = 0;
@@ -247,14 +227,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     long long t_prev = (stamps_on >= 3) ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define CV_MARK(i) do { if (stamps_on >= 3) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); sec[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
-#if CONV_PRIO == 1
     if (prio_group) __builtin_amdgcn_s_setprio(1);
-#endif
     stamp(stamps_on, 0);
-#if CONV_EXP & 8
-    if (!DIAG && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && blockIdx.x < STAMP_BLOCKS)   // (scalar branch: all of wave 0 stores)
-        g_conv_stamps[blockIdx.x * STAMP_N + 0] = (long long)__builtin_amdgcn_s_memtime();
-#endif
     stamp(stamps_on, 5);
 
     // ---- software pipeline over the block's phases (tiles x chunks, walked linearly by the staging cursor) ----
@@ -355,16 +329,16 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 
         // Pixel rows of this wave that lie inside the image (wave-uniform, fixed per tile): in the image's last band (180 rows =
         // 11 x 16 + 4) a wave owns one row or none, and MFMAs on all-zero operands cost the same time and energy as useful ones
-        // -- 6 % of the MFMA work of a 16-row-tile launch at 180 rows.  The phase body is instantiated per row count (ROWS_SKIP):
+        // -- 6 % of the MFMA work of a 16-row-tile launch at 180 rows.  The phase body is instantiated with and without matrix work:
         // every variant stages, reads its fragments (the ring feeds the NEXT tile too) and meets the barriers alike; only the MFMA
         // groups of absent rows are left out.
         const int rows_valid = __builtin_amdgcn_readfirstlane((y0 + wave < H ? 1 : 0) + (PXT > 1 && y0 + wave + CONV_TH < H ? 1 : 0));
-        // EPI_PREFETCH: the loads the epilogue would start with -- the bias quads of both channel groups and the residual quads of
+        // Epilogue prefetch: the loads the epilogue would start with -- the bias quads of both channel groups and the residual quads of
         // its first (row, channel-group) step -- go out in front of the tile's LAST phase, so their global latency (one exposed
         // HBM round trip per tile and wave, ~1.5 k of a single-tile launch's ~30 k cycles) runs under that phase's MFMAs.  They are
         // older than everything the phase's barrier waits for, so its counted vmcnt is unchanged.  Always issued, always used
         // (absent operands read zeros): hipcc's wait insertion keeps count only of unconditional loads.
-        constexpr bool EPI_PF = EPI_PREFETCH && !DIAG && KS == 3;       // (the 1x1 kernels have no registers to spare: 25 spills)
+        constexpr bool EPI_PF = !DIAG && KS == 3;       // (the 1x1 kernels have no registers to spare: 25 spills)
         [[maybe_unused]] f32x4 pf_bias[NT], pf_r[4];
         auto epi_prefetch = [&]() {
             const float* pb = p.bias;
@@ -379,7 +353,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
             for (int t = 0; t < NT; ++t) pf_bias[t] = ldg4(b_base, b_off + (unsigned)t * b_step);
             const int y = y0 + __builtin_amdgcn_readfirstlane(wave);
-            const bool row_ok = pr && full && !(CONV_EXP & 32) && y < H, x_in = x0 + CONV_TW <= W;
+            const bool row_ok = pr && full && y < H, x_in = x0 + CONV_TW <= W;
             const float* r1_base = row_ok ? pr : zero16;
             const unsigned off0 = 4u * (unsigned)((y * W + x0 + (lane >> 3)) * prpix + cob * COT + 4 * c4), ustride = 32u * (unsigned)prpix;
 #pragma unroll
@@ -422,48 +396,31 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                     CV_MARK(3);
                     if (!FINE) pend2 = pend && stage_next();
                 }
-                if (dbg_nofrag || (CONV_EXP & 2)) {
+                if (dbg_nofrag) {
                 } else if (s + LEAD < STEPS) load_frag(buf, s + LEAD, f[(s + LEAD) % RING]);
                 else if (pend) load_frag(buf ^ 1, s + LEAD - STEPS, f[(s + LEAD) % RING]);
-#if CONV_INTERLEAVE < 2
                 __builtin_amdgcn_sched_barrier(0);
-#else
-                if (!(FINE && !DIAG)) __builtin_amdgcn_sched_barrier(0);
-#endif
-                // The two waves of a SIMD alternate issue priority step by step.  Left to the oldest-first arbiter, waves
-                // 0-3 run every step ahead, then idle ~2 k cycles per phase at the barrier while waves 4-7 finish alone
-                // (a lone wave cannot cover its own staging work with MFMAs): stamps, 80 k vs 99 k cycles of steps.
-#if CONV_PRIO == 0
-                if (((s ^ prio_group) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
-#if CONV_INTERLEAVE
                 // Straight-line step (FINE, product build): the staging pieces are issued unconditionally -- without a next
                 // phase they re-stage the cursor's last phase into a buffer nobody reads -- so that the step is ONE basic
                 // block and the scheduler can be told to put a few vector instructions behind every MFMA instead of
                 // clumps between the MFMA groups (both waves of a SIMD clump at the same time and the matrix pipe drains).
                 if (FINE && !DIAG) {
                     mma_part(f[s % RING], 0);
-                    if (!(CONV_EXP & 1) && s >= SD && s < SD + B_IT) stage_store_item(s - SD, buf ^ 1);
+                    if (s >= SD && s < SD + B_IT) stage_store_item(s - SD, buf ^ 1);
                     mma_part(f[s % RING], 1);
-                    if (!(CONV_EXP & 1)) {
-                        if (s < SB) { if (LEAD + s < W_IT) issue_w(LEAD + s, buf ^ 1); }
-                        else if (s - SB < W_IT) issue_w(s - SB, buf);
-                        if (s >= LB0 && s - LB0 < B_IT) issue_b(s - LB0);
-                    }
+                    if (s < SB) { if (LEAD + s < W_IT) issue_w(LEAD + s, buf ^ 1); }
+                    else if (s - SB < W_IT) issue_w(s - SB, buf);
+                    if (s >= LB0 && s - LB0 < B_IT) issue_b(s - LB0);
                     mma_part(f[s % RING], 2);
 #pragma unroll
                     for (int i = 0; i < 3 * R * NT; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-#if CONV_INTERLEAVE >= 2
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // up to one DS read (next step's fragments)
-#endif
-                        __builtin_amdgcn_sched_group_barrier(0x002, CONV_IL_VALU, 0);      // up to CONV_IL_VALU (3) VALU
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // up to 3 vector instructions
                         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // up to one DS write
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     continue;
                 }
-#endif
                 mma_part(f[s % RING], 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (FINE && s >= SD && s < SD + B_IT && pend && !dbg_nostage) stage_store_item(s - SD, buf ^ 1);
@@ -486,8 +443,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 __builtin_amdgcn_sched_barrier(0);
             }
           };
-          if (ROWS_SKIP == 0 || rows_valid == PXT || (ROWS_SKIP == 1 && rows_valid > 0)) phase(std::integral_constant<int, PXT>{});
-          else if (PXT > 1 && rows_valid == 1) phase(std::integral_constant<int, 1>{});
+          if (rows_valid > 0) phase(std::integral_constant<int, PXT>{});
           else phase(std::integral_constant<int, 0>{});
             if (STEPS % RING != 0) {                          // keep the ring aligned: the next phase starts at slots 0 ..
                 const Frag n0 = f[STEPS % RING], n1 = f[(STEPS + 1) % RING];
@@ -534,7 +490,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         // (the epilogue's ~10 scalar branches per unit were a third of its time).
         const bool chan_full = (cob + 1) * COT <= COUT;       // the 16-row variant is only launched with cout % 64 == 0
         const bool x_inside = x0 + CONV_TW <= W;
-        if ((DIAG && (dbg_all & 256)) || (CONV_EXP & 4)) {
+        if (DIAG && (dbg_all & 256)) {
             // timing experiment: no epilogue body at all (results invalid)
 #pragma unroll
             for (int r = 0; r < PXT; ++r)
@@ -561,14 +517,14 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                 if (EPI_PF) bias4[t] = pf_bias[t];
                 else bias4[t] = (DIAG && (dbg_all & 512)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ldg4(b_base, b_off + (unsigned)t * b_step);   // (512: timing experiment without the bias load)
             }
-            const float* r1_base = (e_r1 && !(CONV_EXP & 32)) ? e_r1 : zero16;
+            const float* r1_base = e_r1 ? e_r1 : zero16;
             f32x4 rr[2][4];
             auto load_r1 = [&](int r, int t, f32x4 (&dst)[4]) {
                 const int y = y0 + wave_s + CONV_TH * r;
                 const int co = cob * COT + 32 * t + 4 * c4;
                 // one integer multiply per group, then uniform strides (v_mul_lo_u32 is a quarter-rate instruction)
                 const unsigned off0 = 4u * (unsigned)((y * W + x0 + (lane >> 3)) * e_r1pix + co), ustride = 32u * (unsigned)e_r1pix;
-                const bool row_ok = e_r1 && !(CONV_EXP & 32) && y < H;          // scalar
+                const bool row_ok = e_r1 && y < H;          // scalar
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const bool ok = row_ok && (x_inside || x0 + (lane >> 3) + 8 * i < W);
@@ -596,7 +552,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 v = {acc[r][t][4 * g], acc[r][t][4 * g + 1], acc[r][t][4 * g + 2], acc[r][t][4 * g + 3]};
-                        if (!(DIAG && dbg_nolds) && !(CONV_EXP & 64)) *reinterpret_cast<f32x4*>(ep + px * EPS + 8 * g + 4 * half) = v;
+                        if (!(DIAG && dbg_nolds)) *reinterpret_cast<f32x4*>(ep + px * EPS + 8 * g + 4 * half) = v;
                     }
                     const int co = cob * COT + 32 * t + 4 * c4;
                     const f32x4 b4 = bias4[t];
@@ -610,7 +566,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             f32x4 a4;
-                            if ((DIAG && dbg_nolds) || (CONV_EXP & 64)) a4 = f32x4{acc[r][t][8 * ih + 4 * i], acc[r][t][8 * ih + 4 * i + 1], acc[r][t][8 * ih + 4 * i + 2], acc[r][t][8 * ih + 4 * i + 3]};
+                            if (DIAG && dbg_nolds) a4 = f32x4{acc[r][t][8 * ih + 4 * i], acc[r][t][8 * ih + 4 * i + 1], acc[r][t][8 * ih + 4 * i + 2], acc[r][t][8 * ih + 4 * i + 3]};
                             else a4 = *reinterpret_cast<const f32x4*>(ep + ((lane >> 3) + 16 * ih + 8 * i) * EPS + 4 * c4);
                             v[i] = a4 + b4;           // (whole-vector forms: two v_pk_add_f32 / v_pk_mul_f32 per quad; written per element
                         }                             //  hipcc issued 4 scalar instructions each, and the epilogue is vector-issue-bound)
@@ -651,7 +607,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             if (i == 0 ? ok0 : ok1) {
-                                if (!(DIAG && dbg_nost) && !(CONV_EXP & 16)) stg4(e_out, ooff0 + (unsigned)(2 * ih + i) * ostride, v[i]);
+                                if (!(DIAG && dbg_nost)) stg4(e_out, ooff0 + (unsigned)(2 * ih + i) * ostride, v[i]);
                                 else asm volatile("" :: "v"(v[i][0]), "v"(v[i][1]), "v"(v[i][2]), "v"(v[i][3]));
                                 if (e_pool) ps += v[i];
                             }
@@ -771,10 +727,6 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     // The last phases re-stage unconditionally (straight-line steps): no LDS-DMA of this wave may still be in flight when
     // its LDS is released.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if CONV_EXP & 8
-    if (!DIAG && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && blockIdx.x < STAMP_BLOCKS)
-        g_conv_stamps[blockIdx.x * STAMP_N + 4] = (long long)__builtin_amdgcn_s_memtime();
-#endif
     if (stamps_on == 1) {
         __builtin_amdgcn_s_waitcnt(0);              // diagnostics: include the store drain in the last stamp
         stamp(stamps_on, 4);

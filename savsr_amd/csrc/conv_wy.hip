@@ -31,14 +31,12 @@
 
 #include <type_traits>
 
-// Timing experiments (results invalid; never set in a shipped build): 1 = no fragment reads in the steps, 2 = no transform / split / V stores,
-// 4 = no weight DMA in the steps, 8 = no row loads in the steps, 16 = no epilogue body.  Compare CYCLES (tools/ab_conv.py prints them):
-// constant operands also change the power draw and with it the clock.
-#ifndef WY_EXP
-#define WY_EXP 0
-#endif
-#ifndef WY_NT_ROWS
-#define WY_NT_ROWS 0              // 1: the row loads carry the nt (streaming) hint: +17 % time -- two waves load each input row and the second one's loads are L1 hits
+// Diagnostic build switch (tools/ab_conv.sh "-DWY_STAMPS=1"; never set in the shipped library): per-wave s_memtime section stamps, read back with
+// savsr_debug_read_wy_stamps -- 1 = the K loop's halves, 2 = the epilogue's pieces.  The ablation knobs the round-4 tables of DESIGN.md section 4c
+// were measured with (no fragment reads / staging stores / row loads / residual loads / output stores / epilogue, nt row loads, static wave
+// priority) are archived as tools/experiments/conv_wy_timing_knobs.patch.
+#ifndef WY_STAMPS
+#define WY_STAMPS 0
 #endif
 #ifndef WY_VALU
 #define WY_VALU 6                 // vector instructions the scheduler may put behind every MFMA of a step
@@ -65,13 +63,13 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 __device__ __attribute__((aligned(16))) const float g_wy_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // what padding lanes load
 
-#if WY_EXP & 2048
-// instrumented experiment build: per (workgroup, wave) accumulated s_memtime of 8 sections (savsr_debug_read_wy_stamps):
+#if WY_STAMPS
+// instrumented build: per (workgroup, wave) accumulated s_memtime of 8 sections (savsr_debug_read_wy_stamps):
 // 0 half A steps 0-4 | 1 half A wait + barrier | 2 half A step 5 rest | 3 half B steps 0-4 | 4 half B wait + barrier | 5 half B step 5 rest | 6 transform + epilogue | 7 total
 __device__ long long g_wy_stamps[256 * 8 * 8];
-#define WY_KSEC(i) ((WY_EXP & 8192) ? 0 : (i))
+#define WY_KSEC(i) (WY_STAMPS == 2 ? 0 : (i))
 #define WY_MARK(i) do { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); wy_sec[i] += t_now - wy_prev; wy_prev = t_now; } while (0)
-#if WY_EXP & 8192             // the epilogue in pieces instead of the K-loop halves: sections 0 = K loop, 1 = epilogue loads issued + output transform, 2..5 = the four groups
+#if WY_STAMPS == 2             // the epilogue in pieces instead of the K-loop halves: sections 0 = K loop, 1 = epilogue loads issued + output transform, 2..5 = the four groups
 #define WY_EMARK(i) WY_MARK(i)
 #endif
 #else
@@ -80,12 +78,6 @@ __device__ long long g_wy_stamps[256 * 8 * 8];
 #endif
 
 __device__ __forceinline__ void wy_split_store(const f32x4& v, bf16x4* hi_dst, bf16x4* lo_dst) {
-#if WY_EXP & 32
-    { union { f32x4 f; bf16x4 h[2]; } u; u.f = v; *hi_dst = u.h[0]; *lo_dst = u.h[1]; return; }      // timing: raw bits, no split arithmetic
-#endif
-#if WY_EXP & 128
-    { asm volatile("" :: "v"(v)); return; }                                                          // timing: the loaded value is waited for, nothing else
-#endif
     bf16x4 hi, lo;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -93,10 +85,6 @@ __device__ __forceinline__ void wy_split_store(const f32x4& v, bf16x4* hi_dst, b
         hi[j] = hh;
         lo[j] = (__bf16)(v[j] - (float)hh);
     }
-#if WY_EXP & 64
-    asm volatile("" :: "v"(hi), "v"(lo));                                                              // timing: arithmetic kept, no LDS stores
-    return;
-#endif
     *hi_dst = hi;
     *lo_dst = lo;
 }
@@ -107,12 +95,6 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     bf16x8* smem = reinterpret_cast<bf16x8*>(smem_raw);       // [8 waves][V_WAVE] | [2][W_HALF] | epilogue slices
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-#ifndef WY_PRIO
-#define WY_PRIO 0             // 1: static issue priority for waves 4-7 as in the direct kernel (CONV_PRIO): +2 % time here (A/B in one process, 7 rounds:
-#endif                        // 6 x 128->64 138.0 -> 135.1 us without it) -- the prioritised waves finish each half early and idle at its barrier
-#if WY_PRIO
-    if (wave_s >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     const int tiles_per_cob = mp.ntx * mp.nty;
     const int total = mp.nconv * mp.ncob * tiles_per_cob;
     const int H = mp.h, W = mp.w;
@@ -184,15 +166,10 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     auto load_at = [&](int pixel, bool ok) -> f32x4 {
         const SAVSR_GLOBAL float* src = ok ? (const SAVSR_GLOBAL float*)st_base + (pixel * st_pix + st_cb + 4 * q4)
                                            : (const SAVSR_GLOBAL float*)g_wy_zero16;
-#if WY_NT_ROWS
-        return __builtin_nontemporal_load((const SAVSR_GLOBAL f32x4*)src);
-#else
-        return *(const SAVSR_GLOBAL f32x4*)src;
-#endif
+        return *(const SAVSR_GLOBAL f32x4*)src;      // (not nt: two waves load each input row and the second one's loads are L1 hits -- nt cost +17 %)
     };
     auto issue_row = [&](int r, int i) {                      // round r of the cursor's phase, row d_i of this lane's column
-        if ((WY_EXP & 256) && (i == 0 || i == 3)) { asm volatile("" : "+v"(d[r][i])); return; }     // timing knob: rows d0, d3 are not loaded (5 instead of 9 loads; vmcnt counts then over-wait)
-        const bool row_ok = st_row0 + i >= 0 && st_row0 + i < H && !(WY_EXP & 4096);                 // timing knob 4096: every row load reads the 16-B zero block (L1 hits)
+        const bool row_ok = st_row0 + i >= 0 && st_row0 + i < H;
         d[r][i] = load_at(st_pxb[r] + i * W, row_ok && st_pxb[r] != INVALID);
     };
     auto issue_d = [&](int r) {
@@ -282,7 +259,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     };
 
     int tile = blockIdx.x;
-#if WY_EXP & 2048
+#if WY_STAMPS
     long long wy_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long wy_prev = (long long)__builtin_amdgcn_s_memtime();
     const long long wy_t0 = wy_prev;
@@ -320,7 +297,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
         for (int chunk = 0; chunk < mp.nchunk; ++chunk) {
             auto phase = [&](auto mm) {
                 constexpr bool MM = decltype(mm)::value;      // false: both rows below the image -> no matrix work (everything else as usual)
-                // Staging work of (half, step).  Two rules, both from the section stamps (WY_EXP 2048):
+                // Staging work of (half, step).  Two rules, both from the section stamps (WY_STAMPS):
                 //  * at most TWO vector-memory instructions per wave and step: with the three DMAs and the nine row loads of a phase in steps 0-2 the
                 //    eight waves queued 96 KB on the CU's address path at once and every wave stalled at issue in front of its MFMAs (half A 5.1 k
                 //    cycles per phase against 3.2 k for half B, which carries more arithmetic);
@@ -363,11 +340,12 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
                         // step s < 5, one scheduling region: fragments of sub-step (s, 1) and the next step's activation pair first, 3 MFMAs, the
                         // next step's first weight pair (into the registers the first three MFMAs have read), 3 MFMAs; the staging work between them
                         const int pz = hf * 2 + s / 3;
-                        if (!(WY_EXP & 1)) { load_a(hf, s, 1, fa[1]); load_b(hf, s + 1, fb[(s + 1) & 1]); }
+                        load_a(hf, s, 1, fa[1]);
+                        load_b(hf, s + 1, fb[(s + 1) & 1]);
                         __builtin_amdgcn_sched_barrier(0);
                         mma3(pz, 0, s & 1);
                         pieces(hf, s);
-                        if (!(WY_EXP & 1)) load_a(hf, s + 1, 0, fa[0]);
+                        load_a(hf, s + 1, 0, fa[0]);
                         mma3(pz, 1, s & 1);
                         if (MM) {
 #pragma unroll
@@ -383,7 +361,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
                     }
                     {   // step 5: sub-step (5, 0), then the barrier that publishes the other weight half, then (5, 1) on the next half's first fragments
                         const int pz = hf * 2 + 1;
-                        if (!(WY_EXP & 1)) load_a(hf, 5, 1, fa[1]);
+                        load_a(hf, 5, 1, fa[1]);
                         __builtin_amdgcn_sched_barrier(0);
                         mma3(pz, 0, 1);
                         pieces(hf, 5);
@@ -403,7 +381,8 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __syncthreads();
                         WY_MARK(WY_KSEC(hf * 3 + 1));
-                        if (!(WY_EXP & 1)) { load_b(hf ^ 1, 0, fb[0]); load_a(hf ^ 1, 0, 0, fa[0]); }
+                        load_b(hf ^ 1, 0, fb[0]);
+                        load_a(hf ^ 1, 0, 0, fa[0]);
                         __builtin_amdgcn_sched_barrier(0);
                         mma3(pz, 1, 1);
                         if (hf == 0) issue_dx();
@@ -447,7 +426,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
             const int y = y0 + 2 * wave_s + r;
             const int co = cob * COT + 32 * t + 4 * c4;
             const unsigned off0 = 4u * (unsigned)((y * W + x0 + (lane >> 3)) * e_r1pix + co), ustride = 32u * (unsigned)e_r1pix;
-            const bool row_ok = e_r1 && y < H && !(WY_EXP & 1024);      // (timing knob: no residual loads: the zero block instead)
+            const bool row_ok = e_r1 && y < H;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = row_ok && (x_inside || x0 + (lane >> 3) + 8 * i < W);
@@ -472,7 +451,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
         WY_EMARK(1);
 #endif
 #pragma unroll
-        for (int r = 0; r < ((WY_EXP & 16) ? 0 : 2); ++r) {
+        for (int r = 0; r < 2; ++r) {
             const int y = y0 + 2 * wave_s + r;
             const int pbase = y * W + x0 + (lane >> 3);
 #pragma unroll
@@ -540,7 +519,6 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         if (i == 0 ? ok0 : ok1) {
-                            if (WY_EXP & 512) asm volatile("" :: "v"(v[i])); else       // (timing knob: no output stores)
                             stg4(e_out, ooff0 + (unsigned)(2 * ih + i) * ostride, v[i]);
                             if (e_pool) ps += v[i];
                         }
@@ -553,9 +531,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
                 if (gi + RR < 4) load_r1((gi + RR) / 2, (gi + RR) % 2, rr[gi % RR]);       // the ring slot is free: next residual group out
             }
         }
-        if (WY_EXP & 16) {
-            asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][0][0]), "v"(acc[0][1][5]), "v"(acc[3][1][7]), "v"(bias4[0]), "v"(bias4[1]), "v"(rr[0][0]), "v"(rr[0][1]), "v"(rr[0][2]), "v"(rr[0][3]));
-        } else if (e_pool) {
+        if (e_pool) {
             // AdaptiveAvgPool2d(1) partials (savsr_arch.py:146,515): one row per 8-row band and 32-pixel column of the image, as the direct
             // kernel writes them (same row numbering: savsr_conv_pool_blocks); band of wave w's rows = w / 4; waves summed in wave order
 #pragma unroll
@@ -587,7 +563,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
         }
         WY_MARK(6);
     }
-#if WY_EXP & 2048
+#if WY_STAMPS
     wy_sec[7] = (long long)__builtin_amdgcn_s_memtime() - wy_t0;
     if (lane == 0 && blockIdx.x < 256)
         for (int i = 0; i < 8; ++i) g_wy_stamps[(blockIdx.x * 8 + wave) * 8 + i] = wy_sec[i];
@@ -610,7 +586,7 @@ int conv_wy_prepare_device() {
 
 using namespace savsr;
 
-#if WY_EXP & 2048
+#if WY_STAMPS
 extern "C" int savsr_debug_read_wy_stamps(long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wy_stamps), sizeof(long long) * 256 * 8 * 8);
 }

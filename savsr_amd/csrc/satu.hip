@@ -19,30 +19,11 @@
 //   the lane that consumes it (HR stage): no cross-lane movement on either side.
 #include "common.hpp"
 
-// Timing experiments on the product LR kernel (results invalid; never set in a shipped build): 1 = weight fragments not
-// re-read per tap, 2 = x / bias quads not re-read per group; 8 = every workgroup records its s_memtime total in stamp
-// slot 7 (cycles are the comparable figure: the variants change the power draw and with it the shader clock).
-#ifndef LR_EXP
-#define LR_EXP 0
-#endif
-#ifndef LR_XPREFETCH
-#define LR_XPREFETCH 1
-#endif
-#ifndef LR_ST
-#define LR_ST 0                   // LRcat stores of satu_lr_stream_kernel: 0 plain, 1 nt, 2 sc1 (write-through), 3 sc0 sc1
-#endif
-#ifndef QS_EXP
-#define QS_EXP 0                  // timing experiments on the row-summed HR form (results invalid): 1 no DPP shifts, 2 no seam stores, 4 ds_bpermute shifts
-#endif
-#ifndef HR_ST
-#define HR_ST 2                   // plane stores of the lane = pixel HR tile: 0 plain, 1 nt, 2 sc1 (write-through)
-#endif
-#ifndef LRS_LRELU
-#define LRS_LRELU 1               // LeakyReLU * x accumulation of satu_lr_stream_kernel: 0 = mul, max, fmac per element; 1 = two independent FMAs
-#endif                            // (0.55 sum x k + 0.45 sum x |k|); 2 = form 0 batched per quad (4 mul | 4 max | 4 fmac)
-#ifndef LRS_EXP
-#define LRS_EXP 0                 // timing experiments on satu_lr_stream_kernel (results invalid; never set in a shipped build): 1 no fragment
-#endif                            // re-reads, 2 no x / bias reads, 4 no LeakyReLU * x arithmetic, 16 no slab DMAs inside the loop
+// Settled build-time choices (numbers in DESIGN.md section 4b; the switches themselves -- LR_EXP / LRS_EXP / QS_EXP timing knobs, LR_XPREFETCH, LR_ST,
+// HR_ST, LRS_LRELU, HR_SCALAR_FMA, HR_LANE_PX -- are archived as tools/experiments/satu_switches.patch):
+//  * LR stage: the second channel group's x tile is loaded under phase 4 of the first; plain LRcat stores; LeakyReLU_0.1(k) * x accumulated as two
+//    independent FMAs (0.55 sum x k + 0.45 sum x |k|);
+//  * HR stage (tail-projected forms): lane = pixel wave tiles, packed FMAs in the gathers, write-through (`sc1`) plane stores.
 
 namespace savsr {
 
@@ -55,7 +36,7 @@ static_assert(rec_floats(2) == SAVSR_SATU_LRCAT && rec_floats(1) == SAVSR_SATU_L
 // Diagnostics (never used by the product path): accumulated s_memtime deltas of kernel sections, written by
 // wave 0 of each workgroup when enabled with savsr_debug_satu_stamps(1).
 [[maybe_unused]] constexpr int SSTAMP_BLOCKS = 2048, SSTAMP_N = 8;
-#if defined(SAVSR_DIAG) || (LR_EXP & 8)
+#if defined(SAVSR_DIAG)
 #define SATU_HAS_STAMPS 1
 __device__ long long g_satu_stamps[SSTAMP_BLOCKS * SSTAMP_N];
 __device__ int g_satu_stamps_on = 0;
@@ -271,14 +252,13 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
 #pragma unroll
     for (int cg = 0; cg < 2; ++cg) {                  // unrolled: sta[cg] must stay in registers
         f32x16 sacc;
-        [[maybe_unused]] f32x16 sabs;                                // LRS_LRELU == 1: sum x |k| (sacc then holds sum x k)
+        f32x16 sabs;                                                 // sum x |k| (sacc holds sum x k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; sabs[r] = 0.f; }
         auto x_read = [&](int ky, int kx, int g) -> f32x4 {          // x_pad at tap (ky, kx), channel quad g of this half
             return *reinterpret_cast<const f32x4*>(xt + ((wave + ky) * LR_XC + px + kx) * LR_XS + 4 * half + 8 * g);
         };
         auto lrelu_x = [&](int g, const f32x16& a, const f32x4 xq) {   // sacc += LeakyReLU_0.1(K) * x_pad   (:228, :297-313)
-#if LRS_LRELU == 1
             // LeakyReLU_0.1(k) = 0.55 k + 0.45 |k|: two INDEPENDENT accumulations per element (sum x k, sum x |k|; combined once per
             // channel group) instead of the dependent mul -> max -> fmac chain.  The first reader of the MFMA result is the
             // compiler's fma (it inserts the wait states an accumulator read needs); the |k| source modifier needs the VOP3 form.
@@ -290,25 +270,6 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
                 asm volatile("v_fma_f32 %0, |%1|, %2, %0" : "+v"(sv) : "v"(k), "v"(xq[q]));
                 sabs[4 * g + q] = sv;
             }
-#elif LRS_LRELU == 2
-            // same arithmetic as below, batched: 4 mul | 4 max | 4 fmac, so that no instruction follows its producer directly
-            float m[4], sv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { m[q] = 0.1f * a[4 * g + q]; sv[q] = sacc[4 * g + q]; }
-            asm volatile("v_max_f32 %0, %8, %0\n\tv_max_f32 %1, %9, %1\n\tv_max_f32 %2, %10, %2\n\tv_max_f32 %3, %11, %3\n\t"
-                         "v_fmac_f32 %4, %0, %12\n\tv_fmac_f32 %5, %1, %13\n\tv_fmac_f32 %6, %2, %14\n\tv_fmac_f32 %7, %3, %15"
-                         : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3])
-                         : "v"(a[4 * g]), "v"(a[4 * g + 1]), "v"(a[4 * g + 2]), "v"(a[4 * g + 3]), "v"(xq[0]), "v"(xq[1]), "v"(xq[2]), "v"(xq[3]));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sacc[4 * g + q] = sv[q];
-#else
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float sv = sacc[4 * g + q], m_tmp = 0.1f * a[4 * g + q];
-                asm volatile("v_max_f32 %0, %2, %0\n\tv_fmac_f32 %1, %0, %3" : "+v"(m_tmp), "+v"(sv) : "v"(a[4 * g + q]), "v"(xq[q]));
-                sacc[4 * g + q] = sv;
-            }
-#endif
         };
         // carried across the phases: the LDS operands of the NEXT group's vector work (read one group ahead of their use)
         f32x4 x_pf = {0.f, 0.f, 0.f, 0.f};                            // (multiplies the zero accumulator in the first phase of a channel group)
@@ -316,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
 #pragma unroll 1
         for (int ky = 0; ky < 5; ++ky) {
             const int ph = cg * 5 + ky, buf = ph & 1;
-            if (LR_XPREFETCH && ph == 4) xt_load(1);   // the second channel group's x tile: its loads fly under this phase (28 registers; written to LDS at the group boundary)
+            if (ph == 4) xt_load(1);   // the second channel group's x tile: its loads fly under this phase (28 registers; written to LDS at the group boundary)
             const bf16x8* wl = wbuf + buf * LR_PHASE + lane;
             const bf16x8* wn = wbuf + (buf ^ 1) * LR_PHASE + lane;
             // x operand of the deferred tap (ky - 1, 4); in the first phase of a channel group the accumulator it multiplies is zero
@@ -344,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                 }
-                if (G >= 16 && !(LRS_EXP & 16)) {       // the slabs of phase ph + 2 into the freed buffer, one piece per group (two with the last)
+                if (G >= 16) {       // the slabs of phase ph + 2 into the freed buffer, one piece per group (two with the last)
                     dma_piece(ph + 2, buf, G - 16);
                     if (G == 19) dma_piece(ph + 2, buf, 4);
                     __builtin_amdgcn_sched_barrier(0);
@@ -352,14 +313,10 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
                 if (kx == 4) acc2 = mma3(fr.ah[ks], fr.al[ks], sth[ks], stl[ks], acc2);
                 else acc[kx & 1] = mma3(fr.ah[ks], fr.al[ks], sth[ks], stl[ks], acc[kx & 1]);
                 // this k-step's fragments of the NEXT tap (tap 0 of the next phase from the other buffer: complete since B(ph))
-                if (LRS_EXP & 1) {
-                } else if (kx < 4) { fr.ah[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 0) * 64]; fr.al[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 1) * 64]; }
+                if (kx < 4) { fr.ah[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 0) * 64]; fr.al[ks] = wl[(kx + 1) * LR_SLAB + (ks * 2 + 1) * 64]; }
                 else { fr.ah[ks] = wn[(ks * 2 + 0) * 64]; fr.al[ks] = wn[(ks * 2 + 1) * 64]; }
                 // LeakyReLU * x of the PREVIOUS tap (tap 4 of the previous phase under tap 0)
-                if (LRS_EXP & 4) {                      // (the accumulators stay live: the MFMAs are not dead code)
-                    const f32x16& a_ = kx == 0 ? acc2 : acc[(kx - 1) & 1];
-                    asm volatile("" :: "v"(a_[4 * ks]), "v"(a_[4 * ks + 1]), "v"(a_[4 * ks + 2]), "v"(a_[4 * ks + 3]), "v"(x_pf[0]));
-                } else if (kx == 0) lrelu_x(ks, acc2, x_pf);
+                if (kx == 0) lrelu_x(ks, acc2, x_pf);
                 else lrelu_x(ks, acc[(kx - 1) & 1], x_pf);
                 // the bias (initial accumulator) of the NEXT tap, quad ks: its previous contents were consumed a tap ago
                 {
@@ -369,8 +326,7 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
                 // LDS operands of the next group's vector work
                 {
                     const int G1 = G + 1, kx1 = (G1 % 20) / 4, ks1 = G1 % 4;
-                    if (LRS_EXP & 2) {
-                    } else if (G1 < 20) {
+                    if (G1 < 20) {
                         x_pf = kx1 > 0 ? x_read(ky, kx1 - 1, ks1) : *reinterpret_cast<const f32x4*>(xdef + 8 * ks1);
                         b_pf = *reinterpret_cast<const f32x4*>((kx1 < 4 ? bias_ptr(ph, kx1 + 1) : bias_ptr(ph + 1, 0)) + 8 * ks1);
                     } else {                                // group 0 of the next phase: the deferred tap (ky, 4) and the bias of its tap 1
@@ -397,15 +353,12 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
         }
-#if LRS_LRELU == 1
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.55f * sacc[r] + 0.45f * sabs[r];
-#endif
         sta[cg] = sacc;
         if (cg == 0) {
-            if (!LR_XPREFETCH) xt_load(1);
             // (the x loads are older than the five pieces of phase 6 issued behind B(4): VMEM returns in order)
-            if (LR_XPREFETCH) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             __syncthreads();                           // every wave is done with the old x tile
             xt_store();
             __syncthreads();
@@ -466,25 +419,9 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
     if (!valid) return;
     float* recf = p.lrcat + ((long long)gy * p.w + gx) * REC;
     f32x4* rec = reinterpret_cast<f32x4*>(recf + half * 32 * NB);
-    // LRcat stores.  LR_ST 2 / 3: write-through (`sc1` / `sc0 sc1`): the 22 MB of records leave the XCD's L2 while the kernel
-    // still computes instead of in the end-of-kernel write-back that the dependent HR launch waits behind (a kernel boundary
-    // costs ~1.5 us + dirty bytes / 6 TB/s, MI355X_MICROARCH.md "boundary"); the readers are other CUs anyway.  The stores are
-    // inline asm, and the first reader of an MFMA result must otherwise be a compiler-generated instruction (hipcc inserts the
-    // wait states): the s_nops in front of them cover the 16-pass MFMA's write-back.
-    auto st16 = [&](f32x4* dst, const f32x4& v) {
-#if LR_ST == 1
-        __builtin_nontemporal_store(v, dst);
-#elif LR_ST == 2
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
-#elif LR_ST == 3
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory");
-#else
-        *dst = v;
-#endif
-    };
-#if LR_ST >= 2
-    asm volatile("s_nop 15\n\ts_nop 15" :: "v"(accC[15]), "v"(accA[NB - 1][15]), "v"(accB[NB - 1][15]));
-#endif
+    // LRcat stores: plain.  (Write-through `sc1` / `sc0 sc1` and `nt` forms were measured in round 3 -- the 22 MB of records would leave the XCD's L2
+    // while the kernel still computes instead of in the end-of-kernel write-back the dependent HR launch waits behind -- and were not faster.)
+    auto st16 = [&](f32x4* dst, const f32x4& v) { *dst = v; };
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
@@ -597,11 +534,6 @@ __device__ __forceinline__ Taps make_taps(float gxn, float gyn, float onx, float
 
 // acc[4g .. 4g+3] += w * v as two v_pk_fma_f32 (explicit 2-vectors: the SLP vectoriser packs only about half of these)
 __device__ __forceinline__ void fma_quad(f32x16& acc, int g, float w, const f32x4& v) {
-#if HR_SCALAR_FMA
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[4 * g + i] = __builtin_fmaf(w, v[i], acc[4 * g + i]);
-    return;
-#endif
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 w2 = {w, w};
     const f32x2 a01 = __builtin_elementwise_fma(w2, f32x2{v[0], v[1]}, f32x2{acc[4 * g], acc[4 * g + 1]});
@@ -735,9 +667,6 @@ __device__ __forceinline__ void hr_tile(const HrParams& p, const float* lds, int
     }
 }
 
-#ifndef HR_SCALAR_FMA
-#define HR_SCALAR_FMA 0           // experiment: plain v_fma_f32 instead of v_pk_fma_f32 in the gathers
-#endif
 // Tail-projected form, LANE = PIXEL: a wave tile is 32 pixels x 2 rows (lanes 0-31 row Y, lanes 32-63 row Y + 1); every lane
 // gathers all 32 output rows of ITS pixel, so the per-pixel work that both lanes of a pixel repeated in hr_tile (table lookup,
 // tap arithmetic, window test, record addresses, the expert operand) is done once: ~300 vector instructions per 32 pixels
@@ -872,25 +801,13 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
             asm volatile("" : "+v"(oo));
             auto st1 = [&](float* pl, unsigned off, float v) {
                 __attribute__((address_space(1))) float* a_ = (__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)pl + off);
-#if HR_ST == 2
-                __hip_atomic_store(a_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif HR_ST == 1
-                __builtin_nontemporal_store(v, a_);
-#else
-                *a_ = v;
-#endif
+                __hip_atomic_store(a_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // emitted as a `sc1` (write-through) store
             };
             float q[5];
 #pragma unroll
             for (int gi = 0; gi < 5; ++gi) {
-#if QS_EXP & 1
-                const float l = acc[3 * gi], r = acc[3 * gi + 2];
-#elif QS_EXP & 4
-                const float l = __shfl_up(acc[3 * gi], 1, 64), r = __shfl_down(acc[3 * gi + 2], 1, 64);
-#else
                 const float l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[3 * gi]), 0x138, 0xf, 0xf, true));        // wave_shr:1: lane i <- lane i - 1
                 const float r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[3 * gi + 2]), 0x130, 0xf, 0xf, true));    // wave_shl:1: lane i <- lane i + 1
-#endif
                 q[gi] = __builtin_fmaf(r, m31, __builtin_fmaf(l, m0, acc[3 * gi + 1]));
             }
             if (valid) {
@@ -913,7 +830,7 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
             // every output store in flight: 35 -> 47 us.  The row's seam record has a wave-uniform base: scalar address arithmetic,
             // the lane supplies only its half's 20-byte offset.)
             typedef float f32x4u_ __attribute__((ext_vector_type(4), aligned(4)));
-            if (!(QS_EXP & 2) && row_ok) {
+            if (row_ok) {
                 float* rowb = p.seam + (long long)((Y + G) * p.nseg + seg) * 18;      // this segment's record: [side A 9 | side B 9]
                 asm volatile("" : "+s"(rowb));
                 const unsigned ho = half ? 20u : 0u;
@@ -937,17 +854,11 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
         if (G ? valid1 : valid0) {
             unsigned oo = G ? o_off1 : o_off0;
             asm volatile("" : "+v"(oo));
-            // HR_ST 2: `sc1` (write-through) stores -- the planes leave L2 as they are written, so the kernel's end has (almost) no
-            // dirty lines left to write back in front of the dependent tail launch; 1: `nt`
+            // `sc1` (write-through) stores -- the planes leave L2 as they are written, so the kernel's end has (almost) no
+            // dirty lines left to write back in front of the dependent tail launch
             auto st1 = [&](float* pl, unsigned off, float v) {
                 __attribute__((address_space(1))) float* a_ = (__attribute__((address_space(1))) float*)((__attribute__((address_space(1))) char*)pl + off);
-#if HR_ST == 2
-                __hip_atomic_store(a_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif HR_ST == 1
-                __builtin_nontemporal_store(v, a_);
-#else
-                *a_ = v;
-#endif
+                __hip_atomic_store(a_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // emitted as a `sc1` (write-through) store
             };
 #pragma unroll
             for (int r = 0; r < 12; ++r) {
@@ -972,9 +883,7 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
 // needs ~4.1 k cycles per 32-pixel tile, three waves sharing a SIMD finish one every ~1.3 k, so the kernel wants as many
 // compute waves per SIMD as the register file holds (the launch bounds give the VGPR cap the kernel is compiled for).
 // A producer wave gets ~4-5 LDS-DMAs in flight (one 1-KiB DMA per ~450 cycles, measured).
-#ifndef HR_LANE_PX
-#define HR_LANE_PX 1              // tail-projected form: lane = pixel wave tiles (hr_tile_px); 0 = two lanes per pixel (hr_tile)
-#endif
+// The tail-projected forms (NB == 1) run lane = pixel wave tiles (hr_tile_px); the standalone form (NB == 2) two lanes per pixel (hr_tile).
 // Two wave splits are compiled (savsr_satu_tiling.variant; the caller picks per size / scale, results do not depend on it):
 //   variant 0 =  8 compute + 4 producer waves (3 waves per SIMD)
 //   variant 1 = 10 compute + 6 producer waves (4 per SIMD: the lane = pixel tile needs 126 VGPRs)
@@ -1016,7 +925,7 @@ __host__ __device__ constexpr int hr_producer_waves(int variant) { return varian
 template <bool DIAG, int NB, int VAR, bool QS = false>
 __global__ __launch_bounds__(64 * (hr_compute_waves(VAR) + hr_producer_waves(VAR)), (hr_compute_waves(VAR) + hr_producer_waves(VAR) + 3) / 4)
 void satu_hr_kernel(const HrParams p) {
-    static_assert(!QS || (NB == 1 && HR_LANE_PX), "the row-summed form is the lane = pixel tail form");
+    static_assert(!QS || NB == 1, "the row-summed form is the lane = pixel tail form");
     constexpr int HR_WAVES = hr_compute_waves(VAR), HR_PRODUCERS = hr_producer_waves(VAR);
     constexpr int REC = rec_floats(NB), LREC = hr_lds_rec(NB);
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1170,7 +1079,7 @@ void satu_hr_kernel(const HrParams p) {
         const float* colg = rowg + HR_MAX_ROWS;
         const int* rowi = reinterpret_cast<const int*>(colg + ncol);
         const int* coli = rowi + HR_MAX_ROWS;
-        if (!dbg_stage_only && NB == 1 && HR_LANE_PX) {
+        if (!dbg_stage_only && NB == 1) {
             // lane = pixel: wave tiles of 32 pixels x 2 rows (tile_rows is a multiple of 4)
             const int npair = (p.ty >> 1) * p.txw, hl = lane >> 5;
             for (int T = wave_s; T < npair; T += HR_WAVES) {
@@ -1293,7 +1202,7 @@ extern "C" int savsr_debug_satu_stamps(int enable) {
 extern "C" int savsr_satu_hr_occupancy_target(int tail_form) { (void)tail_form; return 1; }
 extern "C" int savsr_satu_hr_variants(void) { return HR_VARIANTS; }
 extern "C" int savsr_satu_hr_compute_waves(int variant) { return variant < 0 || variant >= HR_VARIANTS ? -1 : hr_compute_waves(variant); }
-extern "C" int savsr_satu_hr_rows_per_wave_tile(int tail_form) { return tail_form && HR_LANE_PX ? 2 : 1; }
+extern "C" int savsr_satu_hr_rows_per_wave_tile(int tail_form) { return tail_form ? 2 : 1; }
 
 #ifdef SAVSR_DIAG
 // Diagnostics: resident workgroups per CU the runtime predicts for the HR / LR kernels (tail-projected form) with `lds_bytes` of dynamic LDS.

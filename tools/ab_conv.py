@@ -5,7 +5,7 @@ looped `--iters` times between HIP events; median / min over rounds, plus the sh
 loop (savsr_clock_probe of the product library on a side stream) and max |difference| of the outputs to the first variant.
 
     python3 tools/ab_conv.py --libs savsr_amd/csrc/libsavsr_hip.so savsr_amd/csrc/libsavsr_hip_exp_p1.so [--shapes 6x128 1x64 6x64]
-    bash tools/ab_conv.sh "-DCONV_PRIO=1" "-DCONV_PRIO=2"        # builds the variants, then runs this
+    AB_ONLY=conv_wy.hip bash tools/ab_conv.sh "-DWY_VALU=4" "-DWY_STAMPS=1"        # builds the variants, then runs this
 """
 import argparse
 import ctypes as C
@@ -114,7 +114,7 @@ def main():
                     clocks[name].append(win[len(win) // 2])
                     if r == 1:
                         print(f"    [{name}] probe windows MHz: " + " ".join(f"{v:.0f}" for v in (100.0 * c / rt for c, rt in probe_buf.cpu().view(8, 2).tolist() if rt > 0)))
-        for name, (lib, arr) in libs:                          # instrumented Winograd builds (-DWY_EXP=2048): section cycles per wave
+        for name, (lib, arr) in libs:                          # instrumented Winograd builds (-DWY_STAMPS=1 / 2): section cycles per wave
             if hasattr(lib, "savsr_debug_read_wy_stamps") and "winograd" in name:
                 import numpy as np
                 for _ in range(5):
@@ -125,7 +125,7 @@ def main():
                 stt = np.array(buf[:], dtype=np.int64).reshape(256, 8, 8)
                 med = np.median(stt, axis=0)                   # [wave][section]
                 names = ["A s0-4", "A wait+bar", "A s5", "B s0-4", "B wait+bar", "B s5", "epilogue", "total"]
-                if "8192" in os.environ.get("AB_STAMP_MODE", ""):
+                if os.environ.get("AB_STAMP_MODE", "") in ("2", "8192"):       # the library was built with -DWY_STAMPS=2
                     names = ["K loop", "epi loads + transform", "group 0", "group 1", "group 2", "group 3", "pool / rest", "total"]
                 print(f"    [{name}] median cycles per wave over the launch (sections: " + ", ".join(names) + ")")
                 for wv in (0, 3, 4, 7):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build conv-kernel variants HERE or on the GPU box and A/B them in one process:  bash tools/ab_conv.sh "-DCONV_PRIO=1" "-DCONV_PRIO=2"
+# Build conv-kernel variants HERE or on the GPU box and A/B them in one process:  AB_ONLY=conv_wy.hip bash tools/ab_conv.sh "-DWY_VALU=4" "-DWY_STAMPS=1"
 # Each argument is one variant's EXTRA_FLAGS for conv_mfma.hip (own object dir savsr_amd/csrc/exp_vN, own libsavsr_hip_exp_vN.so; the
 # product library is variant 0 and is never touched).  AB_BUILD_ONLY=1: build only (the .so files travel to the GPU box with gpurun).
 set -u

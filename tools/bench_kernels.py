@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--h", type=int, default=180)
     ap.add_argument("--w", type=int, default=320)
     ap.add_argument("--batch", type=int, default=1, help="conv: convs per launch (savsr_conv2d_batch)")
-    ap.add_argument("--cycles", action="store_true", help="conv / satu, library built with -DCONV_EXP=8 / -DLR_EXP=8 (+ experiments): per-workgroup s_memtime totals")
+    ap.add_argument("--cycles", action="store_true", help="conv / satu, instrumented library (libsavsr_hip_diag.so; the CONV_EXP / LR_EXP stamp knobs are archived under tools/experiments/): per-workgroup s_memtime totals")
     ap.add_argument("--stamps", action="store_true", help="conv / satu: print per-workgroup section timings (s_memtime); needs the instrumented library: SAVSR_DIAG=1 bash savsr_amd/csrc/build.sh, SAVSR_LIB_PATH=savsr_amd/csrc/libsavsr_hip_diag.so")
     ap.add_argument("--distinct", action="store_true", help="conv: every conv of the batch gets its own inputs and weights")
     ap.add_argument("--wy", action="store_true", help="conv (3x3, cout % 64 == 0): the Winograd-y form (SAVSR_CONV_WINOGRAD_Y) instead of the direct kernel")
@@ -133,7 +133,7 @@ def main():
         buf = (C.c_longlong * (8 * nb))()
         eng.lib.savsr_debug_read_satu_stamps(buf, nb)
         tot = np.array(buf[:], dtype=np.int64).reshape(nb, 8)[:, 7]
-        print("LR workgroup s_memtime totals (library built with -DLR_EXP=8 + experiments): median %d  max %d" % (np.median(tot), tot.max()))
+        print("LR workgroup s_memtime totals (instrumented library): median %d  max %d" % (np.median(tot), tot.max()))
     if a.stamps and a.what == "satu":
         import ctypes as C
         import numpy as np
