@@ -144,3 +144,21 @@ def test_config3_all_30_scales_shape_finite_bitwise(net):
     assert len(workloads.CONFIG3_SCALES) == 30
     for sc in workloads.CONFIG3_SCALES:
         _run(net, lq, sc)
+
+
+def test_large_frames_1080p_vs_oracle_and_4k(net, synth_sd):
+    """Maximum sizes: an LR clip of 540 x 960 (9 x the pixels of the headline shape; 16-row conv tiles 34 x 30 per image, byte offsets of the
+    128-channel pair buffers at 265 MB) to 1080 x 1920 at x2 against the CPU oracle, and to 2160 x 3840 (4K: 9 planes of 33 MB between the SATU
+    HR stage and the tail) at x4 through the property checks -- shape, finiteness, bitwise rerun -- plus the x2 / x4 agreement of the LR-resolution
+    body (the same clip: the x4 output, box-averaged 2 x 2, stays close to the x2 output: a loose sanity bound, not parity)."""
+    lq = synth.synth_clip(7, 3, 540, 960, seed=5)
+    out2 = _run(net, lq, (2.0, 2.0))
+    with torch.no_grad():
+        ref = O.forward(synth_sd, lq, (2.0, 2.0))
+    err = float((out2 - ref).abs().max())
+    print("540x960 x2 max-abs vs oracle", err)
+    assert err < TOL
+    out4 = _run(net, lq, (4.0, 4.0))
+    assert tuple(out4.shape) == (1, 3, 2160, 3840)
+    down = torch.nn.functional.avg_pool2d(out4, 2)
+    assert float((down - out2).abs().mean()) < 0.05
