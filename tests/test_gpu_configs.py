@@ -1,7 +1,7 @@
 """BASELINE configs 3, 4, 5 at their working sizes (the arbitrary-scale purpose of the model): every phase-table regime
 of the SATU HR stage (4 ... 24 360 distinct coordinate pairs at 180x320), the UDM10 asymmetric shapes, and a seeded sample
 of the Vimeo90K training (shape, scale) list -- shape per the reference's get_HW, finiteness, bitwise rerun, and max-abs
-against the CPU oracle.  Tolerance: 5e-5 max-abs on outputs of magnitude ~1 (fp32 re-association + split-bf16 products;
+against the CPU oracle (config 5: 8 seeded draws + every third entry of the 60-entry list).  Tolerance: 5e-5 max-abs on outputs of magnitude ~1 (fp32 re-association + split-bf16 products;
 measured <= 1.5e-5), far inside north_star's 1e-3 dB PSNR."""
 import pytest
 import torch
@@ -88,6 +88,23 @@ def test_config5_vimeo_training_shapes(net, synth_sd, h, w, sc):
         ref = O.forward(synth_sd, lq, sc)
     err = float((out - ref).abs().max())
     print("config5", (h, w), sc, "max-abs vs oracle", err)
+    assert err < TOL
+
+
+_C5_SEEDED = set(workloads.config5_cases(8, seed=0))
+_C5_SYSTEMATIC = [(workloads.lr_shape(workloads.VIMEO_GT, sc) + (sc,)) for sc in workloads.TRAIN_SCALES[::3]]
+
+
+@pytest.mark.parametrize("h,w,sc", [c for c in _C5_SYSTEMATIC if c not in _C5_SEEDED])
+def test_config5_every_third_training_scale(net, synth_sd, h, w, sc):
+    """beside the 8 seeded draws above, every third entry of the 60-entry training scale list (10 symmetric, 10 asymmetric
+    pairs; LR 64 x 112 ... 230 x 400) against the oracle: up to 28 of the 60 (shape, scale) pairs at their working sizes."""
+    lq = synth.synth_clip(7, 3, h, w, seed=7)
+    out = _run(net, lq, sc)
+    with torch.no_grad():
+        ref = O.forward(synth_sd, lq, sc)
+    err = float((out - ref).abs().max())
+    print("config5 (systematic)", (h, w), sc, "max-abs vs oracle", err)
     assert err < TOL
 
 
