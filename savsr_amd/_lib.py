@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SAVSR_LIB_PATH: diagnostics only (the instrumented build libsavsr_hip_diag.so of `SAVSR_DIAG=1 build.sh`, or an experiment
-# build of tools/conv_experiments.sh under its own name: the product library is never overwritten); unset, the in-tree
+# build of tools/ab_conv.sh under its own name: the product library is never overwritten); unset, the in-tree
 # product library is the only one ever loaded.
 LIB_PATH = os.environ.get("SAVSR_LIB_PATH") or os.path.join(_HERE, "csrc", "libsavsr_hip.so")
 
