@@ -90,18 +90,76 @@ def cpu_baseline(sd, threads):
             "sample": f"{n} frame(s) of the workload clip (7x3x180x320, x4 -> 720x1280) through oracle/savsr_oracle.py, {dt:.2f} s"}, out, lq
 
 
-def sysfs_sclk_mhz():
+def sysfs_device_dir(dev=None):
+    """sysfs directory of the GPU this process runs on (by PCI address: a node has eight cards and card0 is rarely ours); None if unknown."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(dev if dev is not None else torch.cuda.current_device())
+        d = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        if os.path.isdir(d):
+            return d
+    except (AttributeError, RuntimeError, AssertionError):
+        pass
+    cards = sorted(glob.glob("/sys/class/drm/card*/device"))
+    return cards[0] if len(cards) == 1 else None
+
+
+def sysfs_sclk_mhz(dev=None):
     """Current shader-clock level the driver reports (pp_dpm_sclk, the line marked '*'); None where sysfs is not readable.  Not the
     clock a loaded kernel holds (MI355X_MICROARCH.md, DVFS give-back item 6): reported beside the in-kernel probe."""
-    import glob
-    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
-        try:
-            for ln in open(f):
-                if "*" in ln:
-                    return int(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
-        except (OSError, ValueError, IndexError):
-            continue
+    d = sysfs_device_dir(dev)
+    try:
+        for ln in open(os.path.join(d, "pp_dpm_sclk")):
+            if "*" in ln:
+                return int(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+    except (OSError, ValueError, IndexError, TypeError):
+        pass
     return None
+
+
+def sysfs_power_w(dev=None):
+    """(socket power now, power cap) in W from the card's hwmon (power1_input / power1_average, power1_cap: microwatts); None where unreadable."""
+    import glob
+    d = sysfs_device_dir(dev)
+    if not d:
+        return None, None
+    out = []
+    for name in (("power1_input", "power1_average"), ("power1_cap",)):
+        v = None
+        for n in name:
+            for f in glob.glob(os.path.join(d, "hwmon", "hwmon*", n)):
+                try:
+                    v = int(open(f).read().strip()) / 1e6
+                except (OSError, ValueError):
+                    continue
+            if v is not None:
+                break
+        out.append(v)
+    return out[0], out[1]
+
+
+class PowerSampler:
+    """Socket power sampled every 50 ms by a host thread while some load runs (the hwmon figure is the driver's own running average)."""
+
+    def __init__(self, dev):
+        import threading
+        self.dev, self.samples, self.stop_flag = dev, [], threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self.stop_flag.is_set():
+            w, _ = sysfs_power_w(self.dev)
+            if w is not None:
+                self.samples.append(w)
+            self.stop_flag.wait(0.05)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop_flag.set()
+        self.thread.join()
 
 
 class ClockProbe:
@@ -346,9 +404,9 @@ def run_config2(args, rank, world, dev, dist):
                 gathered.copy_(torch.cat(lst, 0))
     # THREE timed regions of exactly K steps each, each bracketed by barrier + synchronize with the MAX over ranks; `value` is the
     # MEDIAN region's (a lease's shader clock drifts by a few % over seconds; one region cannot tell that from a code change)
-    sclk0 = sysfs_sclk_mhz()
+    sclk0 = sysfs_sclk_mhz(dev)
     regions = [timed(dist, dev, region) for _ in range(max(1, args.regions))]
-    sclk1 = sysfs_sclk_mhz()
+    sclk1 = sysfs_sclk_mhz(dev)
     elapsed = sorted(regions)[len(regions) // 2]
     in_flight = [a.elapsed_time(b) for a, b in eng.satu_events]
     eng.satu_events = None
@@ -371,6 +429,16 @@ def run_config2(args, rank, world, dev, dist):
     step(0, False)
     torch.cuda.synchronize()
     clock["under_frame_load"] = probe.mhz()
+    # board power under the same load: ~1 s of untimed steps with the hwmon figure sampled every 50 ms (the frame sits at the power cap)
+    idle_w, cap_w = sysfs_power_w(dev)
+    with PowerSampler(dev) as ps:
+        for i in range(max(2, int(round(1.0 / (elapsed / args.steps))))):
+            step(i, False)
+        torch.cuda.synchronize()
+    if ps.samples:
+        tail = sorted(ps.samples[len(ps.samples) // 2:])          # second half: the running average has caught up with the load
+        line["power_w"] = {"under_frame_load": round(tail[len(tail) // 2], 1), "max_sample": round(max(ps.samples), 1), "before": idle_w, "cap": cap_w,
+                           "samples": len(ps.samples), "note": "hwmon power1 of this GPU, sampled every 50 ms over ~1 s of untimed steps (median of the second half)"}
     allrows = (gathered if dist is not None else rows).cpu()
     line["psnr_y_vs_synthetic_gt"] = round(float(allrows[:, 0].mean()), 4)
     line["ssim_y_vs_synthetic_gt"] = round(float(allrows[:, 1].mean()), 6)
