@@ -37,6 +37,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
+from savsr_amd.utils.host import cpu_model, effective_cpus  # noqa: E402
+
 LR_H, LR_W, SCALE = 180, 320, (4, 4)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (sustained under load: ~1870, tools/micro/mfma_rate.hip)
@@ -44,28 +46,6 @@ MAC_PER_LR_PX = 22.99e6          # algorithmic MACs of the network,
 MAC_PER_HR_PX = 19.9e3
 DTYPE = "f32 (bf16x3 split products, fp32 accumulate)"
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "satu_traffic.json")     # PMC-measured HBM bytes of the SATU launches (tools/pmc_summary.py)
-
-
-def effective_cpus():
-    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return n
-
-
-def cpu_model():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
 
 
 def cpu_baseline(sd, threads):
@@ -234,16 +214,21 @@ def conv_roofline(eng, dev, iters=20, probe=None):
     direct_eq = 3.0 * alg                                   # split-bf16 direct form: three bf16 MFMA products per fp32 product
     form = int(descs[0].algo)
     is_wy = form == 3
+    # MFMAs the launch really issues (v_mfma_f32_32x32x16_bf16 = 32768 flop): per 32-px column block, ROW PAIR (waves below the image run an
+    # MFMA-free body), 16-channel phase and 64 output channels 108 in the direct form (9 taps x 2 rows x 2 channel blocks x 3 products), 72 in
+    # the Winograd-y form (12 taps for the two rows).  6 x 128->64 at 180x320: 3.1104 M = the PMC count (profiles/r04_conv_wy_pmc_summary.csv: 3.110 M)
+    n_mfma = n * ((LR_W + 31) // 32) * ((LR_H + 1) // 2) * (cin // 16) * (cout // 64) * (72 if is_wy else 108)
+    issued = n_mfma * 32768.0
     r = {"kernel": ("conv_wy_kernel (Winograd F(2,3) along y" if is_wy else "conv_bf16x3_kernel<3,2,2> (direct") +
                    "; 6 x conv3x3 128->64 + bias + LeakyReLU + residual, 180x320)", "bound": "mfma",
-         "achieved": round(direct_eq / sec / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(direct_eq / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-         "traffic": None, "algorithmic_flops": alg, "fp32_equivalent_tflops": round(alg / sec / 1e12, 1), "avg_ms": round(1e3 * sec, 4),
-         "clock_mhz_under_launch": clock,
-         "note": "achieved = the split-bf16 DIRECT form's MFMA flops of this conv work (3 bf16 products per fp32-equivalent MAC x 2) / time: the "
-                 "figure rounds 1-3 reported"
-                 + ("; the Winograd form the product runs issues 2/3 of them (mfma_issued_frac)" if is_wy else "") + "; launch timed solo after the timed region"}
-    if is_wy:
-        r["mfma_issued_frac"] = round(2.0 / 3.0 * direct_eq / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
+         "achieved": round(issued / sec / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(issued / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+         "traffic": None, "issued_mfma": n_mfma, "issued_flops": issued,
+         "direct_equivalent_tflops": round(direct_eq / sec / 1e12, 1), "direct_equivalent_frac": round(direct_eq / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+         "algorithmic_flops": alg, "fp32_equivalent_tflops": round(alg / sec / 1e12, 1), "algorithmic_frac": round(alg / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+         "avg_ms": round(1e3 * sec, 4), "clock_mhz_under_launch": clock,
+         "note": "achieved / frac = bf16 MFMA flops the launch ISSUES (issued_mfma x 32768; the instruction count is the PMC's) / time"
+                 + ("; direct_equivalent_* = what the same conv work costs in the direct split-bf16 form (3 products per MAC), the figure rounds 1-4 reported as "
+                    "frac; the Winograd form issues 2/3 of it" if is_wy else "") + "; algorithmic_* = 2 x MACs (fp32-equivalent); launch timed solo after the timed region"}
     return r
 
 
@@ -371,6 +356,7 @@ def run_config2(args, rank, world, dev, dist):
     net, sd = build_net(dev)
     net.set_scale(SCALE)
     eng = net.engine()
+    eng.census = {}               # matrix work of every conv launch by the form it takes (engine._count_conv), filled while the frames are captured
     H, W = LR_H * SCALE[0], LR_W * SCALE[1]
     cps = max(1, args.clips_per_step)
     n_batches = 2
@@ -457,8 +443,23 @@ def run_config2(args, rank, world, dev, dist):
     line["batch1_ms_per_frame"] = round(1e3 * b1, 3)
     frame_s = elapsed / (args.steps * cps)
     macs = MAC_PER_LR_PX * LR_H * LR_W + MAC_PER_HR_PX * H * W
-    line["whole_frame_mfma_frac"] = round(3 * 2 * macs / frame_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
-    line["whole_frame_note"] = "3 bf16 MFMA products per fp32-equivalent MAC x 2 flop x 1.34 TMAC per frame (SURVEY 8(d) census) / frame time / 2.5 PF"
+    # Matrix-unit utilisation of the whole frame = flops of the bf16 MFMAs the frame ISSUES / frame time / dense bf16 peak.  Issued: the conv
+    # launches from the engine's census of the captured frame (3 split products per MAC in the direct form, 2 in the Winograd-y form, on the
+    # padded tile grid) + the SATU LR stage's (kernel_conv 64 -> 1600 and the three projections, 3 products per MAC).  Rounds 1-4 reported
+    # `whole_frame_direct_equivalent_frac` under this name: 3 products for EVERY MAC of the SURVEY census, executed or not.
+    cen = eng.census
+    mode = "tp" if cen.get("frames_tp") else "b1"
+    nfr = max(1, cen.get("frames_" + mode, 1))
+    satu_lr_issued = 3 * 2 * LR_H * LR_W * (1600 * 64 + 96 * 64)
+    issued = cen.get("issued_" + mode, 0.0) / nfr + satu_lr_issued
+    line["whole_frame_mfma_frac"] = round(issued / frame_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
+    line["whole_frame_direct_equivalent_frac"] = round(3 * 2 * macs / frame_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
+    line["whole_frame_algorithmic_frac"] = round(2 * macs / frame_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
+    line["whole_frame_winograd_share"] = round(cen.get("wy_alg_" + mode, 0.0) / max(cen.get("alg_" + mode, 1.0), 1.0), 4)
+    line["whole_frame_note"] = ("whole_frame_mfma_frac = ISSUED bf16 MFMA flops per frame (conv census of the captured frame: 3 products per MAC direct, 2 in the "
+                                "Winograd-y form, padded tiles; + SATU LR) / frame time / 2.5 PF; _direct_equivalent_ = 3 x 2 x 1.34 TMAC (SURVEY 8(d)) / time / peak "
+                                "(rounds 1-4's figure: counts products the Winograd launches do not execute); _algorithmic_ = 2 x 1.34 TMAC / time / peak; "
+                                "winograd_share = share of the conv MACs that ran in the Winograd-y form")
     line["roofline"] = satu_roofline(eng, clips[0][0], LR_H, LR_W, SCALE, in_flight)
     line["roofline_conv"] = conv_roofline(eng, dev, probe=probe)
     clock["under_conv_launch"] = line["roofline_conv"]["clock_mhz_under_launch"]
@@ -604,13 +605,15 @@ def run_run_test(args, rank, world, dev, dist):
     from savsr_amd import models as M
     from savsr_amd import test as T
     from savsr_amd.utils import synth
-    root = tempfile.mkdtemp(prefix="savsr_bench_") if rank == 0 else None
+    emu = args.emulate_world > 0                # a lone process running rank --emulate-rank's share of a world-size --emulate-world run
+    own_tree = not args.tree
+    root = args.tree or (tempfile.mkdtemp(prefix="savsr_bench_") if rank == 0 else None)
     if dist is not None:
         box = [root]
         dist.broadcast_object_list(box, src=0)
         root = box[0]
     try:
-        if rank == 0:
+        if rank == 0 and own_tree:
             make_png_tree(root, args.frames_per_folder)
             sd = synth.synth_state_dict(seed=0)
             torch.save({"params": sd}, os.path.join(root, "net.pth"))
@@ -618,13 +621,18 @@ def run_run_test(args, rank, world, dev, dist):
             dist.barrier()
         opt = run_test_opt(root, os.path.join(root, "net.pth"), args.save_img)
         opt["rank"], opt["world_size"], opt["dist"] = rank, world, dist is not None
-        os.environ.setdefault("SAVSR_CACHE_SHAPES", str(4 * len(RUN_TEST_SCALES) + 1))      # every (folder, scale) LR shape stays captured
+        if emu:
+            opt["rank"], opt["world_size"], opt["dist"], opt["emulate_world"] = args.emulate_rank, args.emulate_world, True, True
+            rank_e, world_e = args.emulate_rank, args.emulate_world
         torch.cuda.set_device(dev)
         model = M.build_model(opt)            # one model (= one engine, its graphs) across the passes, as in one long YAML
         model_box = {"m": model}
         passes = []
         n_frames = len(VID4_SHAPES) * args.frames_per_folder * len(RUN_TEST_SCALES)
         hr_px = sum(round_hw(H, W, sc) for _, H, W in VID4_SHAPES for sc in RUN_TEST_SCALES) * args.frames_per_folder
+        if emu:                                # this rank's share: per folder block [r n / N, (r + 1) n / N)
+            per_folder = ((rank_e + 1) * args.frames_per_folder) // world_e - (rank_e * args.frames_per_folder) // world_e
+            n_frames = len(VID4_SHAPES) * per_folder * len(RUN_TEST_SCALES)
         results = None
         for p in range(2):
             if "m" in model_box:
@@ -637,8 +645,13 @@ def run_run_test(args, rank, world, dev, dist):
             el = timed(dist, dev, region)
             results = box["res"]
             st1 = sio.frame_store().stats
+            hs = dict(model.net_g.engine().host_stats)
             passes.append({"wall_s": round(el, 3), "frames_per_s": round(n_frames / el, 2), "gpu_busy_frac": round(model_box["m"].gpu_ms / 1e3 / el, 4),
-                           "png_decoded_rank0": st1["decoded"] - st0["decoded"], "uploaded_rank0": st1["uploaded"] - st0["uploaded"]})
+                           "png_decoded_rank0": st1["decoded"] - st0["decoded"], "uploaded_rank0": st1["uploaded"] - st0["uploaded"],
+                           "host_stats_cumulative": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in hs.items()}})
+        if emu:                                # the child of --emulate-world: its passes are the result
+            print(json.dumps({"emulated_world": world_e, "emulated_rank": rank_e, "frames": n_frames, "cold_pass": passes[0], "steady_pass": passes[1]}), flush=True)
+            return
         # the same frames through the network alone (inputs resident in HBM, groups of n_streams clips in flight, no metrics):
         # what the workflow would run at if everything around the path were free
         m = model_box["m"]
@@ -686,8 +699,57 @@ def run_run_test(args, rank, world, dev, dist):
     finally:
         if dist is not None:
             dist.barrier()
-        if rank == 0 and root:
+        if rank == 0 and root and own_tree:
             shutil.rmtree(root, ignore_errors=True)
+
+
+def run_emulate_world(args, argv):
+    """`--config run_test --emulate-world N` without --emulate-rank: the part of the 1 -> N strong-scaling curve of the YAML flow that one GPU
+    can know in advance.  Fresh child processes (what a rank is: its own decode cache, engine, captures, HR plan choices), one at a time on
+    the one GPU, over ONE PNG tree: the whole job (world 1) and rank 0 / rank N - 1 of a world-size-N run, each its block partition alone
+    (harness.block_partition; the collective -- a [n, 2] all_gather per dataset -- is left out).  predicted efficiency = T(1) / (N x max_r T_r),
+    for the cold pass (what `python -m savsr_amd.test -opt <yaml>` is) and for the steady one."""
+    import shutil
+    import subprocess
+    import tempfile
+    from savsr_amd.utils import synth
+    n = args.emulate_world
+    root = tempfile.mkdtemp(prefix="savsr_bench_emu_")
+    try:
+        make_png_tree(root, args.frames_per_folder)
+        torch.save({"params": synth.synth_state_dict(seed=0)}, os.path.join(root, "net.pth"))
+        runs = {}
+        for w, r in [(1, 0), (n, 0), (n, n - 1)]:
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", "run_test", "--emulate-world", str(w), "--emulate-rank", str(r),
+                   "--tree", root, "--frames-per-folder", str(args.frames_per_folder)] + (["--save-img"] if args.save_img else [])
+            p = subprocess.run(cmd, capture_output=True, text=True)
+            if p.returncode != 0:
+                print(p.stdout[-2000:] + p.stderr[-4000:], file=sys.stderr, flush=True)
+                sys.exit(p.returncode)
+            runs[(w, r)] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        one = runs[(1, 0)]
+        ranks = [runs[(n, 0)], runs[(n, n - 1)]]
+        line = {"metric": f"predicted strong-scaling efficiency of the YAML flow at world size {n} (one GPU, ranks emulated one at a time)",
+                "unit": "fraction of linear", "n_gpus": 1, "higher_is_better": True, "bench_config": "run_test --emulate-world",
+                "emulated_world": n, "data": "synthetic", "frames_per_folder": args.frames_per_folder, "world1": one, "ranks": ranks}
+        for name in ("cold_pass", "steady_pass"):
+            t1 = one[name]["wall_s"]
+            tr = max(x[name]["wall_s"] for x in ranks)
+            line["predicted_strong_scaling_eff_" + name.split("_")[0]] = round(t1 / (n * tr), 4)
+        slow = max(ranks, key=lambda x: x["cold_pass"]["wall_s"])
+        hs = slow["cold_pass"]["host_stats_cumulative"]
+        ideal = one["cold_pass"]["wall_s"] / n
+        line["value"] = line["predicted_strong_scaling_eff_cold"]
+        line["loss_breakdown_cold_slowest_rank"] = {
+            "rank_wall_s": slow["cold_pass"]["wall_s"], "ideal_s (T1 / N)": round(ideal, 3), "graph_capture_s": hs["capture_s"], "hr_plan_timing_s": hs["plan_s"],
+            "captures": hs["captures"], "eager_frames": hs["eager_frames"], "png_decoded": slow["cold_pass"]["png_decoded_rank0"],
+            "gpu_busy_frac": slow["cold_pass"]["gpu_busy_frac"],
+            "note": "what a rank pays per (folder, scale) whatever its share of the frames: PNG decode of its block + window reach, the first frame's "
+                    "buffer plan and table upload, graph captures (after SAVSR_CAPTURE_AFTER eager frames) and HR plan timing (scales missing from "
+                    "savsr_amd/hr_plans.json); the collective (one [n, 2] all_gather per dataset) is not in the emulation"}
+        print(json.dumps(line), flush=True)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def round_hw(H, W, sc):
@@ -728,6 +790,10 @@ def main():
                     help="BASELINE.json config (2 = the judged line); run_test = the YAML workflow on a synthetic PNG tree")
     ap.add_argument("--frames-per-folder", type=int, default=32, help="run_test: frames per synthetic folder (4 folders)")
     ap.add_argument("--save-img", action="store_true", help="run_test: also write every output frame as PNG (val.save_img)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="run_test on ONE GPU: time the whole job and ranks 0 / N-1 of a world-size-N run in fresh "
+                                                                 "processes, report the predicted strong-scaling efficiency")
+    ap.add_argument("--emulate-rank", type=int, default=-1, help="(internal: the child of --emulate-world that runs one rank's share)")
+    ap.add_argument("--tree", type=str, default="", help="(internal: an existing synthetic PNG tree + net.pth)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--regions", type=int, default=3, help="config 2: timed regions of K steps each (value = the median region)")
     ap.add_argument("--clips-per-step", type=int, default=18,
@@ -738,6 +804,12 @@ def main():
         args.config = int(args.config)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.emulate_world:
+        if args.config != "run_test" or args.gpus != 1:
+            ap.error("--emulate-world goes with --config run_test on one GPU")
+        if args.emulate_rank < 0:
+            run_emulate_world(args, sys.argv[1:])       # children first: this process never touches the GPU
+            return
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
             self_launch(args, sys.argv[1:])            # never returns

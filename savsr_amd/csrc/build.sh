@@ -25,7 +25,12 @@ mkdir -p "$OBJDIR"
 # savsr_source_hash(): sha256 over the kernel sources + headers + flags this library is built from (first 16 hex digits), compiled into
 # api.cpp, so that a measurement file (profiles/satu_traffic.json) can name the build it was taken on and bench.py can tell a stale one
 SRC_HASH=$( (cat conv_mfma.hip conv_wy.hip osconv.hip elementwise.hip satu.hip tail.hip metrics.hip resize.hip api.cpp common.hpp conv_common.hpp ../../include/savsr_hip.h; printf '%s' "$BASE_FLAGS ${EXTRA_FLAGS:-} ${EXTRA_ONLY:-}") | sha256sum | cut -c1-16)
-SATU_HASH=$( (cat satu.hip tail.hip common.hpp; printf '%s' "$BASE_FLAGS -fno-slp-vectorize") | sha256sum | cut -c1-16)   # the SATU + tail kernels alone (not the header: it changes with every other kernel's interface)
+# the SATU + tail kernels alone (not the header: it changes with every other kernel's interface) -- with the EXTRA_FLAGS that reach them: an
+# experiment / DIAG build that changes these kernels through -D switches must not report the product's hash (profiles/satu_traffic.json and
+# savsr_amd/hr_plans.json are attached to a library by this stamp)
+SATU_EXTRA=""
+if [ -n "${EXTRA_FLAGS:-}" ] && { [ -z "${EXTRA_ONLY:-}" ] || [[ " ${EXTRA_ONLY} " == *" satu.hip "* ]] || [[ " ${EXTRA_ONLY} " == *" tail.hip "* ]]; }; then SATU_EXTRA=" ${EXTRA_FLAGS}"; fi
+SATU_HASH=$( (cat satu.hip tail.hip common.hpp; printf '%s' "$BASE_FLAGS -fno-slp-vectorize$SATU_EXTRA") | sha256sum | cut -c1-16)
 
 # per-file flags: satu.hip and conv_wy.hip keep their scalar fp32 arithmetic scalar -- packed fp32 instructions (v_pk_mul / v_pk_fma) are an
 # anti-lever beside MFMAs on gfx950 (MI355X_MICROARCH.md); the explicit 2-vector code of the HR stage is unaffected

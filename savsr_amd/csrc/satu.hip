@@ -25,6 +25,13 @@
 //    independent FMAs (0.55 sum x k + 0.45 sum x |k|);
 //  * HR stage (tail-projected forms): lane = pixel wave tiles, packed FMAs in the gathers, write-through (`sc1`) plane stores.
 
+// LR stage, tail form: 1 = the records leave through a wave-private LDS transpose as whole 128-B lines, non-temporal (round 5: LR 42.4-43.0 ->
+// 39.4-39.5 us on one lease; plain / sc1 / sc0 sc1 stores of the same lines 40.3-40.8 / 39.2-39.7 / 39.5-39.7); 0 = straight from the
+// accumulators, 16-B pieces of 64 different lines per store instruction (rounds 1-4; the standalone 160-float form always)
+#ifndef LR_COALESCED_STORES
+#define LR_COALESCED_STORES 1
+#endif
+
 namespace savsr {
 
 // Floats per LRcat record for NB 32-row output blocks per projection: (A | B) per lane half, then the 32 compressed channels.
@@ -414,6 +421,50 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
             o[6] = (long long)__builtin_amdgcn_s_memrealtime();
             o[7] = SATU_T() - ts0;
         }
+    }
+#endif
+#if LR_COALESCED_STORES
+    if constexpr (NB == 1) {
+        // ---- LRcat write-back, COALESCED (round 5).  A lane holds 12 of the 24 quads of ITS pixel's 384-B record; stored straight
+        // from the accumulators every store instruction touched 64 different 128-B lines with 16 B each (768 partial-line writes per
+        // wave and tile, nothing a write-through policy can stream).  The 32 records of a wave's row are one contiguous 12-KB run of
+        // LRcat, so they go through a wave-private LDS region (record pitch 100 floats: conflict-free b128 in both directions) and
+        // leave as twelve 1-KiB stores of eight whole lines each.
+        // LDS that is free here: the x tile (every wave read it for the last time in the drain above) and weight buffer 1 (last read in
+        // phase 9; its last -- dummy -- DMAs were waited for above); buffer 0 still holds the projection image ((2 NB + 1) x 8 KB).
+        __syncthreads();
+        // (every index below is rebuilt from an opaque copy of the thread id: values kept live from the top of the kernel through the phase
+        // loops cost registers the loops do not have -- 256 allocated -- and the first version of this block spilled one of the centre-pixel
+        // loads of the last phase behind an s_waitcnt vmcnt(1))
+        unsigned t2 = threadIdx.x;
+        asm volatile("" : "+v"(t2));
+        const int ln = (int)(t2 & 63u), pxe = ln & 31, hfe = ln >> 5;
+        const int wv = __builtin_amdgcn_readfirstlane((int)(t2 >> 6));
+        constexpr int SP = 100;                                       // staged record pitch (floats)
+        float* stg = wv < 4 ? smem + wv * (32 * SP)
+                   : (wv < 7 ? smem + LR_NPX * LR_XS + LR_PHASE * 4 + (wv - 4) * (32 * SP)
+                             : smem + LR_NPX * LR_XS + (2 * NB + 1) * LR_SLAB * 4);
+        static_assert(4 * 32 * SP <= LR_NPX * LR_XS && 3 * 32 * SP <= LR_PHASE * 4 && (2 * NB + 1) * LR_SLAB * 4 + 32 * SP <= LR_PHASE * 4, "staging regions");
+        f32x4* mine = reinterpret_cast<f32x4*>(stg + pxe * SP);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mine[hfe * 8 + g] = f32x4{accA[0][4 * g], accA[0][4 * g + 1], accA[0][4 * g + 2], accA[0][4 * g + 3]};
+            mine[hfe * 8 + 4 + g] = f32x4{accB[0][4 * g], accB[0][4 * g + 1], accB[0][4 * g + 2], accB[0][4 * g + 3]};
+            mine[16 + 2 * g + hfe] = f32x4{accC[4 * g], accC[4 * g + 1], accC[4 * g + 2], accC[4 * g + 3]};
+        }
+        const int ex0 = blockIdx.x * LR_TW, ey0 = blockIdx.y * LR_TH;    // (scalar)
+        const int egy = ey0 + wv;
+        if (egy >= p.h) return;                                       // (wave-uniform; no barrier follows)
+        const int nq = (p.w - ex0 < 32 ? p.w - ex0 : 32) * (REC / 4);  // valid quads of this wave's run
+        f32x4* row = reinterpret_cast<f32x4*>(p.lrcat + ((long long)egy * p.w + ex0) * REC);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const unsigned Q = 64u * j + (unsigned)ln;
+            const unsigned rp = Q / 24u, rq = Q - rp * 24u;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + rp * SP + 4 * rq);
+            if ((int)Q < nq) __builtin_nontemporal_store(v, row + Q);
+        }
+        return;
     }
 #endif
     if (!valid) return;
@@ -927,7 +978,7 @@ __global__ __launch_bounds__(64 * (hr_compute_waves(VAR) + hr_producer_waves(VAR
 void satu_hr_kernel(const HrParams p) {
     static_assert(!QS || NB == 1, "the row-summed form is the lane = pixel tail form");
     constexpr int HR_WAVES = hr_compute_waves(VAR), HR_PRODUCERS = hr_producer_waves(VAR);
-    constexpr int REC = rec_floats(NB), LREC = hr_lds_rec(NB);
+    constexpr int REC = rec_floats(NB);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);      // tile walk and row / column tests as scalar code
@@ -959,7 +1010,7 @@ void satu_hr_kernel(const HrParams p) {
     int* ring = reinterpret_cast<int*>(cst + hr_wimg_floats(NB) + 64);   // [4] tile ids handed out by the queue (dynamic walk)
     float* tabl = cst + hr_wimg_floats(NB) + 64 + 16;             // whole table, offsets normalised (small tables)
     const int once = hr_once_floats(NB, small), bufsz = hr_buf_floats(NB, p.ty, p.txw, p.lrh, p.lrw, small);
-    const int win_floats = p.lrh * p.lrw * LREC, slice_floats = small ? 0 : p.ty * ncol * SAVSR_SATU_TABLE;
+    const int win_floats = p.lrh * p.lrw * hr_lds_rec(NB), slice_floats = small ? 0 : p.ty * ncol * SAVSR_SATU_TABLE;
 
 #if SATU_HAS_STAMPS
     const int dbg_all = DIAG ? __builtin_amdgcn_readfirstlane(g_satu_stamps_on) : 0;

@@ -186,8 +186,16 @@ class HipEngine:
         self._keep: List[torch.Tensor] = []
         self._init_caches()
         self.satu_events: Optional[list] = None     # bench.py: (start, end) HIP events around SATU
+        self.census: Optional[dict] = None          # bench.py: per-launch matrix-work census (_count_conv), shared with the sibling engines
+        # A (shape, scale) context's first frames run EAGERLY and the hipGraphs are captured on visit SAVSR_CAPTURE_AFTER + 1: a capture costs
+        # ~5 ms of host time with the GPU idle and only pays back over replays (steadier launch timing beside decode threads and the GIL) --
+        # a rank's block of a YAML folder at world size 8 is 4-6 frames, for which eager launches (~330 x 11 us of host time under an 8 ms
+        # GPU frame) are simply faster.  Eager, captured and replayed frames are the same launch sequence: bit-identical results.
+        self.capture_after = max(0, int(os.environ.get("SAVSR_CAPTURE_AFTER", "4")))
+        self.host_stats = {"captures": 0, "capture_s": 0.0, "plan_s": 0.0, "eager_frames": 0}     # shared with the sibling engines (bench.py)
         self.conv_algo = _lib.CONV_DIRECT           # CONV_DIRECT_THROUGHPUT while several clips are in flight (forward_many / batches)
         self._hr_choice: Dict[tuple, int] = {}      # (h, w, sh, sw) -> timed choice of the HR kernel's wave split; shared with the sibling engines
+        self._hr_table = self._load_hr_plans()      # scale -> plan measured once per build of the SATU kernels (savsr_amd/hr_plans.json)
         self.use_graphs = os.environ.get("SAVSR_GRAPHS", "1") != "0"
         # SATU in the row-summed tail form (savsr_satu_hr_tail_q + savsr_tail_gather_q: 9 planes + seams between the HR stage and the
         # tail instead of 27 planes); SAVSR_SATU_Q=0: the 27-plane form
@@ -205,6 +213,26 @@ class HipEngine:
         self._siblings: List["HipEngine"] = []
         self._streams: List[torch.cuda.Stream] = []
         self._pack_all({k: v.detach() for k, v in state.items()})
+
+    HR_PLANS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hr_plans.json")
+
+    def _load_hr_plans(self) -> Dict[tuple, tuple]:
+        """The HR stage's launch plan per scale as measured for THIS build of the SATU kernels (tools/tune_hr_plans.py writes the file with the
+        library's savsr_source_hash_satu()): every rank of a multi-GPU run, and every run, then launches the same plan without timing the
+        candidates on its first frame of a (folder, scale) -- eight ranks used to make eight measurements and could pick eight plans.  A table
+        from another build is ignored (the engine measures, as before); so is an entry whose plan is not feasible for the offsets of the loaded
+        weights.  Results never depend on the plan (bit-identical in every plan)."""
+        if os.environ.get("SAVSR_HR_PLANS", "1") == "0":
+            return {}
+        try:
+            import json
+            with open(self.HR_PLANS_FILE) as f:
+                t = json.load(f)
+            if t.get("satu_source_hash") != self.lib.savsr_source_hash_satu().decode():
+                return {}
+            return {tuple(float(v) for v in k.split(",")): tuple(int(x) for x in p) for k, p in t.get("plans", {}).items()}
+        except (OSError, ValueError, AttributeError):
+            return {}
 
     # ------------------------------------------------------------------ weight preparation
     def _dev(self, t: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
@@ -456,10 +484,11 @@ class HipEngine:
             e.osc[k] = c
         e.se_gate = torch.empty_like(self.se_gate)
         e._init_caches()
-        e.max_shapes, e.max_scales = self.max_shapes, self.max_scales
-        e.satu_events, e.use_graphs = None, self.use_graphs
+        e.max_shapes, e.max_scales, e._budget = self.max_shapes, self.max_scales, self._budget
+        e.satu_events, e.use_graphs, e.census = None, self.use_graphs, self.census
+        e.capture_after, e.host_stats = self.capture_after, self.host_stats
         e.conv_algo = _lib.CONV_DIRECT
-        e._hr_choice = self._hr_choice
+        e._hr_choice, e._hr_table = self._hr_choice, self._hr_table
         e._siblings, e._streams = [], []
         return e
 
@@ -470,43 +499,106 @@ class HipEngine:
     # pinning every size it has ever seen (the reference frees everything per frame, video_base_model.py:72-74).
     def _init_caches(self):
         from collections import OrderedDict
-        self.max_shapes = max(1, int(os.environ.get("SAVSR_CACHE_SHAPES", "12")))     # (0.57 GB per 180x320 shape and stream with the liveness plan: 12 shapes = what 4 cost before it)
+        # Count caps (secondary: the byte budget below is what normally decides) ...
+        self.max_shapes = max(1, int(os.environ.get("SAVSR_CACHE_SHAPES", "256")))
         self.max_scales = max(1, int(os.environ.get("SAVSR_CACHE_SCALES", "48")))
+        # ... and the BYTE budget of everything this engine and its sibling engines (one per HIP stream) keep resident per (shape, scale):
+        # arena chunks of the LR / HR buffers, the graphs' static input / output, per-pixel SATU tables.  SAVSR_CACHE_GB, default half of the
+        # HBM that is free when the engine is built: a Vimeo-shaped stream (51 LR shapes x 3 streams x ~0.3 GB) stays resident, a 540x960
+        # stream (5 GB per shape and stream) keeps what fits -- one knob for both instead of a shape count that suits one of them.
+        gb = os.environ.get("SAVSR_CACHE_GB")
+        if gb is not None:
+            limit = int(float(gb) * (1 << 30))
+        else:
+            try:
+                limit = int(0.5 * torch.cuda.mem_get_info(self.dev)[0])
+            except RuntimeError:
+                limit = 64 << 30
+        self._budget = {"limit": max(limit, 1), "used": 0, "evictions": 0, "trim": False}    # shared with the sibling engines (clone_for_stream)
         self._ctx: "OrderedDict[tuple, dict]" = OrderedDict()
         self._axes: "OrderedDict[tuple, dict]" = OrderedDict()
-        self._default_ctx = dict(bufs={}, scales=OrderedDict())      # direct kernel-level calls (tests, tools) outside a forward
-        self._default_sc = dict(bufs={}, graphs=None, chunk=0)
+        self._default_ctx = dict(bufs={}, scales=OrderedDict(), bytes=0, untracked=True)      # direct kernel-level calls (tests, tools) outside a forward
+        self._default_sc = dict(bufs={}, graphs=None, chunk=0, bytes=0, untracked=True)
         self.hr_sched = torch.zeros(16, dtype=torch.int32, device=self.dev)     # tile-queue scratch of the SATU HR kernel (one per engine = per stream)
         self._cur, self._cur_sc = self._default_ctx, self._default_sc
+        self._cur_key = None
+
+    def _charge(self, owner: dict, nbytes: int) -> None:
+        """Account `nbytes` of device memory to a (shape) or (shape, scale) context and to the shared budget."""
+        owner["bytes"] = owner.get("bytes", 0) + int(nbytes)
+        if not owner.get("untracked"):
+            self._budget["used"] += int(nbytes)
+
+    @staticmethod
+    def _ctx_bytes(ctx: dict) -> int:
+        return ctx.get("bytes", 0) + sum(sc.get("bytes", 0) for sc in ctx["scales"].values())
+
+    def _drop(self, skey: tuple) -> None:
+        """Evict one shape context of THIS engine.  Its graphs may still be replaying on this engine's stream: their memory came from the
+        graphs' private pool, which the allocator hands to nobody else and returns to the device only through hipFree (device-synchronous,
+        empty_cache() below or the allocator's own out-of-memory path) -- dropping the references is safe at any time."""
+        ctx = self._ctx.pop(skey)
+        self._budget["used"] -= self._ctx_bytes(ctx)
+        self._budget["evictions"] += 1
+        self._budget["trim"] = True
+
+    def _drop_scale(self, ctx: dict, ckey: tuple) -> None:
+        sc = ctx["scales"].pop(ckey)
+        self._budget["used"] -= sc.get("bytes", 0)
+        self._budget["evictions"] += 1
+        self._budget["trim"] = True
+
+    def _evict_to_budget(self, keep: tuple) -> None:
+        """Least recently used shape contexts of this engine go until the shared budget holds (never the current one; a sibling's
+        contexts are its own stream's business).  Then, inside the current shape, its least recently used scales."""
+        b = self._budget
+        while b["used"] > b["limit"] and len(self._ctx) > 1:
+            victim = next(k for k in self._ctx if k != keep)
+            self._drop(victim)
+        cur = self._ctx.get(keep)
+        while cur is not None and b["used"] > b["limit"] and len(cur["scales"]) > 1:
+            self._drop_scale(cur, next(iter(cur["scales"])))
 
     def _select(self, shape: tuple, scale) -> dict:
-        """Make (clip shape, scale) the current buffer context; evicts the least recently used ones beyond the caps."""
+        """Make (clip shape, scale) the current buffer context; evicts least recently used ones beyond the byte budget / the count caps."""
         skey = tuple(int(v) for v in shape)
         ctx = self._ctx.get(skey)
-        if ctx is None:
+        fresh = ctx is None
+        if fresh:
             from collections import OrderedDict
-            ctx = dict(bufs={}, scales=OrderedDict())
+            ctx = dict(bufs={}, scales=OrderedDict(), bytes=0)
             self._ctx[skey] = ctx
             while len(self._ctx) > self.max_shapes:
-                self._ctx.popitem(last=False)
+                self._drop(next(iter(self._ctx)))
         else:
             self._ctx.move_to_end(skey)
         ckey = (float(scale[0]), float(scale[1]))
         sc = ctx["scales"].get(ckey)
         if sc is None:
-            sc = dict(bufs={}, graphs=None, chunk=0)        # (a scale context holds one or two HR-sized buffers: exact-size allocations)
+            fresh = True
+            sc = dict(bufs={}, graphs=None, chunk=0, bytes=0)        # (a scale context holds the HR-sized buffers: exact-size allocations)
             ctx["scales"][ckey] = sc
             while len(ctx["scales"]) > self.max_scales:
-                ctx["scales"].popitem(last=False)
+                self._drop_scale(ctx, next(iter(ctx["scales"])))
         else:
             ctx["scales"].move_to_end(ckey)
-        self._cur, self._cur_sc = ctx, sc
+        if fresh:
+            self._evict_to_budget(skey)
+            if self._budget["trim"] and torch.cuda.memory_reserved(self.dev) > self._budget["limit"]:
+                # evicted graphs' pools are only returned by an explicit trim (rare: the budget was exceeded AND the allocator holds more
+                # than the budget); device-synchronous, so never with a capture under way
+                if not torch.cuda.is_current_stream_capturing():
+                    torch.cuda.empty_cache()
+                    self._budget["trim"] = False
+        self._cur, self._cur_sc, self._cur_key = ctx, sc, (skey, ckey)
         return sc
 
     def cache_stats(self) -> dict:
-        n = lambda d: sum(t.numel() * t.element_size() for t in d.values())
+        """Resident contexts of THIS engine; `bytes` = device memory they hold (arena chunks + graph I/O + per-pixel tables), `budget_*` = the
+        account shared with the sibling engines."""
         return {"shapes": len(self._ctx), "scales": sum(len(c["scales"]) for c in self._ctx.values()), "axes": len(self._axes),
-                "bytes": sum(n(c["bufs"]) + sum(n(sc["bufs"]) for sc in c["scales"].values()) for c in self._ctx.values())}
+                "bytes": sum(self._ctx_bytes(c) for c in self._ctx.values()),
+                "budget_used": self._budget["used"], "budget_limit": self._budget["limit"], "evictions": self._budget["evictions"]}
 
     ARENA_CHUNK = 64 << 20      # bytes per arena chunk (larger requests get a chunk of their own)
 
@@ -530,6 +622,7 @@ class HipEngine:
                 arena = owner.setdefault("arena", [])
                 if not arena or arena[-1][1] + nbytes > arena[-1][0].numel():
                     arena.append([torch.empty(max(nbytes, owner.get("chunk", self.ARENA_CHUNK)), device=self.dev, dtype=torch.uint8), 0])
+                    self._charge(owner, arena[-1][0].numel())
                 chunk, off = arena[-1]
                 raw = chunk[off:off + nbytes]
                 arena[-1][1] = off + nbytes
@@ -558,6 +651,21 @@ class HipEngine:
         """End of a context's first frame: the name -> memory assignment is final."""
         self._cur["sealed"] = True
         self._cur.pop("free", None)
+
+    def _abort_frame(self) -> None:
+        """A frame's launch sequence raised (allocation failure, a capture error, ...).  While a shape's buffer plan is still being made (first
+        frame, not sealed) a partly consumed free list would hand live memory to the next new name on a retry -- the plan is all or nothing:
+        the whole shape context goes.  A sealed shape keeps its plan; only the half-built (shape, scale) context is dropped."""
+        if self._cur_key is None:
+            return
+        skey, ckey = self._cur_key
+        ctx = self._ctx.get(skey)
+        if ctx is not None:
+            if not ctx.get("sealed"):
+                self._drop(skey)
+            elif ckey in ctx["scales"] and not ctx["scales"][ckey].get("graphs"):
+                self._drop_scale(ctx, ckey)
+        self._cur, self._cur_sc, self._cur_key = self._default_ctx, self._default_sc, None
 
     def buf(self, name: str, *shape: int) -> torch.Tensor:
         """Named LR-sized buffer of the current clip shape."""
@@ -618,8 +726,28 @@ class HipEngine:
                 if tiles >= (self.wy_min_tiles_tp if d0.algo == _lib.CONV_DIRECT_THROUGHPUT else self.wy_min_tiles):
                     for c in chunk:
                         c.wpacked, c.algo = c._wy, _lib.CONV_WINOGRAD_Y
+            if self.census is not None:      # diagnostics (bench.py): matrix work of this launch, by the form it takes
+                self._count_conv(chunk)
             arr = (ConvDesc * len(chunk))(*chunk)
             _lib.check(self.lib.savsr_conv2d_batch(arr, len(chunk), st), f"savsr_conv2d_batch[{label}]")
+
+    def _count_conv(self, chunk) -> None:
+        """Census of one conv launch for bench.py's matrix-utilisation figures.  `alg` = 2 x MACs of the convs as the reference states them;
+        `issued` = flops of the bf16 MFMAs the launch really executes: 3 split products per MAC in the direct form, 2 in the Winograd F(2,3)-y
+        form (12 taps for two output rows instead of 18), on the padded tile grid -- 32-pixel column blocks, row PAIRS (waves whose rows lie
+        below the image run an MFMA-free body), output channels in blocks of 32 / 64.  For 6 x 128->64 at 180x320 this gives 3.110 M
+        instructions, the count the PMC pass reads (profiles/r04_conv_wy_pmc_summary.csv)."""
+        mode = "tp" if self.conv_algo == _lib.CONV_DIRECT_THROUGHPUT else "b1"
+        c = self.census
+        for d in chunk:
+            taps = d.ksize * d.ksize
+            alg = 2.0 * d.h * d.w * d.cin * d.cout * taps
+            cot = 64 if d.cout > 32 else 32
+            px = (2 * ((d.h + 1) // 2) if d.ksize == 3 else d.h) * (32 * ((d.w + 31) // 32))
+            wy = int(d.algo) == _lib.CONV_WINOGRAD_Y
+            issued = 2.0 * px * d.cin * (cot * ((d.cout + cot - 1) // cot)) * taps * (2.0 if wy else 3.0)
+            for k, v in (("alg_" + mode, alg), ("issued_" + mode, issued), ("direct_eq_" + mode, 3.0 * alg), ("wy_alg_" + mode, alg if wy else 0.0)):
+                c[k] = c.get(k, 0.0) + v
 
     def conv(self, key, srcs: List[Src], out: Src, h: int, w: int, act=ACT_NONE, slope=0.0,
              mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None, pool=None):
@@ -798,7 +926,7 @@ class HipEngine:
                        ih=up(ih.reshape(-1), np.int32), iw=up(iw.reshape(-1), np.int32), gyn=up(gyn, np.float32), gxn=up(gxn, np.float32))
             self._plan_hr_tiling(ent, h, w, scale)
             self._axes[key] = ent
-            while len(self._axes) > max(self.max_shapes, self.max_scales):
+            while len(self._axes) > min(64, max(self.max_shapes, self.max_scales)):      # (live graphs hold their own reference: _forward_graphed)
                 self._axes.popitem(last=False)
         else:
             self._axes.move_to_end(key)
@@ -928,8 +1056,12 @@ class HipEngine:
             pick = lambda k: next((t for t in cands if (t.variant, t.tile_rows, t.tile_cols32) == k), cands[0])
             skey = ("scale", float(scale[0]), float(scale[1]))
             near = self._hr_choice.get(skey)    # (plan, h, w) measured at this scale on another LR size
+            tab = self._hr_table.get((float(scale[0]), float(scale[1])))
             if ckey in self._hr_choice:         # (a sibling engine has timed this size / scale already)
                 ax["tiling_tail"] = pick(self._hr_choice[ckey])
+            elif tab is not None and any((t.variant, t.tile_rows, t.tile_cols32) == tab for t in cands):
+                ax["tiling_tail"] = pick(tab)   # measured for this build of the kernels (savsr_amd/hr_plans.json): nothing to time
+                self._hr_choice[ckey] = tab
             elif near is not None and 0.5 <= (h * w) / float(near[1] * near[2]) <= 2.0 and any((t.variant, t.tile_rows, t.tile_cols32) == near[0] for t in cands):
                 # the folders of a YAML dataset differ by a few rows / columns at one scale (Vid4 x4: 144x180, 144x176, 120x180): the
                 # plan is a function of the scale and the offset range far more than of the size -- one measurement per scale
@@ -986,6 +1118,9 @@ class HipEngine:
         cfg, nf = self.cfg, self.nf
         T, cin, h_in, w_in = lq.shape
         assert T == cfg["num_frame"] and cin == cfg["num_in_ch"] == 3
+        if self.census is not None:
+            k = "frames_tp" if self.conv_algo == _lib.CONV_DIRECT_THROUGHPUT else "frames_b1"
+            self.census[k] = self.census.get(k, 0) + 1
         if h_in < 2 or w_in < 2:
             raise ValueError("SAVSR needs h, w >= 2")
         hp, wp = h_in + (h_in & 1), w_in + (w_in & 1)              # pad_spatial to even (savsr_arch.py:670-690)
@@ -1056,10 +1191,12 @@ class HipEngine:
         self.seal_buffers()                              # the LR buffer plan of this shape is final (align / hfeat / SATU buffers are never shared)
         H, W = get_hw(h_in, w_in, scale)
         plane = self.hr_plane(H, W)
-        d = dict(align=align, hfeat=hfeat, wp=wp, h=h_in, w=w_in, H=H, W=W, plane=plane, p27=self.sbuf("satu.p27", _lib.TAIL_PLANES, plane))
+        d = dict(align=align, hfeat=hfeat, wp=wp, h=h_in, w=w_in, H=H, W=W, plane=plane)
         if self.satu_q:
             d["q9"] = self.sbuf("satu.q9", 9, plane)
             d["seam"] = self.sbuf("satu.seam", self.seam_floats(H, W))
+        else:                # (the 27 planes -- 99.5 MB at 720x1280 -- exist only in the 27-plane form; taps allocate them on demand)
+            d["p27"] = self.sbuf("satu.p27", _lib.TAIL_PLANES, plane)
         return d
 
     def _stage_satu(self, c: dict, scale):
@@ -1093,7 +1230,11 @@ class HipEngine:
     def forward_one(self, lq: torch.Tensor, scale, out: torch.Tensor, taps: Optional[dict] = None):
         """Eager launch sequence.  lq: [T, 3, h, w] fp32 contiguous on device; out: [3, H, W]."""
         self._select(lq.shape, scale)
-        c = self._stage_body(lq, scale)
+        try:
+            c = self._stage_body(lq, scale)
+        except BaseException:
+            self._abort_frame()
+            raise
         if self.satu_events is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -1106,6 +1247,7 @@ class HipEngine:
             taps["h_feat"] = c["hfeat"].t
             taps["satu"] = self._satu_standalone(c, scale)
             if self.satu_q:     # the 27-plane form beside the row-summed one the frame runs (taps only)
+                c["p27"] = self.sbuf("satu.p27", _lib.TAIL_PLANES, c["plane"])
                 self.satu_hr(self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True), c["h"], c["w"], scale, c["p27"], c["plane"], tail_form=True)
             taps["p27"] = c["p27"][:, : c["H"] * c["W"]].view(_lib.TAIL_PLANES, c["H"], c["W"])
         self._stage_tail(c, lq, out)
@@ -1125,6 +1267,11 @@ class HipEngine:
         self.conv_algo = _lib.CONV_DIRECT_THROUGHPUT if throughput else _lib.CONV_DIRECT
         g = sc["graphs"].get(throughput)
         if g is None:
+            used = sc.setdefault("uses", {}).get(throughput, 0)
+            if used < self.capture_after:            # the context's first frames: eager (see capture_after)
+                sc["uses"][throughput] = used + 1
+                self.host_stats["eager_frames"] += 1
+                return self.forward_one(lq, scale, out)
             s_in = torch.empty_like(lq)
             s_out = torch.empty_like(out)
             s_in.copy_(lq)
@@ -1155,16 +1302,26 @@ class HipEngine:
                 _t2 = _time.perf_counter()
                 self._capture(graphs[1], graphs[0].pool(), lambda: self._stage_satu(box["c"], scale))
                 self._capture(graphs[2], graphs[0].pool(), lambda: self._stage_tail(box["c"], s_in, s_out))
+            except BaseException:
+                self._abort_frame()
+                raise
             finally:
                 self.satu_events = ev
+            self._charge(sc, s_in.numel() * 4 + s_out.numel() * 4)
+            _t3 = _time.perf_counter()
+            self.host_stats["captures"] += 1
+            self.host_stats["plan_s"] += _t1 - _t0
+            self.host_stats["capture_s"] += _t3 - _t1
             if os.environ.get("SAVSR_PROFILE_CAPTURE"):
-                _t3 = _time.perf_counter()
                 print(f"[capture] {tuple(lq.shape)} x{scale}: plan {1e3 * (_t1 - _t0):.1f} ms, body {1e3 * (_t2 - _t1):.1f} ms "
                       f"(python launches {1e3 * box.get('t_launch', 0):.1f}), satu+tail {1e3 * (_t3 - _t2):.1f} ms", file=__import__("sys").stderr, flush=True)
             # The captured launches bake in the raw device pointers of this (size, scale)'s SATU tables (phase table, per-pixel
             # expansion, row / column index and coordinate arrays).  Replays never go through satu_axes(), so its LRU neither sees
             # them nor may it free them: the graph tuple owns a reference and the tables live exactly as long as the graph does.
             g = (s_in, s_out, graphs, self.satu_axes(lq.shape[-2], lq.shape[-1], scale))
+            if g[3].get("ptab") is not None and not sc.get("ptab_charged"):
+                self._charge(sc, g[3]["ptab"].numel() * 4)               # (the per-pixel table lives as long as a graph that names it)
+                sc["ptab_charged"] = True
             sc["graphs"][throughput] = g
         s_in, s_out, graphs = g[:3]
         s_in.copy_(lq)

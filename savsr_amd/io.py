@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import os
 import os.path as osp
-from collections import OrderedDict
+from collections import OrderedDict, deque
 from copy import deepcopy
 from typing import List, Optional, Sequence, Tuple, Union
 
@@ -141,6 +141,8 @@ class FrameStore:
         self._shape: Dict[tuple, Tuple[int, int]] = {}                # file key -> (H, W)
         self._lut: Dict[str, torch.Tensor] = {}
         self.stats = {"decoded": 0, "host_hits": 0, "uploaded": 0, "device_hits": 0}
+        self._inflight = 0                                            # decodes submitted to the pool and not settled yet
+        self._pending: "deque[tuple]" = deque()                       # (key, path) requested beyond the in-flight cap, oldest first
 
     @staticmethod
     def _key(path: str) -> tuple:
@@ -168,42 +170,64 @@ class FrameStore:
 
     def _settle(self, k, fut: Future) -> None:
         """A decode has finished (worker thread or the waiting caller, whoever comes first): the array replaces its Future and is
-        counted against SAVSR_DECODE_CACHE_GB; a failed decode is dropped so that the next request tries again."""
+        counted against SAVSR_DECODE_CACHE_GB; a failed decode is dropped so that the next request tries again.  The pool is then topped
+        up from the pending queue."""
         with self._lock:
             if self._host.get(k) is not fut:
                 return
+            self._inflight -= 1
             if fut.cancelled() or fut.exception() is not None:
                 self._host.pop(k, None)
-                return
-            img = fut.result()
-            self._host[k] = img
-            self._host_bytes += img.nbytes
-            self._shape[k] = (int(img.shape[0]), int(img.shape[1]))
-            self._evict_host(k)
+            else:
+                img = fut.result()
+                self._host[k] = img
+                self._host_bytes += img.nbytes
+                self._shape[k] = (int(img.shape[0]), int(img.shape[1]))
+                self._evict_host(k)
+        self._top_up()
 
-    def request(self, paths: Iterable[str]) -> None:
-        """Start decoding `paths` in the background (no-op for files already decoded or in flight).  At most 8 files per worker are in
-        flight: what is beyond that is decoded when it is asked for (host()), so a folder prefetch cannot pile up undecoded work or
-        arrays nobody has counted yet."""
-        for p in paths:
-            k = self._key(p)
-            with self._lock:
+    def _submit(self, k, path: str) -> Future:
+        """(under the lock) One decode into the pool; the caller attaches the done callback outside the lock."""
+        fut = self._pool.submit(self._decode, path)
+        self._host[k] = fut
+        self._inflight += 1
+        return fut
+
+    def _top_up(self) -> None:
+        """Move pending requests into the pool while fewer than 8 decodes per worker are in flight: a folder longer than the cap (100-frame
+        REDS folders, or any folder with few decode threads) keeps the pool full instead of falling back to one file at a time on the
+        consumer thread."""
+        started = []
+        with self._lock:
+            while self._pending and self._inflight < 8 * self.workers:
+                k, p = self._pending.popleft()
                 if k in self._host or self._dev_files.get(k, 0) > 0:
                     continue
-                if sum(1 for v in self._host.values() if isinstance(v, Future)) >= 8 * self.workers:
-                    return
-                fut = self._pool.submit(self._decode, p)
-                self._host[k] = fut
+                started.append((k, self._submit(k, p)))
+        for k, fut in started:
             fut.add_done_callback(lambda f, k=k: self._settle(k, f))
+
+    def request(self, paths: Iterable[str]) -> None:
+        """Start decoding `paths` in the background (no-op for files already decoded, in flight or queued).  At most 8 files per worker
+        are in flight at a time -- undecoded work and arrays nobody has counted yet stay bounded --; the rest waits in a queue that every
+        finished decode tops the pool up from."""
+        with self._lock:
+            queued = {k for k, _ in self._pending}
+            for p in paths:
+                k = self._key(p)
+                if k in self._host or k in queued or self._dev_files.get(k, 0) > 0:
+                    continue
+                self._pending.append((k, p))
+                queued.add(k)
+        self._top_up()
 
     def host(self, path: str) -> np.ndarray:
         """HWC RGB uint8 of one file (blocks until its decode is done; decodes here when nobody requested it)."""
         k = self._key(path)
         with self._lock:
             ent = self._host.get(k)
-            if ent is None:
-                ent = self._pool.submit(self._decode, path)
-                self._host[k] = ent
+            if ent is None:                             # not requested, or still in the pending queue: decode now (the queue entry is skipped later)
+                ent = self._submit(k, path)
             elif not isinstance(ent, Future):
                 self.stats["host_hits"] += 1
                 self._host.move_to_end(k)

@@ -204,7 +204,14 @@ class VideoBaseModel(BaseModel):
             self.gpu_ms = getattr(self, "gpu_ms", 0.0) + sum(a.elapsed_time(b) for a, b in ev)
         if not with_metrics:
             return None
-        allrows = gather_rows(rows, n, rank, world, owners)           # the one collective of the dataset (:108-113)
+        if self.opt.get("emulate_world"):
+            # bench.py --emulate-world: this process runs rank `rank`'s share of a world-size-N run ALONE (no process group) to time it; the
+            # other ranks' rows stay zero and the metric table of such a run means nothing
+            allrows = torch.zeros(n, 2, dtype=rows.dtype, device=rows.device)
+            if len(mine):
+                allrows[torch.as_tensor(list(mine), device=rows.device)] = rows
+        else:
+            allrows = gather_rows(rows, n, rank, world, owners)       # the one collective of the dataset (:108-113)
         cols = [(m, 0 if metrics_opt[m]["type"] == "calculate_psnr" else 1) for m in names]
         self.last_validation = aggregate_rows(allrows, cols, folders_all, dataset_name, self.opt.get("scale"))   # :125-167
         self.metric_results = self.last_validation["frames"]

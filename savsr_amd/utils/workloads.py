@@ -15,6 +15,12 @@ from ..resize_gpu import as_mod_crop_hw
 
 CONFIG3_SCALES: List[Tuple[float, float]] = [(k / 10, k / 10) for k in range(11, 41)]
 
+# the 12 asymmetric pairs the shipped YAMLs test beside the 30 symmetric scales (options/test/SAVSR/test_SAVSR_Vid4_asBI.yml:518-826,
+# the same list in test_SAVSR_UDM10_asBI.yml); with CONFIG3_SCALES = the 42 datasets of a YAML
+VID4_ASYM_SCALES: List[Tuple[float, float]] = [(1.5, 4.0), (2.0, 4.0), (2.0, 3.75), (1.5, 3.5), (1.6, 3.05), (1.7, 3.75),
+                                               (2.95, 3.75), (3.9, 2.0), (3.5, 1.5), (3.5, 2.0), (3.5, 1.75), (4.0, 1.4)]
+YAML_SCALES: List[Tuple[float, float]] = CONFIG3_SCALES + VID4_ASYM_SCALES
+
 CONFIG4_CASES = [((720, 1272), (1.5, 4.0)), ((720, 1272), (3.5, 2.0))]
 
 _SYM = [k / 10 for k in range(11, 41)]

@@ -55,6 +55,20 @@ def test_config3_vid4_sweep_full_size(net, synth_sd, sc, vs_oracle):
         assert err < TOL
 
 
+@pytest.mark.parametrize("sc", workloads.VID4_ASYM_SCALES)
+def test_vid4_asymmetric_yaml_scales_half_size(net, synth_sd, sc):
+    """The 12 asymmetric pairs of the shipped YAMLs (Vid4.yml:518-826), at half the Vid4 LR size (90 x 160) so the suite stays inside the
+    driver's budget; all 42 YAML pairs at 180 x 320 and all 60 training pairs at their sizes: tools/scale_list_sweep.py ->
+    profiles/r05_scale_lists_vs_oracle.log."""
+    lq = synth.synth_clip(7, 3, 90, 160, seed=12)
+    out = _run(net, lq, sc)
+    with torch.no_grad():
+        ref = O.forward(synth_sd, lq, sc)
+    err = float((out - ref).abs().max())
+    print("vid4 asymmetric", sc, "max-abs vs oracle", err)
+    assert err < TOL
+
+
 def test_config3_table_regimes_are_covered():
     """The sweep above really spans the phase-table sizes of the 30-scale list (host arithmetic only)."""
     import numpy as np
@@ -152,6 +166,105 @@ def test_live_graphs_keep_their_satu_tables(synth_sd, monkeypatch):
         for sc in scales:
             n.set_scale(sc)
             assert torch.equal(n(lq.to("cuda:0")).cpu(), first[(h, w, sc)]), (h, w, sc)
+
+
+def _eviction_stream(synth_sd, monkeypatch, env):
+    """A forward_many stream of 12 distinct (shape, scale) pairs, each visited three times in shuffled order, through an engine whose caches are
+    far smaller than the working set: contexts are evicted while the sibling streams replay theirs, and re-captured on the next visit."""
+    import random
+    import savsr_amd
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = savsr_amd.build_network(dict(type="SAVSR")).eval()
+    n.load_state_dict(synth_sd, strict=True)
+    n = n.to("cuda:0")
+    scs = [workloads.TRAIN_SCALES[i] for i in (0, 9, 19, 29, 31, 36, 41, 44, 49, 52, 55, 58)]       # 4 symmetric + 8 asymmetric, x1.1 ... x4
+    pairs = [(22 + 2 * i, 30 + 3 * i, sc) for i, sc in enumerate(scs)]                                # 12 distinct LR shapes (odd widths too)
+    assert len({(h, w) for h, w, _ in pairs}) == 12
+    rng = random.Random(3)
+    visits = []
+    for _ in range(3):
+        order = pairs[:]
+        rng.shuffle(order)
+        visits += order
+    clip = lambda h, w: synth.synth_clip(7, 3, h, w, seed=h * 100 + w)[0]
+    first = {}
+    for i in range(0, len(visits), 6):                                                              # 6 clips per call: 2 per stream
+        chunk = visits[i:i + 6]
+        outs = n.forward_many([clip(h, w).to("cuda:0") for h, w, _ in chunk], [sc for _, _, sc in chunk])
+        torch.cuda.synchronize()
+        for key, o in zip(chunk, outs):
+            o = o.cpu()
+            assert tuple(o.shape) == (3,) + get_hw(key[0], key[1], key[2]) and bool(torch.isfinite(o).all())
+            if key in first:
+                assert torch.equal(first[key], o), ("a re-captured context differs from its first visit", key)
+            first[key] = o
+    return n, pairs, first, clip
+
+
+def test_eviction_by_count_while_sibling_streams_replay(synth_sd, monkeypatch):
+    """SAVSR_CACHE_SHAPES=3 against 12 shapes, 3 streams.  Every output bitwise equal to its first visit, a sample of
+    them against the CPU oracle, and the engines really evicted."""
+    n, pairs, first, clip = _eviction_stream(synth_sd, monkeypatch, {"SAVSR_CACHE_SHAPES": "3", "SAVSR_STREAMS": "3"})
+    eng = n.engine()
+    st = eng.cache_stats()
+    assert st["shapes"] <= 3 and st["evictions"] >= 12, st
+    for h, w, sc in pairs[::4]:
+        with torch.no_grad():
+            ref = O.forward(synth_sd, clip(h, w).unsqueeze(0), sc)
+        err = float((first[(h, w, sc)] - ref[0]).abs().max())
+        print("eviction stream", (h, w), sc, "max-abs vs oracle", err)
+        assert err < TOL
+
+
+def test_eviction_by_byte_budget(synth_sd, monkeypatch):
+    """The byte budget (SAVSR_CACHE_GB, shared by the stream engines) is what evicts by default: 0.2 GB holds two or three of these small
+    contexts (one 64-MiB arena chunk each); same bitwise / oracle checks, and the account never exceeds budget + the context in use."""
+    n, pairs, first, clip = _eviction_stream(synth_sd, monkeypatch, {"SAVSR_CACHE_GB": "0.2", "SAVSR_STREAMS": "3"})
+    eng = n.engine()
+    st = eng.cache_stats()
+    assert st["evictions"] >= 12 and st["budget_limit"] == int(0.2 * (1 << 30)), st
+    per_ctx = 80 << 20                                          # (arena chunk + graph I/O of one small context)
+    assert st["budget_used"] <= st["budget_limit"] + 3 * per_ctx, st
+    total = sum(e.cache_stats()["bytes"] for e in [eng] + eng._siblings)
+    assert total == st["budget_used"], (total, st)
+    h, w, sc = pairs[5]
+    with torch.no_grad():
+        ref = O.forward(synth_sd, clip(h, w).unsqueeze(0), sc)
+    assert float((first[(h, w, sc)] - ref[0]).abs().max()) < TOL
+
+
+def test_failed_first_frame_drops_the_half_made_buffer_plan(synth_sd):
+    """an exception inside a shape's FIRST frame (its buffer liveness plan is being made) must not leave a partly consumed free
+    list behind -- the context is dropped, and the retry equals an undisturbed engine's output bit for bit."""
+    import savsr_amd
+    from savsr_amd import engine as E
+    n = savsr_amd.build_network(dict(type="SAVSR")).eval()
+    n.load_state_dict(synth_sd, strict=True)
+    n = n.to("cuda:0")
+    n.set_scale((2.5, 2.5))
+    lq = synth.synth_clip(7, 3, 30, 44, seed=11).to("cuda:0")
+    eng = n.engine()
+    real = eng.rcab
+    calls = {"n": 0}
+
+    def failing(*a, **k):
+        calls["n"] += 1
+        if calls["n"] == 5:
+            raise RuntimeError("injected failure in the middle of the first frame")
+        return real(*a, **k)
+    eng.rcab = failing
+    with pytest.raises(RuntimeError, match="injected"):
+        n(lq)
+    torch.cuda.synchronize()
+    assert eng.cache_stats()["shapes"] == 0 and eng.cache_stats()["budget_used"] == 0
+    eng.rcab = real
+    out = n(lq).cpu()
+    m = savsr_amd.build_network(dict(type="SAVSR")).eval()
+    m.load_state_dict(synth_sd, strict=True)
+    m = m.to("cuda:0")
+    m.set_scale((2.5, 2.5))
+    assert torch.equal(out, m(lq).cpu())
 
 
 def test_config3_all_30_scales_shape_finite_bitwise(net):

@@ -168,3 +168,36 @@ def test_buffer_liveness_plan_bitwise_and_footprint(synth_sd):
         big[name] = sum(a[1] for a in ctx.get("arena", []))     # bytes bump-allocated for this shape's LR buffers
     print("LR buffer bytes per 180x320 shape: shared %.3f GB, own %.3f GB" % (big["shared"] / 1e9, big["own"] / 1e9))
     assert big["shared"] < 0.45 * big["own"]
+
+
+def test_eager_first_frames_then_capture_bitwise(synth_sd, monkeypatch):
+    """The product default (SAVSR_CAPTURE_AFTER = 4; this suite otherwise sets 0): a (shape, scale) context's first four frames are launched
+    eagerly, the fifth is captured into hipGraphs and replayed from then on -- the same launch sequence either way, so every frame equals the
+    capture-at-once engine's bit for bit, one clip in flight and three (forward_many)."""
+    import savsr_amd
+
+    def build(after):
+        monkeypatch.setenv("SAVSR_CAPTURE_AFTER", after)
+        n = savsr_amd.build_network(dict(type="SAVSR")).eval()
+        n.load_state_dict(synth_sd, strict=True)
+        n = n.to("cuda:0")
+        n.engine()
+        return n
+    lazy, now = build("4"), build("0")
+    assert lazy.engine().capture_after == 4 and now.engine().capture_after == 0
+    h, w, sc = 34, 46, (3.3, 2.5)
+    for n in (lazy, now):
+        n.set_scale(sc)
+    for k in range(7):                                           # frames 0-3 eager, frame 4 captured, 5-6 replayed
+        lq = synth.synth_clip(7, 3, h, w, seed=20 + k).to("cuda:0")
+        assert torch.equal(lazy(lq), now(lq)), k
+    st = lazy.engine().host_stats
+    assert st["eager_frames"] == 4 and st["captures"] == 1, st
+    clips = [synth.synth_clip(7, 3, h, w, seed=40 + k)[0].to("cuda:0") for k in range(18)]
+    for k0 in range(0, 18, 6):                                   # 3 streams x 2 clips per call: each stream's context is visited 6 times
+        a = lazy.forward_many(clips[k0:k0 + 6], [sc] * 6)
+        b = now.forward_many(clips[k0:k0 + 6], [sc] * 6)
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), k0
+    st = lazy.engine().host_stats
+    assert st["eager_frames"] == 4 + 3 * 4 and st["captures"] == 1 + 3, st

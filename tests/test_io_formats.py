@@ -137,6 +137,13 @@ def test_frame_store_host_cap_counts_prefetched_files(tmp_path):
         store.host(bad)                                    # ... and asking for the file raises (again) instead of serving a poisoned entry
     assert store._key(bad) not in store._host
     big = io.FrameStore(host_bytes=1 << 30, device_bytes=1 << 30, workers=1)
-    big.request(paths)                                     # at most 8 per worker in flight; the rest is decoded on demand
-    assert len(big._host) <= 8
-    assert all(big.host(p).shape == (32, 48, 3) for p in paths)
+    big.request(paths)                                     # at most 8 per worker in flight; the rest waits in the queue ...
+    assert big._inflight <= 8 and len(big._host) <= 8
+    for _ in range(500):                                   # ... and is decoded BY THE POOL as decodes finish: nobody calls host() here
+        if big.stats["decoded"] == len(paths) and big._inflight == 0:
+            break
+        time.sleep(0.01)
+    assert big.stats["decoded"] == len(paths) and not big._pending and big._inflight == 0
+    assert all(big.host(p).shape == (32, 48, 3) for p in paths) and big.stats["decoded"] == len(paths)      # all host hits
+    big.request(paths)                                     # already decoded: nothing queued
+    assert not big._pending and big._inflight == 0
