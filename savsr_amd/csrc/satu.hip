@@ -133,6 +133,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, const void* lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+// LDS-DMA with a SCALAR 64-bit base + a 32-bit per-lane byte offset (no per-piece 64-bit VGPR address: the LR kernel has no register to spare --
+// 254 -> 243 VGPRs, and the standalone form no longer spills).
+__device__ __forceinline__ void glds16_sbase(const void* sbase, unsigned voff, const void* lds_dst) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
+    const unsigned long long sb = (unsigned long long)(uintptr_t)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb), hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"((((unsigned long long)hi) << 32) | lo), "s"(dst) : "memory");
+}
+
 // ------------------------------------------------------------------------------------------
 // LR stage, STREAMING form (round 3).  Same arithmetic, same tile, same LDS image as the round-2 kernel (satu_lr_kernel, archived as
 // tools/experiments/satu_lr_round2_kernel.patch) -- what changed is where the per-phase barrier sits.  There, a phase was [5 DMAs | first fragment
@@ -177,13 +188,14 @@ __global__ __launch_bounds__(512, 2) void satu_lr_stream_kernel(const LrParams p
     // straight-line MFMA groups of tap 4 into basic blocks the scheduler cannot interleave): the LDS destination has the same
     // form for slabs and projection pieces (LR_SLAB = 8 x 64 units), and where there is nothing to fetch (q == 10 beyond the
     // image, q == 11) the piece re-fetches slab bytes of phase 9 into a buffer nobody reads any more.
+    const unsigned dma_voff = (unsigned)((wave * 64 + lane) * 16);     // this lane's 16 B inside a 8-KiB slab / projection piece
     auto dma_piece = [&](int q, int b, int i) {
         const int qs = q < 10 ? q : 9;
         const int cg = qs >= 5 ? 1 : 0, ky = qs - 5 * cg;
-        const bf16x8* src = kw + (long long)((ky * 5 + i) * 2 + cg) * LR_SLAB + wave * 64 + lane;
-        const bf16x8* prj = reinterpret_cast<const bf16x8*>(p.wt.proj_w) + (i * 8 + wave) * 64 + lane;
+        const bf16x8* src = kw + (long long)((ky * 5 + i) * 2 + cg) * LR_SLAB;            // (wave-uniform: scalar arithmetic)
+        const bf16x8* prj = reinterpret_cast<const bf16x8*>(p.wt.proj_w) + i * 8 * 64;
         if (i < 2 * NB + 1) src = q == 10 ? prj : src;               // (a select; i is a compile-time constant at every call site)
-        glds16(src, wbuf + b * LR_PHASE + i * LR_SLAB + wave * 64);
+        glds16_sbase(src, dma_voff, wbuf + b * LR_PHASE + i * LR_SLAB + wave * 64);
     };
     constexpr int XT_IT = (LR_NPX * 8 + 511) / 512;                    // 7 float4 per thread
     f32x4 xv[XT_IT];

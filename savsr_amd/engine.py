@@ -83,13 +83,38 @@ def conv_pack_index(cout: int, cin: int, ks: int):
     return _PACK_IDX_CACHE[key]
 
 
-def pack_conv_part(w: torch.Tensor) -> torch.Tensor:
-    """[cout, cin, k, k] -> fp32 CPU tensor of one image part (zero padded), lane order."""
+_IDX_DEV_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def _index_on(kind: str, key: tuple, idx: np.ndarray, device: torch.device) -> torch.Tensor:
+    """The (cached) index map of a weight-image layout as a tensor on `device`."""
+    k = (kind, key, str(device))
+    t = _IDX_DEV_CACHE.get(k)
+    if t is None:
+        t = torch.from_numpy(idx).to(device)
+        _IDX_DEV_CACHE[k] = t
+    return t
+
+
+def _scatter_image(idx: np.ndarray, total: int, values: torch.Tensor, kind: str, key: tuple, device: Optional[torch.device]) -> torch.Tensor:
+    """zeros[total] with values scattered to idx: numpy on the host, one index_put on a GPU (round 5: the engine packs its ~190 conv
+    images and 12 OSConv banks ON THE DEVICE -- 1.7 s of host scatter / split work per process became a few ms; a rank of an 8-GPU run of
+    a YAML spends 2-7 s on the GPU in all).  Pure data movement + RNE conversions: bit-identical either way
+    (tests/test_gpu_kernels.py::test_weight_images_packed_on_device_equal_host_packing)."""
+    if device is None or device.type == "cpu":
+        out = np.zeros(total, dtype=np.float32)
+        out[idx] = values.detach().to("cpu", torch.float32).contiguous().numpy().reshape(-1)
+        return torch.from_numpy(out)
+    out = torch.zeros(total, dtype=torch.float32, device=device)
+    out[_index_on(kind, key, idx, device)] = values.detach().to(device, torch.float32).reshape(-1)
+    return out
+
+
+def pack_conv_part(w: torch.Tensor, device: Optional[torch.device] = None) -> torch.Tensor:
+    """[cout, cin, k, k] -> fp32 tensor of one image part (zero padded), lane order; on `device` (default: host)."""
     cout, cin, ks, _ = w.shape
     idx, total = conv_pack_index(cout, cin, ks)
-    out = np.zeros(total, dtype=np.float32)
-    out[idx] = w.detach().to("cpu", torch.float32).contiguous().numpy().reshape(-1)
-    return torch.from_numpy(out)
+    return _scatter_image(idx, total, w, "direct", (cout, cin, ks), device)
 
 
 def split_bf16_image(part: torch.Tensor) -> torch.Tensor:
@@ -100,9 +125,9 @@ def split_bf16_image(part: torch.Tensor) -> torch.Tensor:
     return img.view(torch.int16).reshape(-1)
 
 
-def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
-    """[cout, cin, k, k] -> split-bf16 weight image (int16 CPU tensor) for savsr_conv2d."""
-    return split_bf16_image(pack_conv_part(w))
+def pack_conv_weight(w: torch.Tensor, device: Optional[torch.device] = None) -> torch.Tensor:
+    """[cout, cin, k, k] -> split-bf16 weight image (int16 tensor) for savsr_conv2d."""
+    return split_bf16_image(pack_conv_part(w, device))
 
 
 _WY_IDX_CACHE: Dict[tuple, tuple] = {}
@@ -132,17 +157,17 @@ def conv_wy_pack_index(cout: int, cin: int):
     return _WY_IDX_CACHE[key]
 
 
-def pack_conv_weight_wy(w: torch.Tensor) -> torch.Tensor:
+def pack_conv_weight_wy(w: torch.Tensor, device: Optional[torch.device] = None) -> torch.Tensor:
     """[cout, cin, 3, 3] -> split-bf16 Winograd-y weight image (SAVSR_CONV_WINOGRAD_Y): the F(2,3) weight transform over the tap ROWS
     g_ky in float64 -- U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2, per kx -- rounded to fp32, then (hi, lo)."""
     cout, cin, ks, _ = w.shape
     assert ks == 3
-    g = w.detach().to("cpu", torch.float64).numpy()                       # [co][ci][ky][kx]
-    u = np.stack([g[:, :, 0], 0.5 * (g[:, :, 0] + g[:, :, 1] + g[:, :, 2]), 0.5 * (g[:, :, 0] - g[:, :, 1] + g[:, :, 2]), g[:, :, 2]], 0)   # [pos][co][ci][kx]
+    dev = device if device is not None and device.type != "cpu" else torch.device("cpu")
+    g = w.detach().to(dev, torch.float64)                                  # [co][ci][ky][kx]
+    g0, g1, g2 = g[:, :, 0], g[:, :, 1], g[:, :, 2]
+    u = torch.stack([g0, 0.5 * (g0 + g1 + g2), 0.5 * (g0 - g1 + g2), g2], 0).to(torch.float32)      # [pos][co][ci][kx]
     idx, total = conv_wy_pack_index(cout, cin)
-    part = np.zeros(total, dtype=np.float32)
-    part[idx] = u.astype(np.float32).reshape(-1)
-    return split_bf16_image(torch.from_numpy(part))
+    return split_bf16_image(_scatter_image(idx, total, u, "wy", (cout, cin), device))
 
 
 def acc_row(r: int, half: int) -> int:
@@ -186,12 +211,14 @@ class HipEngine:
         self._keep: List[torch.Tensor] = []
         self._init_caches()
         self.satu_events: Optional[list] = None     # bench.py: (start, end) HIP events around SATU
+        self._st: Optional[int] = None              # cached stream handle while a frame's launches are being issued (_stream)
         self.census: Optional[dict] = None          # bench.py: per-launch matrix-work census (_count_conv), shared with the sibling engines
-        # A (shape, scale) context's first frames run EAGERLY and the hipGraphs are captured on visit SAVSR_CAPTURE_AFTER + 1: a capture costs
-        # ~5 ms of host time with the GPU idle and only pays back over replays (steadier launch timing beside decode threads and the GIL) --
-        # a rank's block of a YAML folder at world size 8 is 4-6 frames, for which eager launches (~330 x 11 us of host time under an 8 ms
-        # GPU frame) are simply faster.  Eager, captured and replayed frames are the same launch sequence: bit-identical results.
-        self.capture_after = max(0, int(os.environ.get("SAVSR_CAPTURE_AFTER", "4")))
+        # SAVSR_CAPTURE_AFTER = n: a (shape, scale) context's first n frames run EAGERLY and the hipGraphs are captured on visit n + 1 (eager,
+        # captured and replayed frames are the same launch sequence: bit-identical results).  Default 0 = capture on the first visit, by
+        # measurement (bench.py --config run_test --emulate-world 8, cProfile of a rank's cold pass): the Python launch sequence of one frame costs
+        # ~8 ms of host time -- more than the 4-5 ms the GPU needs for a Vid4-sized frame -- and a capture is that same sequence issued once, so
+        # eager frames are host-bound and a block of >= 3 frames is already faster captured (8 + 4.5 n against 8 n ms).
+        self.capture_after = max(0, int(os.environ.get("SAVSR_CAPTURE_AFTER", "0")))
         self.host_stats = {"captures": 0, "capture_s": 0.0, "plan_s": 0.0, "eager_frames": 0}     # shared with the sibling engines (bench.py)
         self.conv_algo = _lib.CONV_DIRECT           # CONV_DIRECT_THROUGHPUT while several clips are in flight (forward_many / batches)
         self._hr_choice: Dict[tuple, int] = {}      # (h, w, sh, sw) -> timed choice of the HR kernel's wave split; shared with the sibling engines
@@ -230,7 +257,8 @@ class HipEngine:
                 t = json.load(f)
             if t.get("satu_source_hash") != self.lib.savsr_source_hash_satu().decode():
                 return {}
-            return {tuple(float(v) for v in k.split(",")): tuple(int(x) for x in p) for k, p in t.get("plans", {}).items()}
+            # entry: [variant, tile rows, tile columns / 32, LR h, LR w of the measurement]
+            return {tuple(float(v) for v in k.split(",")): (tuple(int(x) for x in p[:3]), int(p[3]), int(p[4])) for k, p in t.get("plans", {}).items() if len(p) >= 5}
         except (OSError, ValueError, AttributeError):
             return {}
 
@@ -254,11 +282,12 @@ class HipEngine:
     def _register(self, key: str, w: torch.Tensor, b: Optional[torch.Tensor]):
         cout, cin, ks, _ = w.shape
         bias = None if b is None else self._dev(b)
-        self.pw[key] = (self._dev(pack_conv_weight(w), torch.int16), bias, cout, cin, ks)
+        wd = w.to(self.dev)                                  # (the images are built on the device: _scatter_image)
+        self.pw[key] = (self._dev(pack_conv_weight(wd, self.dev), torch.int16), bias, cout, cin, ks)
         if self.conv_wy and ks == 3 and cout % 64 == 0 and cin % 16 == 0:
             # static 3x3 weights also as the Winograd F(2,3)-along-y image (conv_wy.hip: 2/3 of the matrix work); which form a launch takes is
             # decided per launch in conv_launch (the 16-row Winograd tiles need a launch that fills the chip)
-            self.pw_wy[key] = self._dev(pack_conv_weight_wy(w), torch.int16)
+            self.pw_wy[key] = self._dev(pack_conv_weight_wy(wd, self.dev), torch.int16)
 
     def _add_conv(self, sd, key: str, bn: Optional[str] = None):
         w, b = self._fold(sd, key, bn)
@@ -276,9 +305,9 @@ class HipEngine:
         self._register(d + ".win", w, torch.cat([bc, bs]))
 
     def _add_osconv(self, sd, key: str):
-        bank = sd[key + ".weight"].to("cpu", torch.float32)       # [K, cout, cin, 3, 3]
+        bank = sd[key + ".weight"].to(self.dev, torch.float32)    # [K, cout, cin, 3, 3]
         knum, cout, cin = bank.shape[:3]
-        packed = torch.stack([pack_conv_part(bank[k]) for k in range(knum)], 0)
+        packed = torch.stack([pack_conv_part(bank[k], self.dev) for k in range(knum)], 0)
         a = key + ".attention"
         bn_s = sd[a + ".bn.weight"].cpu() / torch.sqrt(sd[a + ".bn.running_var"].cpu() + BN_EPS)
         bn_b = sd[a + ".bn.bias"].cpu() - sd[a + ".bn.running_mean"].cpu() * bn_s
@@ -485,7 +514,7 @@ class HipEngine:
         e.se_gate = torch.empty_like(self.se_gate)
         e._init_caches()
         e.max_shapes, e.max_scales, e._budget = self.max_shapes, self.max_scales, self._budget
-        e.satu_events, e.use_graphs, e.census = None, self.use_graphs, self.census
+        e.satu_events, e.use_graphs, e.census, e._st = None, self.use_graphs, self.census, None
         e.capture_after, e.host_stats = self.capture_after, self.host_stats
         e.conv_algo = _lib.CONV_DIRECT
         e._hr_choice, e._hr_table = self._hr_choice, self._hr_table
@@ -675,9 +704,22 @@ class HipEngine:
         """Named buffer whose size depends on the scale (HR-sized), owned by the current (shape, scale) context."""
         return self._get_buf(self._cur_sc, name, shape)
 
-    @staticmethod
-    def _stream() -> int:
-        return torch.cuda.current_stream().cuda_stream
+    def _stream(self) -> int:
+        """Raw handle of the current HIP stream.  Inside a frame's stage functions it is looked up once (`_stage_stream`): ~330 launches per
+        frame asked torch for it ~190 times each 9 us -- a fifth of an eager or capturing frame's host time."""
+        st = self._st
+        return st if st is not None else torch.cuda.current_stream().cuda_stream
+
+    class _StageStream:
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            self.prev = self.eng._st
+            self.eng._st = torch.cuda.current_stream().cuda_stream
+
+        def __exit__(self, *a):
+            self.eng._st = self.prev
 
     @staticmethod
     def full(t: torch.Tensor, ch: Optional[int] = None, ch_off: int = 0) -> Src:
@@ -955,13 +997,13 @@ class HipEngine:
             ent["table"] = torch.empty(n_table * _lib.SATU_TABLE, device=self.dev)
             ent["table"].record_stream(cur)
             _lib.check(self.lib.savsr_satu_phase_table(sw, ent["uh"].data_ptr(), ent["n_uh"], ent["uw"].data_ptr(), ent["n_uw"],
-                                                       1.0 / scale[1], 1.0 / scale[0], ent["table"].data_ptr(), self._stream()),
+                                                       1.0 / scale[1], 1.0 / scale[0], ent["table"].data_ptr(), self._side_stream.cuda_stream),
                        "savsr_satu_phase_table")
             if n_table > self.HR_TABLE_LDS:
                 ent["ptab"] = torch.empty(ent["H"] * ent["W"] * _lib.SATU_TABLE, device=self.dev)     # the table per HR pixel, offsets normalised
                 ent["ptab"].record_stream(cur)
                 _lib.check(self.lib.savsr_satu_expand_table(ent["table"].data_ptr(), ent["n_uw"], ent["ih"].data_ptr(), ent["iw"].data_ptr(), h, w,
-                                                            ent["H"], ent["W"], ent["ptab"].data_ptr(), self._stream()), "savsr_satu_expand_table")
+                                                            ent["H"], ent["W"], ent["ptab"].data_ptr(), self._side_stream.cuda_stream), "savsr_satu_expand_table")
             tab = ent["table"].view(-1, _lib.SATU_TABLE).cpu().numpy()   # waits for the side stream only
         cur.wait_stream(self._side_stream)
         ox = np.concatenate([tab[:, 4], tab[:, 6]])
@@ -1059,9 +1101,13 @@ class HipEngine:
             tab = self._hr_table.get((float(scale[0]), float(scale[1])))
             if ckey in self._hr_choice:         # (a sibling engine has timed this size / scale already)
                 ax["tiling_tail"] = pick(self._hr_choice[ckey])
-            elif tab is not None and any((t.variant, t.tile_rows, t.tile_cols32) == tab for t in cands):
-                ax["tiling_tail"] = pick(tab)   # measured for this build of the kernels (savsr_amd/hr_plans.json): nothing to time
-                self._hr_choice[ckey] = tab
+            elif tab is not None and 0.5 <= (h * w) / float(tab[1] * tab[2]) <= 2.0 and any((t.variant, t.tile_rows, t.tile_cols32) == tab[0] for t in cands):
+                # measured for this build of the kernels at a comparable LR size (savsr_amd/hr_plans.json): nothing to time.  (A plan is a
+                # function of the scale AND of how many tiles the image gives the 256 CUs: the x(3.5, 2) plan of a 180x320 frame ran a 204x636
+                # frame's HR stage in 60.5 instead of 48.7 us, and a 64x112 frame has 91 tiles of 20 rows x 64 px -- outside 0.5 ... 2 x the
+                # measured pixel count the engine measures, as before.)
+                ax["tiling_tail"] = pick(tab[0])
+                self._hr_choice[ckey] = tab[0]
             elif near is not None and 0.5 <= (h * w) / float(near[1] * near[2]) <= 2.0 and any((t.variant, t.tile_rows, t.tile_cols32) == near[0] for t in cands):
                 # the folders of a YAML dataset differ by a few rows / columns at one scale (Vid4 x4: 144x180, 144x176, 120x180): the
                 # plan is a function of the scale and the offset range far more than of the size -- one measurement per scale
@@ -1114,6 +1160,10 @@ class HipEngine:
 
     # ------------------------------------------------------------------ whole frame
     def _stage_body(self, lq: torch.Tensor, scale) -> dict:
+        with HipEngine._StageStream(self):
+            return self._stage_body_impl(lq, scale)
+
+    def _stage_body_impl(self, lq: torch.Tensor, scale) -> dict:
         """Everything up to the SATU inputs (savsr_arch.py:692-734).  lq: [T, 3, h, w] on device."""
         cfg, nf = self.cfg, self.nf
         T, cin, h_in, w_in = lq.shape
@@ -1200,6 +1250,10 @@ class HipEngine:
         return d
 
     def _stage_satu(self, c: dict, scale):
+        with HipEngine._StageStream(self):
+            return self._stage_satu_impl(c, scale)
+
+    def _stage_satu_impl(self, c: dict, scale):
         """SATU in the tail-projected form (savsr_arch.py:315-376 with the channel contraction of :738 folded in): -> P [27][H][W]."""
         if self.satu_q:        # row-summed form: the HR stage adds the horizontal taps itself -> 9 planes + seams
             lrcat = self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True, q=True)
@@ -1209,6 +1263,10 @@ class HipEngine:
         self.satu_hr(lrcat, c["h"], c["w"], scale, c["p27"], c["plane"], tail_form=True)
 
     def _stage_tail(self, c: dict, lq: torch.Tensor, out: torch.Tensor):
+        with HipEngine._StageStream(self):
+            return self._stage_tail_impl(c, lq, out)
+
+    def _stage_tail_impl(self, c: dict, lq: torch.Tensor, out: torch.Tensor):
         """What is left of :738-739: the nine shifted taps per colour, the tail bias, the bilinear residual."""
         cfg = self.cfg
         T = lq.shape[0]

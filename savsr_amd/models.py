@@ -228,7 +228,8 @@ class ASVSRModel(VideoBaseModel):
     def test(self):
         net = self.net_g.module if hasattr(self.net_g, "module") else self.net_g
         net.set_scale(self.opt["scale"])
-        net.eval()
+        if net.training:                         # (asvsr_model.py:58 calls eval() per frame; the recursive walk over ~300 modules costs 3 ms a time)
+            net.eval()
         with torch.no_grad():
             self.output = self.net_g(self.lq)
 

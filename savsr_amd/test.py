@@ -68,7 +68,7 @@ def run_test(opt: Union[str, dict], root_path: str = ".", model=None) -> List[di
             new_ckpt, old_ckpt = opt.get("path", {}).get("pretrain_network_g"), model.opt.get("path", {}).get("pretrain_network_g")
             if new_ckpt is not None and new_ckpt != old_ckpt:
                 raise ValueError("run_test(opt, model=...): opt['path']['pretrain_network_g'] differs from the checkpoint the model loaded")
-            for key in ("val", "name"):
+            for key in ("val", "name", "emulate_world"):
                 if key in opt:
                     model.opt[key] = opt[key]
             if "path" in opt:

@@ -679,3 +679,20 @@ def test_pack_windows_reflect_pad(eng):
         t = q + 1
         ref = torch.cat([padded[t], padded[t - 1], padded[t + 1], torch.zeros(7, 8, 10)], 0)
         assert torch.equal(pl(o[q]), ref)
+
+
+def test_weight_images_packed_on_device_equal_host_packing(synth_sd):
+    """The engine builds its weight images on the GPU (engine._scatter_image: index_put + RNE conversions, the Winograd-y transform in
+    float64): bit for bit the host packing that the kernel tests above feed the same kernels with."""
+    from savsr_amd import engine as E
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    for cout, cin, ks in ((64, 64, 3), (64, 128, 3), (128, 16, 3), (64, 192, 1), (3, 64, 3), (16, 64, 3), (64, 320, 3)):
+        w = torch.randn(cout, cin, ks, ks, generator=g) * 0.1
+        assert torch.equal(E.pack_conv_weight(w, dev).cpu(), E.pack_conv_weight(w))
+        assert torch.equal(E.pack_conv_part(w, dev).cpu(), E.pack_conv_part(w))
+        if ks == 3 and cout % 64 == 0 and cin % 16 == 0:
+            assert torch.equal(E.pack_conv_weight_wy(w, dev).cpu(), E.pack_conv_weight_wy(w))
+    bank = synth_sd["f2p_win.blocks.1.osconv.weight"]
+    assert torch.equal(torch.stack([E.pack_conv_part(bank[k].to(dev), dev) for k in range(bank.shape[0])], 0).cpu(),
+                       torch.stack([E.pack_conv_part(bank[k]) for k in range(bank.shape[0])], 0))

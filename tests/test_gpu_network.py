@@ -171,8 +171,8 @@ def test_buffer_liveness_plan_bitwise_and_footprint(synth_sd):
 
 
 def test_eager_first_frames_then_capture_bitwise(synth_sd, monkeypatch):
-    """The product default (SAVSR_CAPTURE_AFTER = 4; this suite otherwise sets 0): a (shape, scale) context's first four frames are launched
-    eagerly, the fifth is captured into hipGraphs and replayed from then on -- the same launch sequence either way, so every frame equals the
+    """SAVSR_CAPTURE_AFTER = 4 (default 0 = capture on the first visit): a (shape, scale) context's first four frames are launched eagerly, the
+    fifth is captured into hipGraphs and replayed from then on -- the same launch sequence either way, so every frame equals the
     capture-at-once engine's bit for bit, one clip in flight and three (forward_many)."""
     import savsr_amd
 

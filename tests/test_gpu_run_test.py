@@ -334,3 +334,25 @@ def test_bench_two_ranks_share_the_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"] == "clip-sharded dp2"
     assert abs(d["value"] - 2 * 2 * 3 * 0.9216 / (d["ms_per_step"] * 2 / 1e3)) < 0.05 * d["value"]      # whole-job: all ranks' clips / max time
+
+
+def test_bench_emulate_world_predicts_strong_scaling():
+    """`bench.py --config run_test --emulate-world 2`: the whole job and both ranks of a world-size-2 run of the YAML flow, each in a fresh child
+    process on the one GPU over one PNG tree; one JSON line with the predicted strong-scaling efficiency and where a rank's cold pass goes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "run_test", "--emulate-world", "2", "--frames-per-folder", "4"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["bench_config"] == "run_test --emulate-world" and d["emulated_world"] == 2 and d["n_gpus"] == 1
+    assert d["world1"]["frames"] == 4 * 4 * 6 and [x["frames"] for x in d["ranks"]] == [4 * 2 * 6, 4 * 2 * 6]
+    for k in ("predicted_strong_scaling_eff_cold", "predicted_strong_scaling_eff_steady"):
+        assert 0.05 < d[k] < 1.3, (k, d[k])
+    loss = d["loss_breakdown_cold_slowest_rank"]
+    assert loss["captures"] >= 1 and loss["rank_wall_s"] > 0 and loss["png_decoded"] >= 8

@@ -32,6 +32,9 @@ constexpr int D_NPX = 18 * IC, D_BPART = 2 * D_NPX, D_BUNITS = 2 * D_BPART, D_WU
 // MODE 1 geometry
 constexpr int W_VWAVE = 2 * 2 * 2 * 2 * IC;      // [half][row in half][part][q][px] units per wave = 544
 constexpr int W_WHALF = 2 * 3 * 2 * 2 * 64;      // [pos in half][kx][t][part][lane] = 1536 units = 24 KB
+// MODE 3 geometry (F(4,3) along y)
+constexpr int F_VQUAD = 2 * 3 * 2 * 2 * IC;      // [half][pos in half][part][q][px] units per row QUAD = 816 (13 KB); 4 quads per workgroup
+constexpr int F_WHALF = 3 * 3 * 2 * 2 * 64;      // [pos in half][kx][t][part][lane] = 2304 units = 36.9 KB
 
 __device__ __forceinline__ void dma1k(const void* src_lane, unsigned lds_wave_base) {
     unsigned keep;
@@ -258,6 +261,112 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ act, long lon
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int r = 0; r < 2; ++r) for (int t = 0; t < 2; ++t) for (int i = 0; i < 16; ++i) sum += acc[r][t][i];
         for (int i = 0; i < B_IT; ++i) sum += breg[i][0];
+    } else if (MODE == 3) {
+        // Winograd F(4,3) ALONG Y (round 5 costing).  6 positions x 3 kx = 18 taps for FOUR output rows (direct 36, F(2,3) 24).
+        // A wave cannot own a row quad with all 64 output channels (6 positions x 2 channel blocks x 16 = 192 accumulator registers), so
+        // wave = (row quad = wave / 2, 32-channel block = wave % 2): 6 accumulators (96 registers), 54 MFMAs per wave and phase for the same
+        // 16-row x 32-px x 64-channel tile.  The two waves of a quad SHARE the quad's transformed rows V0..V5 (each builds half of the 136
+        // (px, channel quad) columns); the two barriers per phase that publish the weight halves publish the V halves too (positions {0,1,2}
+        // are rewritten while {3,4,5} are read and vice versa, as in MODE 1).  Weights 18 taps = 73.7 KB per phase in two halves of 36.9 KB.
+        // Per step (position, kx): 2 A + 2 B fragment reads -> 3 MFMAs.  Staging per lane and phase: 7 float4 loads (6 rows of one column +
+        // the tail), ~56 transform + 72 split VALU, 12 ds_write_b64; 9 (waves 0-3) or 8 weight DMAs of 1 KiB per wave (F(2,3): 6).
+        f32x16 acc[6];
+        for (int p = 0; p < 6; ++p) for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
+        f32x4 d[6];                                               // rows d0..d5 of this lane's (px, quad) column
+        f32x4 dx;                                                 // tail: the last 4 columns x 6 rows of this wave's share, one (row, column) per lane < 24
+        const int quad = wave >> 1, cob = wave & 1;
+        bf16x8* vbase = lds + quad * F_VQUAD;                     // [hf][pos][part][q][px]
+        bf16x8* wbase = lds + 4 * F_VQUAD;                        // [hf][2304]
+        for (int i = tid; i < 4 * F_VQUAD + 2 * F_WHALF; i += 512) lds[i] = wts[i & 8191];
+        __syncthreads();
+        struct Frag { bf16x8 ah, al, bh, bl; } f[2];
+        auto load_frag = [&](int hf, int s, Frag& fr) {           // s = pos-in-half * 3 + kx
+            const int pr = s / 3, kx = s - 3 * pr;
+            const bf16x8* bb = vbase + ((hf * 3 + pr) * 2 * 2 + half) * IC + px + kx;
+            fr.bh = bb[0];
+            fr.bl = bb[2 * IC];
+            const bf16x8* ab = wbase + hf * F_WHALF + s * 256 + lane;
+            fr.ah = ab[(cob * 2 + 0) * 64];
+            fr.al = ab[(cob * 2 + 1) * 64];
+        };
+        const int col0 = cob * 68 + lane;                         // this lane's column of the quad's 136 (px, channel quad) columns
+        auto issue_d = [&](int row, int ph) {                     // row 0..5: one float4 per lane; row 6: the tail item
+            if (X & 8) { if (row == 6) { asm volatile("" : "+v"(dx)); } else { asm volatile("" : "+v"(d[row])); } return; }
+            if (row == 6) {
+                const int r = lane >> 2, col = cob * 68 + 64 + (lane & 3);
+                const long long off = wg_base + (long long)ph * 16384 + ((4 * quad + (r < 6 ? r : 0)) * IC + (col >> 2)) * 16 + (col & 3) * 4;
+                dx = *(const GLOBAL f32x4*)((const GLOBAL float*)act + off);
+                return;
+            }
+            const long long off = wg_base + (long long)ph * 16384 + ((4 * quad + row) * IC + (col0 >> 2)) * 16 + (col0 & 3) * 4;
+            d[row] = *(const GLOBAL f32x4*)((const GLOBAL float*)act + off);
+        };
+        // transform + split + store of position pr (0..2) of half hf from the six rows in registers
+        auto store_v = [&](int pr, int hf) {
+            f32x4 v;
+            if (X & 1) v = d[hf * 3 + pr];
+            else if (hf == 0) v = pr == 0 ? 4.f * d[0] - 5.f * d[2] + d[4] : (pr == 1 ? (d[4] - 4.f * d[2]) + (d[3] - 4.f * d[1]) : (d[4] - 4.f * d[2]) - (d[3] - 4.f * d[1]));
+            else v = pr == 0 ? (d[4] - d[2]) + 2.f * (d[3] - d[1]) : (pr == 1 ? (d[4] - d[2]) - 2.f * (d[3] - d[1]) : 4.f * d[1] - 5.f * d[3] + d[5]);
+            const int pxl = col0 >> 2, c8 = col0 & 3, q = c8 >> 1, sub = c8 & 1;
+            bf16x4* dst = reinterpret_cast<bf16x4*>(vbase + ((hf * 3 + pr) * 2 * 2 + q) * IC + pxl) + sub;
+            split_store<X>(v, dst, dst + 2 * IC * 2);
+        };
+        auto store_tail = [&](int hf) {                           // the 4 tail columns: rows sit 4 lanes apart; three shuffles + adds stand in for the row combination
+            f32x4 o1, o2, o3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o1[j] = __shfl_xor(dx[j], 4, 64); o2[j] = __shfl_xor(dx[j], 8, 64); o3[j] = __shfl_xor(dx[j], 16, 64); }
+            const f32x4 v = (lane & 4) ? (dx - 4.f * o1) + (o2 - 4.f * o3) : 4.f * dx - 5.f * o2 + o3;
+            if (lane < 12) {
+                const int col = cob * 68 + 64 + (lane & 3), pxl = col >> 2, c8 = col & 3, q = c8 >> 1, sub = c8 & 1;
+                bf16x4* dst = reinterpret_cast<bf16x4*>(vbase + ((hf * 3 + (lane >> 2)) * 2 * 2 + q) * IC + pxl) + sub;
+                split_store<X>(v, dst, dst + 2 * IC * 2);
+            }
+        };
+        auto issue_w = [&](int g, int hf, int ph) {              // 36 pieces of 1 KiB per half: waves 0-3 five, waves 4-7 four
+            if (!(X & 2) && g * 8 + wave_s < 36)
+                dma1k(wts + ((ph & 7) * 512 + hf * 2304 + (g * 8 + wave_s) * 64 + lane) % 8192, (unsigned)(uintptr_t)(wbase + hf * F_WHALF + (g * 8 + wave_s) * 64));
+        };
+#pragma unroll
+        for (int r = 0; r < 7; ++r) issue_d(r, 0);
+        load_frag(0, 0, f[0]);
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int ph = 0; ph < phases; ++ph) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    if (s == 8) {                                 // the other half's weights and V rows are published
+                        if (hf == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               // six row loads of the next-but-one phase are younger than the last DMA
+                        __syncthreads();
+                    }
+                    if (X & 4) { asm volatile("" : "+v"(f[(s + 1) & 1].ah), "+v"(f[(s + 1) & 1].bh)); }
+                    else if (s + 1 < 9) load_frag(hf, s + 1, f[(s + 1) & 1]); else load_frag(hf ^ 1, 0, f[(s + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const Frag& fr = f[s & 1];
+                    const int p = hf * 3 + s / 3;
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.al, fr.bh, acc[p], 0, 0, 0);
+                    if (s >= 1 && s < 4) store_v(s - 1, hf ^ 1);
+                    if (s == 4) store_tail(hf ^ 1);
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.ah, fr.bl, acc[p], 0, 0, 0);
+                    if (s < 5) issue_w(s, hf ^ 1, ph + 1);
+                    if (hf == 1 && s >= 2) issue_d(s - 2, ph + 2);  // rows 0..5 at s = 2..7, the tail item at s = 8
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.ah, fr.bh, acc[p], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        t1 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int p = 0; p < 6; ++p) for (int i = 0; i < 16; ++i) sum += acc[p][i];
+        for (int r = 0; r < 6; ++r) sum += d[r][0];
+        sum += dx[0];
     } else {
         constexpr int RND = 3;                                   // 34 px x 4 channel quads = 136 (px, quad) columns per wave / 64 lanes
         f32x16 acc[4][2];                                         // [position][co block]
@@ -376,7 +485,7 @@ template <int MODE, int X = 0>
 void run(const char* name, const float* act, long long act_floats, const bf16x8* wts, int reps, int phases) {
     float* out; long long* cyc;
     hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8);
-    const int lds = MODE != 1 ? (2 * D_BUNITS + 2 * D_WUNITS) * 16 : (8 * W_VWAVE + 2 * W_WHALF) * 16;
+    const int lds = MODE == 3 ? (4 * F_VQUAD + 2 * F_WHALF) * 16 : (MODE != 1 ? (2 * D_BUNITS + 2 * D_WUNITS) * 16 : (8 * W_VWAVE + 2 * W_WHALF) * 16);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, X>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k<MODE, X>), dim3(256), dim3(512), lds, 0, act, act_floats, wts, out, cyc, phases);
@@ -388,7 +497,7 @@ void run(const char* name, const float* act, long long act_floats, const bf16x8*
     ms /= reps;
     long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
     long long med = h[128];
-    const double mfma = (MODE != 1 ? 108.0 : 72.0) * 8 * phases;         // per CU
+    const double mfma = (MODE == 3 ? 54.0 : (MODE != 1 ? 108.0 : 72.0)) * 8 * phases;         // per CU
     printf("%-64s %8.1f us  %7.0f cycles/phase  %.2f GHz  MFMA pipe busy %.0f %%  (LDS %d KB)\n", name, ms * 1e3, (double)med / phases, med / (ms * 1e6),
            100.0 * mfma / 4 * 32 / med, lds / 1024);
     hipFree(out); hipFree(cyc);
@@ -413,6 +522,19 @@ int main(int argc, char** argv) {
         free(w);
     }
     const int phases = 24 * 8;                                    // = 8 launches' worth of the 6 x 128->64 launch's 3 tiles x 8 phases per workgroup
+    if (argc > 4) {          // round 5: F(4,3) along y against F(2,3) and the direct form, with ablations
+        for (int round = 0; round < 3; ++round) {
+            run<0, 0>("direct 3x3 (108 MFMAs / wave / phase)", act, act_floats, wts, 10, phases);
+            run<1, 0>("Winograd F(2,3) along y (72 MFMAs / wave / phase)", act, act_floats, wts, 10, phases);
+            run<3, 0>("Winograd F(4,3) along y (54 MFMAs / wave / phase)", act, act_floats, wts, 10, phases);
+            run<3, 1>("F(4,3), no transform / split VALU", act, act_floats, wts, 10, phases);
+            run<3, 2>("F(4,3), no weight DMA", act, act_floats, wts, 10, phases);
+            run<3, 4>("F(4,3), no fragment reads", act, act_floats, wts, 10, phases);
+            run<3, 8>("F(4,3), no global loads", act, act_floats, wts, 10, phases);
+            run<1, 2>("F(2,3), no weight DMA", act, act_floats, wts, 10, phases);
+        }
+        return 0;
+    }
     if (argc > 3) {          // B-operand reuse (adjacent rows + DPP-shifted horizontal taps)
         for (int round = 0; round < 3; ++round) {
             run<0, 0>("direct (72 KB of fragment reads per wave and phase)", act, act_floats, wts, 10, phases);

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--scale", type=float, nargs=2, default=[4, 4])
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--warm-frames", type=int, default=0,
+                    help="whole network frames run before every timed repetition: the SATU launches are then timed on a board in the state the frame leaves it in "
+                         "(loaded clocks; an idle board's first ~100 launches run up to 10 %% slower) -- what rocprofv3's per-kernel AVERAGES need to mean the steady state")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     eng = E.HipEngine(synth.synth_state_dict(), SAVSR().cfg, dev)
@@ -79,7 +82,10 @@ def main():
         tail = lambda: _lib.check(eng.lib.savsr_tail_gather_q(p27.data_ptr(), plane, seam.data_ptr(), seam.numel(), tb.data_ptr(), center.data_ptr(), h, w, H, W, outb.data_ptr(), st_), "tail_q")
     else:
         tail = lambda: _lib.check(eng.lib.savsr_tail_gather(p27.data_ptr(), plane, tb.data_ptr(), center.data_ptr(), h, w, H, W, outb.data_ptr(), st_), "tail")
+    warm_clip = synth.synth_clip(7, 3, h, w, seed=0).to(dev) if a.warm_frames else None
     for _ in range(a.reps):
+        for _ in range(a.warm_frames):
+            eng.forward(warm_clip, sc)
         tt, tht = t(tail), t(lambda: (hr(), tail()))
         print(f"tail_gather alone {tt:.1f} us   HR->tail pair {tht:.1f} us", flush=True)
         tl, th = t(lr), t(hr)
