@@ -240,3 +240,22 @@ def test_check_readme_logic():
     rows, st = T.check_readme([res("Vid4_x4", (4, 4), 27.17, 0.8184), res("Vid4_x6", (6, 6), 25.0, 0.7)], table)
     assert st == 2 and rows[0]["ok"] and not rows[1]["ok"]
     assert "NO README ENTRY" in T.format_check(rows) and "ok" in T.format_check(rows)
+
+
+def test_hr_plans_table_is_wellformed():
+    """savsr_amd/hr_plans.json (the SATU HR stage's measured launch plan per scale, tools/tune_hr_plans.py): 16-hex source hash, every scale of
+    the shipped YAMLs present, entries [variant, tile rows (multiple of 4, <= 64), tile columns / 32 (1..8), LR h, LR w] -- what the engine's
+    loader (HipEngine._load_hr_plans) and savsr_satu_hr_tail_q's argument checks expect."""
+    import json
+    import re
+    from savsr_amd.utils import workloads
+    path = os.path.join(ROOT, "savsr_amd", "hr_plans.json")
+    t = json.load(open(path))
+    assert re.fullmatch(r"[0-9a-f]{16}", t["satu_source_hash"])
+    keys = {tuple(float(v) for v in k.split(",")) for k in t["plans"]}
+    assert {(float(a), float(b)) for a, b in workloads.YAML_SCALES} <= keys
+    assert {(float(a), float(b)) for a, b in workloads.TRAIN_SCALES} <= keys
+    for k, p in t["plans"].items():
+        assert len(p) == 5 and all(isinstance(v, int) for v in p), (k, p)
+        variant, rows, cols32, h, w = p
+        assert 0 <= variant < 5 and rows % 4 == 0 and 4 <= rows <= 64 and 1 <= cols32 <= 8 and h >= 2 and w >= 2, (k, p)
