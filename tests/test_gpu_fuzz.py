@@ -30,3 +30,13 @@ def test_random_sizes_and_scales_vs_oracle_winograd_everywhere():
     tail = "\n".join(r.stdout.strip().splitlines()[-5:])
     assert r.returncode == 0, tail + r.stderr[-2000:]
     assert "20 cases, worst max-abs" in tail
+
+
+def test_every_scale_pair_of_the_reference_lists_vs_oracle():
+    """tools/scale_list_sweep.py in the suite (the lists were sampled, not closed): all 42 scale pairs of the shipped YAMLs at
+    LR 180 x 320 and all 60 Vimeo90K training pairs at their LR sizes, HIP forward against the CPU oracle -- shape, max-abs < 5e-5, |dPSNR-Y| <= 1e-3 dB,
+    |dSSIM-Y| <= 1e-4 against one synthetic GT, bitwise rerun.  ~170 s on the box's 16 host cores (the oracle is the cost)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_list_sweep.py")], capture_output=True, text=True, timeout=1500)
+    tail = "\n".join(r.stdout.strip().splitlines()[-4:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    assert "# 102 cases, 0 failed" in tail, tail
