@@ -394,14 +394,14 @@ def run_config2(args, rank, world, dev, dist):
     regions = [timed(dist, dev, region) for _ in range(max(1, args.regions))]
     sclk1 = sysfs_sclk_mhz(dev)
     elapsed = sorted(regions)[len(regions) // 2]
-    in_flight = [a.elapsed_time(b) for a, b in eng.satu_events]
+    in_flight = [a.elapsed_time(b) / n for a, b, n in eng.satu_events]       # per clip: a batched launch sequence holds several clips' SATU stages
     eng.satu_events = None
     if rank != 0:
         return
     hr_mpx = H * W / 1e6
     value = world * args.steps * cps * hr_mpx / elapsed
     line = base_line(args, world, value, elapsed, "BASELINE config 2: synthetic 7x3x180x320 clips, scale x4 -> 720x1280, key-seeded random-init weights",
-                     {"frames_per_step": cps, "streams_per_gpu": min(cps, eng.n_streams)})
+                     {"frames_per_step": cps, "streams_per_gpu": min(cps, eng.n_streams), "clips_per_launch_sequence": eng.clip_batch})
     line["metric"] = "HR Mpixels/sec (Vid4-shape x4, 7-frame window)"
     line["timed_region_s"] = round(elapsed, 3)
     vals = sorted(world * args.steps * cps * hr_mpx / e for e in regions)
@@ -519,34 +519,35 @@ def run_cases(args, rank, world, dev, dist, cases, workload, config_id):
 
 
 def run_config5(args, rank, world, dev, dist):
-    """Vimeo90K-shape mixed-scale throughput: every step draws `clips-per-step` (shape, scale) pairs from the 60-entry training
-    list (random.Random(seed = rank)) and runs them as a stream of independent clips over the engine's HIP streams."""
+    """Vimeo90K-shape mixed-scale throughput: `clips-per-step` x (steps + warmup) (shape, scale) pairs drawn from the 60-entry training list
+    (random.Random(seed = rank)) run as a stream of independent clips over the engine's HIP streams.  The stream is BUCKETED, as a loader for
+    mixed-shape data would deliver it (batching clips of equal (shape, scale) is allowed): the draws are ordered so that equal pairs
+    are adjacent, and the engine runs up to SAVSR_CLIP_BATCH of them per launch sequence (`--no-bucket`: the draw order)."""
     from savsr_amd.engine import get_hw
     from savsr_amd.utils import synth, workloads
     net, sd = build_net(dev)
     eng = net.engine()                                    # product defaults: the byte budget (SAVSR_CACHE_GB) decides what stays resident
     cps = max(1, args.clips_per_step)
-    draws = workloads.config5_cases(cps * (args.steps + args.warmup), seed=rank)
+    draws = workloads.config5_cases(cps * args.steps, seed=rank)
+    if not args.no_bucket:
+        draws = sorted(draws, key=lambda k: (k[0] * k[1], k[2]))
     uniq = sorted(set(draws))
     clips = {k: synth.synth_clip(7, 3, k[0], k[1], seed=11, batch=1).to(dev) for k in uniq}
 
     def run_step(i):
         ks = draws[i * cps:(i + 1) * cps]
-        outs = net.forward_many([clips[k][0] for k in ks], [k[2] for k in ks])       # clip j on HIP stream j % n_streams
+        outs = net.forward_many([clips[k][0] for k in ks], [k[2] for k in ks])       # launch units dealt over the HIP streams
         return sum(o.shape[-1] * o.shape[-2] for o in outs)
-    # The steady state of a long stream (64 612 clips over 60 pairs: ~1000 visits each): every (shape, scale) has been seen by every
-    # stream's engine often enough to be captured (SAVSR_CAPTURE_AFTER eager frames, then the capture) -- untimed
-    for _ in range(eng.capture_after + 1):
-        for j in range(0, len(uniq), eng.n_streams):
-            for r in range(eng.n_streams):
-                ks = [uniq[(j + (q + r) % eng.n_streams) % len(uniq)] for q in range(eng.n_streams)]
-                net.forward_many([clips[k][0] for k in ks], [k[2] for k in ks])
-    for i in range(args.warmup):
-        run_step(i)
+    # The steady state of a long stream (64 612 clips over 60 pairs: ~1000 visits each): every context the timed pass uses -- (shape, scale,
+    # clips per launch sequence) on the stream that runs it -- exists.  The untimed passes run the SAME step sequence (the draws are
+    # deterministic), `--warmup` + 1 times.
+    for _ in range(max(1, args.warmup) + eng.capture_after):
+        for i in range(args.steps):
+            run_step(i)
     px = [0]
 
     def region():
-        for i in range(args.warmup, args.warmup + args.steps):
+        for i in range(args.steps):
             px[0] += run_step(i)
     hs0 = dict(eng.host_stats)
     ev0 = eng.cache_stats()["evictions"]
@@ -555,7 +556,8 @@ def run_config5(args, rank, world, dev, dist):
         return
     line = base_line(args, world, world * px[0] / el / 1e6, el,
                      "BASELINE config 5: synthetic Vimeo90K-shape clips (GT 256x448), (sh, sw) drawn from the 60-entry training list, random-init weights",
-                     {"frames_per_step": cps, "distinct_shape_scale_pairs": len(uniq), "streams_per_gpu": eng.n_streams})
+                     {"frames_per_step": cps, "distinct_shape_scale_pairs": len(uniq), "streams_per_gpu": eng.n_streams,
+                      "clips_per_launch_sequence": eng.clip_batch, "bucketed_by_shape_and_scale": not args.no_bucket})
     line["bench_config"] = 5
     line["clips_per_s"] = round(world * cps * args.steps / el, 2)
     st = eng.cache_stats()
@@ -820,6 +822,7 @@ def main():
     ap.add_argument("--clips-per-step", type=int, default=18,
                     help="independent clips per step (3 in flight on separate HIP streams; 18 keeps a 20-step timed region at ~3 s)")
     ap.add_argument("--scales", type=str, default="", help="config 3: comma-separated subset, e.g. 1.1,2.5,4")
+    ap.add_argument("--no-bucket", action="store_true", help="config 5: keep the draw order instead of grouping equal (shape, scale) clips")
     args = ap.parse_args()
     if args.config != "run_test":
         args.config = int(args.config)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 25
+#define SAVSR_ABI_VERSION 26
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -134,10 +134,11 @@ int64_t savsr_conv_wy_packed_elems(int cout, int cin);
 int64_t savsr_conv_wy_pack_index(int cout, int cin, int co, int ci, int pos, int kx);
 int savsr_conv_pool_blocks(int h, int w);
 int savsr_conv2d(const savsr_conv_desc* d, void* stream);
-/* n (1..6) independent convs of identical geometry (ksize, nsrc, src_ch, h, w, cout) in ONE launch
- * (grid.z = n * output-channel blocks): e.g. the per-stream convs of a ResidualBlock (savsr_arch.py:402,413)
- * of both propagation directions.  More workgroups than CUs, so workgroups run out of phase and the
+/* n (1..savsr_conv2d_max_batch() = 18; 6 up to ABI 25) independent convs of identical geometry (ksize, nsrc, src_ch, h, w, cout) in ONE launch:
+ * e.g. the per-stream convs of a ResidualBlock (savsr_arch.py:402,413) of both propagation directions -- and, since ABI 26, of up to three
+ * clips of one (shape, scale) whose launch sequences the caller runs as one (small clips are launch-latency-bound).  More workgroups than CUs, so workgroups run out of phase and the
  * load/store bursts of one overlap the MFMA phases of another. */
+int savsr_conv2d_max_batch(void);
 int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 25
+ABI_VERSION = 26
 CONV_DIRECT, CONV_DIRECT_THROUGHPUT, CONV_WINOGRAD_Y = 0, 2, 3
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
@@ -77,6 +77,7 @@ class SatuTiling(C.Structure):
 # name -> (restype, argtypes); must list every symbol include/savsr_hip.h declares
 SIGNATURES = {
     "savsr_version": (C.c_char_p, []),
+    "savsr_conv2d_max_batch": (C.c_int, []),
     "savsr_conv_wy_packed_elems": (C.c_int64, [C.c_int, C.c_int]),
     "savsr_conv_wy_pack_index": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "savsr_source_hash": (C.c_char_p, []),

@@ -869,9 +869,11 @@ static int fill_params(const savsr_conv_desc* d, ConvParams& p) {
     return 0;
 }
 
+extern "C" int savsr_conv2d_max_batch(void) { return CONV_MAX_BATCH; }
+
 extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* stream) {
     if (!descs) return fail_arg("conv: null descriptor");
-    if (n < 1 || n > CONV_MAX_BATCH) return fail_arg("conv: batch size must be 1..6");
+    if (n < 1 || n > CONV_MAX_BATCH) return fail_arg("conv: batch size must be 1..18 (savsr_conv2d_max_batch())");
     MultiConvParams mp;
     for (int i = 0; i < n; ++i) {
         const int rc = fill_params(descs + i, mp.c[i]);

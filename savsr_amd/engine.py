@@ -180,13 +180,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 class Src:
-    """A channel-last feature map slice: element (px, c) at ptr + 4*(px*pix + c), c < ch."""
-    __slots__ = ("t", "ptr", "ch", "pix")
+    """A channel-last feature map slice: element (px, c) at ptr + 4*(px*pix + c), c < ch.  bs = bytes from one clip's copy of the tensor to the
+    next when several clips of one (shape, scale) share the launches (HipEngine.nb > 1), 0 otherwise."""
+    __slots__ = ("t", "ptr", "ch", "pix", "bs")
 
-    def __init__(self, t: torch.Tensor, ch: int, pix: int, ch_off: int = 0, float_off: int = 0):
+    def __init__(self, t: torch.Tensor, ch: int, pix: int, ch_off: int = 0, float_off: int = 0, bs: int = 0):
         self.t = t
         self.ptr = t.data_ptr() + 4 * (ch_off + float_off)
-        self.ch, self.pix = ch, pix
+        self.ch, self.pix, self.bs = ch, pix, bs
 
 
 class HipEngine:
@@ -210,8 +211,19 @@ class HipEngine:
         self.se: Dict[str, tuple] = {}
         self._keep: List[torch.Tensor] = []
         self._init_caches()
-        self.satu_events: Optional[list] = None     # bench.py: (start, end) HIP events around SATU
+        self.satu_events: Optional[list] = None     # bench.py: (start, end, clips) HIP events around the SATU stage(s) of a launch sequence
         self._st: Optional[int] = None              # cached stream handle while a frame's launches are being issued (_stream)
+        # Clips of ONE (shape, scale) batched into the launches (round 5).  A small clip is launch-latency-bound -- 330 dependent launches at ~11 us
+        # each whatever its size (tools/probe_small_clips.py) -- and more than three streams do not help (a conv workgroup holds its CU's LDS).  With
+        # nb clips in one launch sequence every named buffer holds nb copies (`_bstride`: bytes between them), every conv / OSConv descriptor is
+        # issued once per clip INSIDE the same batched launch (savsr_conv2d_batch takes 18 convs since ABI 26) and the per-clip kernels (SE gate,
+        # SATU, tail, ...) are looped: 151 + 63 + nb x ~116 launches for nb clips instead of nb x 330.  Results are those of the one-clip
+        # sequence bit for bit (the convs of a batched launch are independent).  forward_many groups equal (shape, scale) clips up to
+        # SAVSR_CLIP_BATCH (default 3) when the LR frame has at most SAVSR_CLIP_BATCH_MAX_PX pixels.
+        self.nb = 1
+        self._bstride: Dict[int, int] = {}
+        self.clip_batch = max(1, min(self.NB_MAX, int(os.environ.get("SAVSR_CLIP_BATCH", "3"))))
+        self.clip_batch_max_px = int(os.environ.get("SAVSR_CLIP_BATCH_MAX_PX", str(200 * 352)))
         self.census: Optional[dict] = None          # bench.py: per-launch matrix-work census (_count_conv), shared with the sibling engines
         # SAVSR_CAPTURE_AFTER = n: a (shape, scale) context's first n frames run EAGERLY and the hipGraphs are captured on visit n + 1 (eager,
         # captured and replayed frames are the same launch sequence: bit-identical results).  Default 0 = capture on the first visit, by
@@ -240,6 +252,8 @@ class HipEngine:
         self._siblings: List["HipEngine"] = []
         self._streams: List[torch.cuda.Stream] = []
         self._pack_all({k: v.detach() for k, v in state.items()})
+
+    NB_MAX = 3                  # clips per batched launch sequence (6 convs x 3 clips = the 18 of savsr_conv2d_max_batch(); 2 OSConvs x 3 = 6)
 
     HR_PLANS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hr_plans.json")
 
@@ -322,11 +336,25 @@ class HipEngine:
                    fl_w=g(a + ".filter_fc.weight"), fl_b=g(a + ".filter_fc.bias"),
                    sp_w=g(a + ".spatial_fc.weight"), sp_b=g(a + ".spatial_fc.bias"),
                    kn_w=g(a + ".kernel_fc.weight"), kn_b=g(a + ".kernel_fc.bias"),
-                   v1=torch.empty(2 * cin, device=self.dev), v2=torch.empty(cin, device=self.dev),
-                   att=torch.empty(cin + cout + 9 + knum, device=self.dev),
-                   wdyn=torch.empty(2 * elems, device=self.dev, dtype=torch.int16),
-                   wdyn_wy=torch.empty(2 * (elems * 4 // 3) if cout % 64 == 0 else 0, device=self.dev, dtype=torch.int16))     # (12 taps instead of 9)
+                   **self._osc_scratch(cin, cout, knum, elems))
         self.osc[key] = ent
+
+    def _osc_scratch(self, cin: int, cout: int, knum: int, elems: int) -> dict:
+        """Per-engine scratch of one OSConv (routing vectors, gates, the generated weight images), NB_MAX copies: one per clip of a batched
+        launch sequence (the tensors handed around are clip 0's; `_bstride` knows the distance to the next)."""
+        nb = self.NB_MAX
+        al = lambda n, unit: ((n * unit + 255) // 256) * 256 // unit          # copies stay 256-byte aligned
+        out = {}
+        for name, n, dt in (("v1", 2 * cin, torch.float32), ("v2", cin, torch.float32), ("att", cin + cout + 9 + knum, torch.float32),
+                            ("wdyn", 2 * elems, torch.int16), ("wdyn_wy", 2 * (elems * 4 // 3) if cout % 64 == 0 else 0, torch.int16)):      # (12 taps instead of 9)
+            unit = 4 if dt == torch.float32 else 2
+            pitch = al(n, unit)
+            full = torch.empty(nb * pitch, device=self.dev, dtype=dt)
+            self._keep.append(full)
+            t = full[:n]
+            self._bstride[t.data_ptr()] = pitch * unit
+            out[name] = t
+        return out
 
     def _pack_satu(self, sd):
         p = "upsample."
@@ -505,11 +533,11 @@ class HipEngine:
         e.iter_win, e.fwd_idx, e.bwd_idx = self.iter_win, self.fwd_idx, self.bwd_idx
         e.satu_tail_t, e.satu_w_tail = self.satu_tail_t, self.satu_w_tail
         e.satu_tailq_t, e.satu_w_tailq, e.satu_q = self.satu_tailq_t, self.satu_w_tailq, self.satu_q
+        e.nb, e._bstride, e.clip_batch, e.clip_batch_max_px = 1, {}, self.clip_batch, self.clip_batch_max_px
         e.osc = {}
         for k, ent in self.osc.items():
             c = dict(ent)
-            for name in ("v1", "v2", "att", "wdyn", "wdyn_wy"):
-                c[name] = torch.empty_like(ent[name])
+            c.update(e._osc_scratch(ent["cin"], ent["cout"], ent["knum"], ent["nunits"] * 8))
             e.osc[k] = c
         e.se_gate = torch.empty_like(self.se_gate)
         e._init_caches()
@@ -643,7 +671,8 @@ class HipEngine:
             n = 1
             for d in shape:
                 n *= int(d)
-            nbytes = (4 * n + 255) & ~255
+            nbytes1 = (4 * n + 255) & ~255
+            nbytes = nbytes1 * self.nb                    # (nb copies: clip b's lives nbytes1 * b further on)
             free = owner.get("free", {}).get(nbytes) if not owner.get("sealed") else None
             if free:
                 raw = free.pop()                          # a slot whose previous owner's last reader is already enqueued (release())
@@ -658,6 +687,10 @@ class HipEngine:
             t = raw[:4 * n].view(torch.float32).view(shape)
             store[key] = t
             owner.setdefault("raw", {})[t.data_ptr()] = raw
+            if self.nb > 1:
+                self._bstride[t.data_ptr()] = nbytes1
+            else:
+                self._bstride.pop(t.data_ptr(), None)     # (an address an evicted batched context used to own)
         return t
 
     # Buffer liveness.  The launch sequence of a clip shape is static, so the assignment of named buffers to memory is decided ONCE, on the
@@ -721,11 +754,14 @@ class HipEngine:
         def __exit__(self, *a):
             self.eng._st = self.prev
 
-    @staticmethod
-    def full(t: torch.Tensor, ch: Optional[int] = None, ch_off: int = 0) -> Src:
+    def full(self, t: torch.Tensor, ch: Optional[int] = None, ch_off: int = 0) -> Src:
         """Channel slice [ch_off, ch_off+ch) of a contiguous channel-last tensor [h][w][C]."""
         c_total = t.shape[-1]
-        return Src(t, c_total - ch_off if ch is None else ch, c_total, ch_off)
+        return Src(t, c_total - ch_off if ch is None else ch, c_total, ch_off, bs=self._bs(t))
+
+    def _bs(self, t: Optional[torch.Tensor]) -> int:
+        """Bytes between the clips' copies of a named buffer (0: one clip, or a tensor every clip shares)."""
+        return 0 if (t is None or self.nb == 1) else self._bstride.get(t.data_ptr(), 0)
 
     def conv_desc(self, key, srcs: List[Src], out: Src, h: int, w: int, act=ACT_NONE, slope=0.0,
                   mul_px=None, res1: Optional[Src] = None, res2: Optional[Src] = None, res2_scale=0.0, weights=None,
@@ -752,13 +788,41 @@ class HipEngine:
         d.out, d.out_pix = out.ptr, out.pix
         if pool is not None:
             d.pool, d.pool_stride = pool[0].data_ptr() + 4 * pool[1], pool[2]
+        if self.nb > 1:      # bytes from clip b's operand to clip b + 1's (Python attribute): sources, out, res1, res2, mul_px, pool, weights
+            d._bs = ([s.bs for s in srcs], out.bs, res1.bs if res1 is not None else 0, res2.bs if res2 is not None else 0, self._bs(mul_px),
+                     self._bs(pool[0]) if pool is not None else 0, self._bs(wpk) if weights is not None else 0)
+            assert out.bs > 0, (key, "a batched launch writes one output per clip")
         return d
 
+    @staticmethod
+    def _clip_desc(d: ConvDesc, b: int) -> ConvDesc:
+        """Descriptor of the same conv for clip b of a batched launch sequence: every per-clip pointer moved on by b clip strides."""
+        if b == 0:
+            return d
+        n = ConvDesc.from_buffer_copy(d)
+        src_bs, out_bs, r1_bs, r2_bs, mp_bs, pool_bs, w_bs = d._bs
+        for i in range(d.nsrc):
+            n.src[i] = d.src[i] + b * src_bs[i]
+        n.out = d.out + b * out_bs
+        if d.res1:
+            n.res1 = d.res1 + b * r1_bs
+        if d.res2:
+            n.res2 = d.res2 + b * r2_bs
+        if d.mul_px:
+            n.mul_px = d.mul_px + b * mp_bs
+        if d.pool:
+            n.pool = d.pool + b * pool_bs
+        n.wpacked = d.wpacked + b * w_bs
+        n._wy = getattr(d, "_wy", None)
+        return n
+
     def conv_launch(self, descs: List[ConvDesc], label: str = "conv"):
-        """Independent convs of identical geometry, up to 6 per launch (savsr_conv2d_batch)."""
+        """Independent convs of identical geometry, up to 6 per launch and clip (savsr_conv2d_batch; x nb clips of a batched launch sequence)."""
         st = self._stream()
         for i in range(0, len(descs), 6):
             chunk = descs[i:i + 6]
+            if self.nb > 1:
+                chunk = [self._clip_desc(d, b) for b in range(self.nb) for d in chunk]
             # Winograd-y form when every conv of the launch has the image and its 16-row x 32-px x 64-channel tiles fill the chip: measured on
             # 180x320 (tools/ab_conv.py --wy): 6 x 128->64 -10 %, 6 x 64->64 -7..-9 %; a lone 64->64 conv (120 tiles) +35 % against the 8-row
             # direct tiling, -4 % against the 16-row direct tiling of the throughput mode
@@ -799,10 +863,11 @@ class HipEngine:
     def channel_sums(self, srcs: List[Src], npx: int, partial: torch.Tensor) -> int:
         n = len(srcs)
         nblk = max(1, min(MAX_SUM_BLOCKS, npx // 128))
-        ptrs = (_lib.fptr * n)(*[s.ptr for s in srcs])
         pix = (C.c_int32 * n)(*[s.pix for s in srcs])
-        _lib.check(self.lib.savsr_channel_sums(ptrs, pix, n, srcs[0].ch, npx, nblk, partial.data_ptr(), self._stream()),
-                   "savsr_channel_sums")
+        for b in range(self.nb):
+            ptrs = (_lib.fptr * n)(*[s.ptr + b * s.bs for s in srcs])
+            _lib.check(self.lib.savsr_channel_sums(ptrs, pix, n, srcs[0].ch, npx, nblk, partial.data_ptr() + b * self._bs(partial), self._stream()),
+                       "savsr_channel_sums")
         return nblk
 
     def pool_rows(self, h: int, w: int) -> int:
@@ -817,7 +882,7 @@ class HipEngine:
         """Whether the dynamic convs of a launch of `n_convs` OSConvs run in the Winograd-y form (the rule of conv_launch)."""
         if not self.conv_wy or cout % 64:
             return False
-        tiles = n_convs * (cout // 64) * ((h + 15) // 16) * ((w + 31) // 32)
+        tiles = n_convs * self.nb * (cout // 64) * ((h + 15) // 16) * ((w + 31) // 32)
         return tiles >= (self.wy_min_tiles_tp if self.conv_algo == _lib.CONV_DIRECT_THROUGHPUT else self.wy_min_tiles)
 
     def osconv_desc(self, key: str, srcs: List[Src], h: int, w: int, scale, pooled: bool = False, wy: bool = False) -> OSConvAttnDesc:
@@ -837,15 +902,30 @@ class HipEngine:
             setattr(d, k, e[k].data_ptr())
         d.wy = 1 if wy else 0
         d.fused = 1 if self.osconv_fused else 0
-        d.wimg_out = (e["wdyn_wy"] if wy else e["wdyn"]).data_ptr()
+        wimg = e["wdyn_wy"] if wy else e["wdyn"]
+        d.wimg_out = wimg.data_ptr()
+        if self.nb > 1:      # per-clip operands of a batched launch sequence: pool partials, routing vectors, gates, the generated image
+            d._bs = {"partial": self._bs(partial), "v1": self._bs(e["v1"]), "v2": self._bs(e["v2"]), "att": self._bs(e["att"]), "wimg_out": self._bs(wimg)}
+            assert all(v > 0 for v in d._bs.values()), (key, d._bs)
         return d
 
     def osconv_launch(self, keys: List[str], descs: List[OSConvAttnDesc]):
         """Weight generation of independent OSConvs of identical geometry, up to 6 per set of launches
         (savsr_osconv_weights_batch); returns the conv `weights` tuples."""
         st = self._stream()
-        for i in range(0, len(descs), 6):
-            chunk = descs[i:i + 6]
+        per = 6 // self.nb                               # OSConvs per set of launches when every one of them goes out once per clip
+        for i in range(0, len(descs), per):
+            chunk = descs[i:i + per]
+            if self.nb > 1:
+                clips = []
+                for b in range(self.nb):
+                    for d in chunk:
+                        n = d if b == 0 else OSConvAttnDesc.from_buffer_copy(d)
+                        if b:
+                            for f, bs in d._bs.items():
+                                setattr(n, f, getattr(d, f) + b * bs)
+                        clips.append(n)
+                chunk = clips
             arr = (OSConvAttnDesc * len(chunk))(*chunk)
             _lib.check(self.lib.savsr_osconv_weights_batch(arr, len(chunk), st), f"savsr_osconv_weights_batch[{keys[i]}]")
         return [(self.osc[k]["wdyn_wy"], None, self.osc[k]["cout"], self.osc[k]["cin"], 3, _lib.CONV_WINOGRAD_Y) if dsc.wy else
@@ -926,8 +1006,10 @@ class HipEngine:
         w1, b1, w2, b2, cm = self.se[pfx]
         st = self._stream()
         assert x.pix == nf and out.pix == nf
-        _lib.check(self.lib.savsr_se_scale_residual(part.data_ptr(), nblk, 1.0 / (hp * wp), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                                    nf, cm, r2.ptr, x.ptr, out.ptr, hp * wp, st), "savsr_se_scale_residual")
+        pbs = self._bs(part)
+        for b in range(self.nb):                 # (a per-clip kernel: looped over the clips of a batched launch sequence)
+            _lib.check(self.lib.savsr_se_scale_residual(part.data_ptr() + b * pbs, nblk, 1.0 / (hp * wp), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                        nf, cm, r2.ptr + b * r2.bs, x.ptr + b * x.bs, out.ptr + b * out.bs, hp * wp, st), "savsr_se_scale_residual")
         return out
 
     def osadapt(self, g: int, x: Src, share: Optional[Src], out: Src, hp: int, wp: int, scale, pooled: bool = False) -> Src:
@@ -939,11 +1021,13 @@ class HipEngine:
         h2, w2 = hp // 2, wp // 2
         m1 = self.conv(m + ".0", [x], self.full(self.buf("ad.m1", hp, wp, c4)), hp, wp, ACT_RELU)
         m2 = self.buf("ad.m2", h2, w2, c4)
-        _lib.check(self.lib.savsr_avgpool2(m1.ptr, m2.data_ptr(), c4, hp, wp, st), "savsr_avgpool2")
+        for b in range(self.nb):
+            _lib.check(self.lib.savsr_avgpool2(m1.ptr + b * m1.bs, m2.data_ptr() + b * self._bs(m2), c4, hp, wp, st), "savsr_avgpool2")
         m3 = self.conv(m + ".4", [self.full(m2)], self.full(self.buf("ad.m3", h2, w2, c4)), h2, w2, ACT_RELU)
         m4 = self.conv(m + ".7", [m3], self.full(self.buf("ad.m4", h2, w2, c4)), h2, w2, ACT_RELU)
         m5 = self.buf("ad.m5", hp, wp, c4)
-        _lib.check(self.lib.savsr_upsample2x(m4.ptr, m5.data_ptr(), c4, h2, w2, st), "savsr_upsample2x")
+        for b in range(self.nb):
+            _lib.check(self.lib.savsr_upsample2x(m4.ptr + b * m4.bs, m5.data_ptr() + b * self._bs(m5), c4, h2, w2, st), "savsr_upsample2x")
         mask = self.buf("ad.mask", hp, wp, 1)
         self.conv(m + ".11", [self.full(m5)], self.full(mask), hp, wp, ACT_SIGMOID)
         wd = self.osconv_weights(f"adapt.{g}.adapt", [x], hp, wp, scale, pooled=pooled, wy=self.osconv_wy(1, self.nf, hp, wp))
@@ -1058,7 +1142,7 @@ class HipEngine:
         16 KiB at 720x1280)."""
         return ((H * W + 255) // 256) * 256 + 1088
 
-    def satu_lr(self, x: Src, st: Src, row_px: int, h: int, w: int, tail_form: bool = False, q: bool = False) -> torch.Tensor:
+    def satu_lr(self, x: Src, st: Src, row_px: int, h: int, w: int, tail_form: bool = False, q: bool = False, b: int = 0) -> torch.Tensor:
         """LR stage of SATU (kernel_conv + LeakyReLU + sta_conv + LR-side projections, savsr_arch.py:226-228,297-320).
         tail_form: the projections carry the tail conv's channel contraction (include/savsr_hip.h); q: in the row order of
         the row-summed form (savsr_satu_hr_tail_q)."""
@@ -1069,11 +1153,12 @@ class HipEngine:
         else:
             lrcat = self.buf("satu.lrcat", h, w, _lib.SATU_LRCAT)
             fn, wts = self.lib.savsr_satu_lr_stage, self.satu_w
-        _lib.check(fn(C.byref(wts), x.ptr, st.ptr, x.pix, row_px, h, w, lrcat.data_ptr(), self._stream()), "savsr_satu_lr_stage")
+        # (b: the clip of a batched launch sequence this call works on; the returned tensor is clip 0's copy either way)
+        _lib.check(fn(C.byref(wts), x.ptr + b * x.bs, st.ptr + b * st.bs, x.pix, row_px, h, w, lrcat.data_ptr() + b * self._bs(lrcat), self._stream()), "savsr_satu_lr_stage")
         return lrcat
 
     def satu_hr(self, lrcat: torch.Tensor, h: int, w: int, scale, out: torch.Tensor, out_plane: Optional[int] = None, tail_form: bool = False,
-                seam: Optional[torch.Tensor] = None):
+                seam: Optional[torch.Tensor] = None, b: int = 0):
         """HR stage of SATU (grid_sample x2, expert mixing, fusion, savsr_arch.py:262-295,353-374) -> out [64] planes of [H][W];
         tail_form: -> the 27 tail-projected planes P, or with `seam` (seam_floats(H, W) floats) the row-summed form: out = the 9 planes Q
         (lrcat from satu_lr(..., q=True))."""
@@ -1085,10 +1170,13 @@ class HipEngine:
         sched = self.hr_sched.data_ptr() if os.environ.get("SAVSR_HR_STATIC") != "1" else None
         plane = out_plane if out_plane is not None else ax["H"] * ax["W"]
 
+        p_lr, p_out = lrcat.data_ptr() + b * self._bs(lrcat), out.data_ptr() + b * self._bs(out)          # (clip b of a batched launch sequence)
+        p_seam = None if seam is None else seam.data_ptr() + b * self._bs(seam)
+
         def launch(til):
-            _lib.check(fn(C.byref(wts), lrcat.data_ptr(), h, w, ax["table"].data_ptr(), ax["n_uh"], ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
+            _lib.check(fn(C.byref(wts), p_lr, h, w, ax["table"].data_ptr(), ax["n_uh"], ax["n_uw"], ax["ih"].data_ptr(), ax["iw"].data_ptr(),
                           _ptr(ax["ptab"]), ax["gyn"].data_ptr(), ax["gxn"].data_ptr(), ax["H"], ax["W"],
-                          C.byref(til), sched, out.data_ptr(), plane, *(() if seam is None else (seam.data_ptr(), seam.numel())), self._stream()), "savsr_satu_hr")
+                          C.byref(til), sched, p_out, plane, *(() if seam is None else (p_seam, seam.numel())), self._stream()), "savsr_satu_hr")
         if not tail_form:
             launch(ax["tiling"])
             return out
@@ -1166,11 +1254,16 @@ class HipEngine:
     def _stage_body_impl(self, lq: torch.Tensor, scale) -> dict:
         """Everything up to the SATU inputs (savsr_arch.py:692-734).  lq: [T, 3, h, w] on device."""
         cfg, nf = self.cfg, self.nf
-        T, cin, h_in, w_in = lq.shape
+        if lq.dim() == 5:          # [nb, T, 3, h, w]: nb clips of one (shape, scale) in one launch sequence (see `nb`)
+            assert lq.shape[0] == self.nb and lq.is_contiguous() and cfg["interval"] == 0
+        else:
+            assert self.nb == 1
+        T, cin, h_in, w_in = lq.shape[-4:]
+        clip_bytes = 4 * T * cin * h_in * w_in
         assert T == cfg["num_frame"] and cin == cfg["num_in_ch"] == 3
         if self.census is not None:
             k = "frames_tp" if self.conv_algo == _lib.CONV_DIRECT_THROUGHPUT else "frames_b1"
-            self.census[k] = self.census.get(k, 0) + 1
+            self.census[k] = self.census.get(k, 0) + self.nb
         if h_in < 2 or w_in < 2:
             raise ValueError("SAVSR needs h, w >= 2")
         hp, wp = h_in + (h_in & 1), w_in + (w_in & 1)              # pad_spatial to even (savsr_arch.py:670-690)
@@ -1178,8 +1271,9 @@ class HipEngine:
         sw, fw = cfg["slid_win"], cfg["fusion_win"]
         if cfg["interval"] == 0:
             wins = self.buf("windows", T - 2, hp, wp, 16)
-            _lib.check(self.lib.savsr_pack_windows(lq.data_ptr(), wins.data_ptr(), T, h_in, w_in, hp, wp, st), "savsr_pack_windows")
-            win_b = win_f = lambda t: Src(wins, 16, 16, 0, float_off=(t - 1) * hp * wp * 16)
+            for b in range(self.nb):
+                _lib.check(self.lib.savsr_pack_windows(lq.data_ptr() + b * clip_bytes, wins.data_ptr() + b * self._bs(wins), T, h_in, w_in, hp, wp, st), "savsr_pack_windows")
+            win_b = win_f = lambda t: Src(wins, 16, 16, 0, float_off=(t - 1) * hp * wp * 16, bs=self._bs(wins))
             T = self.iter_win
         else:
             # frame_sample (:638-659, :699): each direction walks its own sub-sequence of the clip -- gathered (a device copy of
@@ -1197,7 +1291,10 @@ class HipEngine:
             win_b = lambda t, wb=packs[1]: Src(wb, 16, 16, 0, float_off=(t - 1) * hp * wp * 16)
         steps = T - sw + 1
         zero = self.buf("zero", hp, wp, nf)
-        zero.zero_()          # hidden state restarts from zero every window (savsr_arch.py:705-706)
+        if self.nb == 1:
+            zero.zero_()      # hidden state restarts from zero every window (savsr_arch.py:705-706)
+        else:                 # (every clip's copy: the whole allocation behind the name)
+            self._cur["raw"][zero.data_ptr()].zero_()
         hb = hf = self.full(zero)
         hpair = [self.buf(f"hpair{i}", hp, wp, 2 * nf) for i in range(steps)]   # cat(f2p[i], p2f[i]) of :721, written in place
         for idx in range(steps):                                                    # :708-719, both directions per launch
@@ -1255,12 +1352,13 @@ class HipEngine:
 
     def _stage_satu_impl(self, c: dict, scale):
         """SATU in the tail-projected form (savsr_arch.py:315-376 with the channel contraction of :738 folded in): -> P [27][H][W]."""
-        if self.satu_q:        # row-summed form: the HR stage adds the horizontal taps itself -> 9 planes + seams
-            lrcat = self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True, q=True)
-            self.satu_hr(lrcat, c["h"], c["w"], scale, c["q9"], c["plane"], tail_form=True, seam=c["seam"])
-            return
-        lrcat = self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True)       # crops of :737 via (row pitch, h, w)
-        self.satu_hr(lrcat, c["h"], c["w"], scale, c["p27"], c["plane"], tail_form=True)
+        for b in range(self.nb):       # (per-clip kernels: looped over the clips of a batched launch sequence)
+            if self.satu_q:        # row-summed form: the HR stage adds the horizontal taps itself -> 9 planes + seams
+                lrcat = self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True, q=True, b=b)
+                self.satu_hr(lrcat, c["h"], c["w"], scale, c["q9"], c["plane"], tail_form=True, seam=c["seam"], b=b)
+                continue
+            lrcat = self.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True, b=b)       # crops of :737 via (row pitch, h, w)
+            self.satu_hr(lrcat, c["h"], c["w"], scale, c["p27"], c["plane"], tail_form=True, b=b)
 
     def _stage_tail(self, c: dict, lq: torch.Tensor, out: torch.Tensor):
         with HipEngine._StageStream(self):
@@ -1269,15 +1367,18 @@ class HipEngine:
     def _stage_tail_impl(self, c: dict, lq: torch.Tensor, out: torch.Tensor):
         """What is left of :738-739: the nine shifted taps per colour, the tail bias, the bilinear residual."""
         cfg = self.cfg
-        T = lq.shape[0]
+        T = lq.shape[-4]
         center = T // 2 if cfg["center_frame_idx"] is None else cfg["center_frame_idx"]
-        cptr = lq.data_ptr() + 4 * center * 3 * c["h"] * c["w"]                     # unpadded centre frame (:696)
-        if self.satu_q:
-            _lib.check(self.lib.savsr_tail_gather_q(c["q9"].data_ptr(), c["plane"], c["seam"].data_ptr(), c["seam"].numel(), self.tail_b.data_ptr(), cptr,
-                                                    c["h"], c["w"], c["H"], c["W"], out.data_ptr(), self._stream()), "savsr_tail_gather_q")
-            return
-        _lib.check(self.lib.savsr_tail_gather(c["p27"].data_ptr(), c["plane"], self.tail_b.data_ptr(), cptr,
-                                              c["h"], c["w"], c["H"], c["W"], out.data_ptr(), self._stream()), "savsr_tail_gather")
+        clip_bytes, out_bytes = 4 * T * 3 * c["h"] * c["w"], 4 * 3 * c["H"] * c["W"]      # (lq [nb, T, 3, h, w] and out [nb, 3, H, W] are contiguous)
+        for b in range(self.nb):
+            cptr = lq.data_ptr() + b * clip_bytes + 4 * center * 3 * c["h"] * c["w"]    # unpadded centre frame (:696)
+            if self.satu_q:
+                _lib.check(self.lib.savsr_tail_gather_q(c["q9"].data_ptr() + b * self._bs(c["q9"]), c["plane"], c["seam"].data_ptr() + b * self._bs(c["seam"]),
+                                                        c["seam"].numel(), self.tail_b.data_ptr(), cptr,
+                                                        c["h"], c["w"], c["H"], c["W"], out.data_ptr() + b * out_bytes, self._stream()), "savsr_tail_gather_q")
+                continue
+            _lib.check(self.lib.savsr_tail_gather(c["p27"].data_ptr() + b * self._bs(c["p27"]), c["plane"], self.tail_b.data_ptr(), cptr,
+                                                  c["h"], c["w"], c["H"], c["W"], out.data_ptr() + b * out_bytes, self._stream()), "savsr_tail_gather")
 
     def _satu_standalone(self, c: dict, scale) -> torch.Tensor:
         """STAUpsample.forward as such ([64][H][W]; tests / taps only -- the product path never materialises it)."""
@@ -1286,7 +1387,16 @@ class HipEngine:
         return o[:, : c["H"] * c["W"]].view(self.nf, c["H"], c["W"])
 
     def forward_one(self, lq: torch.Tensor, scale, out: torch.Tensor, taps: Optional[dict] = None):
-        """Eager launch sequence.  lq: [T, 3, h, w] fp32 contiguous on device; out: [3, H, W]."""
+        """Eager launch sequence.  lq: [T, 3, h, w] fp32 contiguous on device; out: [3, H, W] (or [nb, T, 3, h, w] -> [nb, 3, H, W]: nb clips
+        of one (shape, scale) in one launch sequence)."""
+        self.nb = int(lq.shape[0]) if lq.dim() == 5 else 1
+        assert self.nb <= self.NB_MAX and (self.nb == 1 or taps is None)
+        try:
+            return self._forward_one(lq, scale, out, taps)
+        finally:
+            self.nb = 1
+
+    def _forward_one(self, lq: torch.Tensor, scale, out: torch.Tensor, taps: Optional[dict] = None):
         self._select(lq.shape, scale)
         try:
             c = self._stage_body(lq, scale)
@@ -1299,7 +1409,7 @@ class HipEngine:
         self._stage_satu(c, scale)
         if self.satu_events is not None:
             ev1.record()
-            self.satu_events.append((ev0, ev1))
+            self.satu_events.append((ev0, ev1, self.nb))
         if taps is not None:                    # channel-last [hp][wp][64] tensors; SATU output planar
             taps["align_feat"] = c["align"].t
             taps["h_feat"] = c["hfeat"].t
@@ -1318,7 +1428,16 @@ class HipEngine:
         throughput=True (several clips in flight on different streams): the convs are launched as
         SAVSR_CONV_DIRECT_THROUGHPUT -- the direct kernel's results bit for bit, its own captured graphs.  (Round 4: a launch's conv FORM --
         direct or Winograd-y -- depends on its tile count and on this mode (conv_launch), so a frame in throughput mode can differ from the
-        one-clip flow by the two forms' rounding, ~1e-5; each mode is bitwise reproducible.)"""
+        one-clip flow by the two forms' rounding, ~1e-5; each mode is bitwise reproducible.)
+        lq [nb, T, 3, h, w] / out [nb, 3, H, W]: nb clips of one (shape, scale) in ONE launch sequence (see `nb`), its own context and graphs."""
+        self.nb = int(lq.shape[0]) if lq.dim() == 5 else 1
+        assert self.nb <= self.NB_MAX
+        try:
+            return self._forward_graphed_impl(lq, scale, out, throughput)
+        finally:
+            self.nb = 1
+
+    def _forward_graphed_impl(self, lq: torch.Tensor, scale, out: torch.Tensor, throughput: bool = False):
         sc = self._select(lq.shape, scale)
         if sc["graphs"] is None:
             sc["graphs"] = {}
@@ -1329,7 +1448,7 @@ class HipEngine:
             if used < self.capture_after:            # the context's first frames: eager (see capture_after)
                 sc["uses"][throughput] = used + 1
                 self.host_stats["eager_frames"] += 1
-                return self.forward_one(lq, scale, out)
+                return self._forward_one(lq, scale, out)
             s_in = torch.empty_like(lq)
             s_out = torch.empty_like(out)
             s_in.copy_(lq)
@@ -1390,7 +1509,7 @@ class HipEngine:
         graphs[1].replay()
         if self.satu_events is not None:
             ev1.record()
-            self.satu_events.append((ev0, ev1))
+            self.satu_events.append((ev0, ev1, self.nb))      # (start, end, clips whose SATU stages lie between them)
         graphs[2].replay()
         out.copy_(s_out)
         return out
@@ -1428,20 +1547,46 @@ class HipEngine:
         launches are latency-bound) overlap; results are those of forward() clip by clip."""
         if not self.use_graphs or self.n_streams < 2 or len(items) < 2:
             return [self.forward(lq.unsqueeze(0), sc)[0] for lq, sc in items]
-        ns = min(self.n_streams, len(items))
-        engines = self._ensure_streams(ns)
+        # Launch units: clips of equal (shape, scale) whose LR frame is small enough to be launch-latency-bound go out up to `clip_batch` at a
+        # time in ONE launch sequence (see `nb`); everything else one clip per unit, as before.  Units are dealt round-robin over the streams.
+        units: List[List[int]] = []
+        if self.clip_batch > 1 and self.cfg["interval"] == 0:
+            from collections import OrderedDict
+            groups: "OrderedDict[tuple, List[int]]" = OrderedDict()
+            for i, (lq, sc) in enumerate(items):
+                if lq.shape[-2] * lq.shape[-1] <= self.clip_batch_max_px:
+                    groups.setdefault((tuple(lq.shape), float(sc[0]), float(sc[1])), []).append(i)
+                else:
+                    units.append([i])
+            for idxs in groups.values():
+                units += [idxs[k:k + self.clip_batch] for k in range(0, len(idxs), self.clip_batch)]
+            units.sort(key=lambda u: u[0])
+        else:
+            units = [[i] for i in range(len(items))]
+        ns = min(self.n_streams, len(units))
+        engines = self._ensure_streams(max(ns, 1))
         cur = torch.cuda.current_stream()
-        outs = []
+        outs: List[Optional[torch.Tensor]] = [None] * len(items)
         for lq, sc in items:
             if lq.device != self.dev:
                 raise RuntimeError(f"input on {lq.device}, engine on {self.dev}")
-            H, W = get_hw(lq.shape[-2], lq.shape[-1], sc)
-            outs.append(torch.empty(3, H, W, device=self.dev, dtype=torch.float32))
         for k in range(ns):
             self._streams[k].wait_stream(cur)
-        for i, (lq, sc) in enumerate(items):
-            with torch.cuda.stream(self._streams[i % ns]):
-                engines[i % ns]._forward_graphed(lq.to(torch.float32).contiguous(), sc, outs[i], throughput=True)
+        for u, unit in enumerate(units):
+            k = u % ns
+            sc = items[unit[0]][1]
+            H, W = get_hw(items[unit[0]][0].shape[-2], items[unit[0]][0].shape[-1], sc)
+            with torch.cuda.stream(self._streams[k]):
+                if len(unit) == 1:
+                    i = unit[0]
+                    outs[i] = torch.empty(3, H, W, device=self.dev, dtype=torch.float32)
+                    engines[k]._forward_graphed(items[i][0].to(torch.float32).contiguous(), sc, outs[i], throughput=True)
+                else:
+                    lqb = torch.stack([items[i][0].to(torch.float32) for i in unit], 0)
+                    outb = torch.empty(len(unit), 3, H, W, device=self.dev, dtype=torch.float32)
+                    engines[k]._forward_graphed(lqb, sc, outb, throughput=True)
+                    for j, i in enumerate(unit):
+                        outs[i] = outb[j]
         for k in range(ns):
             cur.wait_stream(self._streams[k])
         return outs
@@ -1457,15 +1602,21 @@ class HipEngine:
         if b >= 2 and self.n_streams >= 2 and self.use_graphs and taps is None:
             # clips are independent (no cross-clip state, savsr_arch.py:705-706): keep n_streams of them in flight
             # on separate HIP streams so one clip's load/store-bound kernel phases overlap another's MFMA phases
-            ns = min(self.n_streams, b)
+            # ... and up to `clip_batch` consecutive clips per launch sequence (see `nb`): the batch shares one (shape, scale)
+            cb = self.clip_batch if (self.cfg["interval"] == 0 and h * w <= self.clip_batch_max_px) else 1
+            units = [(i0, min(i0 + cb, b)) for i0 in range(0, b, cb)]
+            ns = min(self.n_streams, len(units))
             engines = self._ensure_streams(ns)
             cur = torch.cuda.current_stream()
             for k in range(ns):
                 self._streams[k].wait_stream(cur)
                 engines[k].satu_events = self.satu_events
-            for i in range(b):
-                with torch.cuda.stream(self._streams[i % ns]):
-                    engines[i % ns]._forward_graphed(lq[i], scale, out[i], throughput=True)
+            for u, (i0, i1) in enumerate(units):
+                with torch.cuda.stream(self._streams[u % ns]):
+                    if i1 - i0 == 1:
+                        engines[u % ns]._forward_graphed(lq[i0], scale, out[i0], throughput=True)
+                    else:                # (contiguous slices of the batch: no copy)
+                        engines[u % ns]._forward_graphed(lq[i0:i1], scale, out[i0:i1], throughput=True)
             for k in range(ns):
                 cur.wait_stream(self._streams[k])
             return out

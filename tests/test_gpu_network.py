@@ -178,6 +178,7 @@ def test_eager_first_frames_then_capture_bitwise(synth_sd, monkeypatch):
 
     def build(after):
         monkeypatch.setenv("SAVSR_CAPTURE_AFTER", after)
+        monkeypatch.setenv("SAVSR_CLIP_BATCH", "1")              # (one clip per launch sequence: the counts below are per clip)
         n = savsr_amd.build_network(dict(type="SAVSR")).eval()
         n.load_state_dict(synth_sd, strict=True)
         n = n.to("cuda:0")
@@ -201,3 +202,44 @@ def test_eager_first_frames_then_capture_bitwise(synth_sd, monkeypatch):
         assert all(torch.equal(x, y) for x, y in zip(a, b)), k0
     st = lazy.engine().host_stats
     assert st["eager_frames"] == 4 + 3 * 4 and st["captures"] == 1 + 3, st
+
+
+def test_clip_batched_launch_sequence_bitwise(synth_sd, monkeypatch):
+    """SAVSR_CLIP_BATCH: clips of one (shape, scale) run as ONE launch sequence (every named buffer holds a copy per clip, every conv / OSConv
+    descriptor goes out once per clip inside the same batched launch, the per-clip kernels are looped).  The convs of a batched launch are
+    independent, so with ONE conv form everywhere (SAVSR_CONV_WY=0) every clip's output equals the unbatched stream's bit for bit -- groups of
+    3 and 2, a lone clip, odd sizes, an expanded-table scale, captured and replayed; with the product's per-launch form choice (a batched launch
+    has nb x the tiles, so it may take the Winograd-y form where the one-clip launch takes the direct one) the two agree to the forms' rounding."""
+    import random
+    import savsr_amd
+
+    def build(cb, wy):
+        monkeypatch.setenv("SAVSR_CLIP_BATCH", cb)
+        monkeypatch.setenv("SAVSR_CLIP_BATCH_MAX_PX", str(1 << 30))
+        monkeypatch.setenv("SAVSR_CONV_WY", wy)
+        n = savsr_amd.build_network(dict(type="SAVSR")).eval()
+        n.load_state_dict(synth_sd, strict=True)
+        n = n.to("cuda:0")
+        n.engine()
+        return n
+    cases = [(33, 46, (3.3, 2.5), 5), (24, 40, (4.0, 4.0), 3), (30, 44, (1.5, 4.0), 1), (21, 50, (3.7, 3.7), 4)]      # (h, w, scale, clips): groups 3+2, 3, 1, 3+1
+    clips, scales = [], []
+    for h, w, sc, n in cases:
+        for k in range(n):
+            clips.append(synth.synth_clip(7, 3, h, w, seed=100 * h + k)[0].to("cuda:0"))
+            scales.append(sc)
+    order = list(range(len(clips)))
+    random.Random(1).shuffle(order)                              # equal (shape, scale) clips need not be adjacent
+    clips, scales = [clips[i] for i in order], [scales[i] for i in order]
+    for wy, tol in (("0", 0.0), ("1", 3e-5)):
+        one, three = build("1", wy), build("3", wy)
+        assert one.engine().clip_batch == 1 and three.engine().clip_batch == 3
+        for rep in range(3):                                     # capture, replay, replay
+            a = three.forward_many(clips, scales)
+            b = one.forward_many(clips, scales)
+            torch.cuda.synchronize()
+            for i in range(len(clips)):
+                assert tuple(a[i].shape) == tuple(b[i].shape)
+                err = float((a[i] - b[i]).abs().max())
+                assert err <= tol, (wy, rep, i, tuple(clips[i].shape), scales[i], err)
+        assert three.engine().host_stats["captures"] < one.engine().host_stats["captures"]      # fewer, fatter launch sequences

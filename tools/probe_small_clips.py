@@ -12,23 +12,21 @@ import savsr_amd
 from savsr_amd.utils import synth
 dev = torch.device("cuda:0")
 sd = synth.synth_state_dict(seed=0)
-for ns in (1, 3):
-    os.environ["SAVSR_STREAMS"] = str(ns)
+import itertools
+SIZES = [tuple(float(v) if '.' in v else int(v) for v in c.split(',')) for c in os.environ.get('PROBE_SIZES', '64,112,4.0;128,224,2.0;144,180,4.0;180,320,4.0').split(';')]
+for ns, cb in ((3, 1), (3, 3), (3, 2)):
+    os.environ["SAVSR_STREAMS"], os.environ["SAVSR_CLIP_BATCH"], os.environ["SAVSR_CLIP_BATCH_MAX_PX"] = str(ns), str(cb), str(1 << 30)
     net = savsr_amd.build_network(dict(type="SAVSR")).eval(); net.load_state_dict(sd); net = net.to(dev)
-    for (h, w, sc) in ((64, 112, (4.0, 4.0)), (128, 224, (2.0, 2.0)), (180, 320, (4.0, 4.0))):
-        clips = [synth.synth_clip(7, 3, h, w, seed=i)[0].to(dev) for i in range(6)]
+    for (h, w, s_) in SIZES:
+        sc = (float(s_), float(s_))
+        n_clips = 18
+        clips = [synth.synth_clip(7, 3, h, w, seed=i)[0].to(dev) for i in range(n_clips)]
         for _ in range(3):
-            net.forward_many(clips, [sc] * 6)
+            net.forward_many(clips, [sc] * n_clips)
         torch.cuda.synchronize()
         t0 = time.perf_counter(); n = 0
         while time.perf_counter() - t0 < 1.0:
-            net.forward_many(clips, [sc] * 6); n += 6
+            net.forward_many(clips, [sc] * n_clips); n += n_clips
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        # host-only cost: time to ENQUEUE
-        t1 = time.perf_counter()
-        for _ in range(5):
-            net.forward_many(clips, [sc] * 6)
-        t_enq = (time.perf_counter() - t1) / 30
-        torch.cuda.synchronize()
-        print(f"streams {ns} {h}x{w} x{sc[0]}: {n / dt:.1f} clips/s = {1e3 * dt / n:.2f} ms per clip; host enqueue {1e3 * t_enq:.2f} ms per clip", flush=True)
+        print(f"streams {ns} clip_batch {cb} {h}x{w} x{sc[0]}: {n / dt:.1f} clips/s = {1e3 * dt / n:.2f} ms per clip", flush=True)
