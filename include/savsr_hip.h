@@ -185,6 +185,7 @@ typedef struct savsr_osconv_attn_desc {
 int savsr_osconv_weights(const savsr_osconv_attn_desc* d, void* stream);
 /* n (1..6) independent OSConvs of identical cin / cout / hidden / knum in one set of launches (the two
  * propagation directions of a ResidualBlock pair, savsr_arch.py:399-415). */
+int savsr_osconv_weights_max_batch(void);     /* 6 */
 int savsr_osconv_weights_batch(const savsr_osconv_attn_desc* descs, int n, void* stream);
 
 /* RCAN ChannelAttention gate (savsr_arch.py:514-520): gate = sigmoid(W2 ReLU(W1 mean + b1) + b2) */

@@ -24,7 +24,10 @@ struct ConvParams {
     int pool_stride;
 };
 
-constexpr int CONV_MAX_BATCH = 18;     // convs of identical geometry per launch: 6 (both propagation directions x 3 streams of a block) x up to 3 CLIPS of one
+#ifndef SAVSR_CONV_MAX_BATCH
+#define SAVSR_CONV_MAX_BATCH 18
+#endif
+constexpr int CONV_MAX_BATCH = SAVSR_CONV_MAX_BATCH;     // convs of identical geometry per launch: 6 (both propagation directions x 3 streams of a block) x up to 3 CLIPS of one
                                        // (shape, scale) batched into the launches (round 5); 18 x 160 B of descriptors + 36 B < the 4 KB a kernel argument may have
 constexpr int CONV_WIDE_MIN_TILES = 200;       // 16-row tiles are used when a launch has at least this many of them ...
 constexpr int CONV_WIDE_MIN_TILES_TP = 100;    // ... or this many in throughput mode (SAVSR_CONV_DIRECT_THROUGHPUT)

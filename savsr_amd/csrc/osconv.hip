@@ -58,7 +58,10 @@ __device__ __forceinline__ float wave_dot(const float* __restrict__ w, const flo
 
 // Up to OSC_MAX_BATCH OSConvs of identical geometry per launch (blockIdx.y picks one): the two propagation
 // directions' OSConvs are independent, and these kernels are launch/latency-bound (a few dozen workgroups each).
-constexpr int OSC_MAX_BATCH = 6;
+#ifndef SAVSR_OSC_MAX_BATCH
+#define SAVSR_OSC_MAX_BATCH 6
+#endif
+constexpr int OSC_MAX_BATCH = SAVSR_OSC_MAX_BATCH;      // (2 OSConvs of a block pair x up to 3 clips of a batched launch sequence)
 struct OscBatch { savsr_osconv_attn_desc d[OSC_MAX_BATCH]; };
 constexpr int OSC_PARTS = 32;      // interleaved row slices of the pooled-sum reduction
 
@@ -699,9 +702,11 @@ static int check_osconv_desc(const savsr_osconv_attn_desc* d) {
     return 0;
 }
 
+extern "C" int savsr_osconv_weights_max_batch(void) { return OSC_MAX_BATCH; }
+
 extern "C" int savsr_osconv_weights_batch(const savsr_osconv_attn_desc* descs, int n, void* stream) {
     if (!descs) return fail_arg("osconv_weights: null descriptor");
-    if (n < 1 || n > OSC_MAX_BATCH) return fail_arg("osconv_weights: batch size must be 1..6");
+    if (n < 1 || n > OSC_MAX_BATCH) return fail_arg("osconv_weights: batch size must be 1..savsr_osconv_weights_max_batch()");
     OscBatch bt;
     for (int i = 0; i < n; ++i) {
         const int rc = check_osconv_desc(descs + i);

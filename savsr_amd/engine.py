@@ -197,6 +197,8 @@ class HipEngine:
                                "there is no CPU fallback")
         self.lib = _lib.load()
         self.dev = device
+        # clips per batched launch sequence the library's batch limits allow: 6 convs (a block's two directions x 3 streams) and 2 OSConvs per clip
+        self.NB_MAX = max(1, min(int(self.lib.savsr_conv2d_max_batch()) // 6, int(self.lib.savsr_osconv_weights_max_batch()) // 2))
         with torch.cuda.device(device):                      # per device: every kernel's > 64 KiB dynamic-LDS attribute, before any capture
             _lib.check(self.lib.savsr_prepare_device(), "savsr_prepare_device")
         self.cfg = dict(cfg)
@@ -253,7 +255,7 @@ class HipEngine:
         self._streams: List[torch.cuda.Stream] = []
         self._pack_all({k: v.detach() for k, v in state.items()})
 
-    NB_MAX = 3                  # clips per batched launch sequence (6 convs x 3 clips = the 18 of savsr_conv2d_max_batch(); 2 OSConvs x 3 = 6)
+    NB_MAX = 3                  # (class default; the instance reads the library's batch limits: 18 convs / 6 OSConvs per launch => 3 clips)
 
     HR_PLANS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hr_plans.json")
 
@@ -526,6 +528,7 @@ class HipEngine:
         in flight on two HIP streams."""
         e = HipEngine.__new__(HipEngine)
         e.lib, e.dev, e.cfg, e.nf = self.lib, self.dev, self.cfg, self.nf
+        e.NB_MAX = self.NB_MAX
         e.pw, e.se, e._keep = self.pw, self.se, self._keep
         e.pw_wy, e.conv_wy, e.wy_min_tiles, e.wy_min_tiles_tp = self.pw_wy, self.conv_wy, self.wy_min_tiles, self.wy_min_tiles_tp
         e.reuse_buffers, e.osconv_fused = self.reuse_buffers, self.osconv_fused
@@ -913,7 +916,7 @@ class HipEngine:
         """Weight generation of independent OSConvs of identical geometry, up to 6 per set of launches
         (savsr_osconv_weights_batch); returns the conv `weights` tuples."""
         st = self._stream()
-        per = 6 // self.nb                               # OSConvs per set of launches when every one of them goes out once per clip
+        per = max(1, int(self.lib.savsr_osconv_weights_max_batch()) // self.nb)      # OSConvs per set of launches when every one of them goes out once per clip
         for i in range(0, len(descs), per):
             chunk = descs[i:i + per]
             if self.nb > 1:
