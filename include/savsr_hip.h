@@ -198,6 +198,11 @@ int savsr_scale_residual(const float* r, const float* gate, const float* x, floa
 int savsr_se_scale_residual(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
                             const float* w2, const float* b2, int c, int cmid,
                             const float* r, const float* x, float* out, int64_t npx, void* stream);
+/* The same for `nclip` clips of a batched launch sequence in ONE launch (ABI 26): clip b's partial / r / x / out lie b * the given byte strides
+ * (multiples of 16) behind clip 0's; per clip bit-identical to savsr_se_scale_residual. */
+int savsr_se_scale_residual_batch(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, int c, int cmid, const float* r, const float* x, float* out,
+                                  int64_t npx, int nclip, int64_t partial_stride, int64_t r_stride, int64_t x_stride, int64_t out_stride, void* stream);
 
 /* nn.AvgPool2d(2) (savsr_arch.py:193): [h][w][c] -> [h/2][w/2][c], h and w even, contiguous. */
 int savsr_avgpool2(const float* in, float* out, int c, int h, int w, void* stream);

@@ -98,6 +98,8 @@ SIGNATURES = {
     "savsr_se_gate": (C.c_int, [fptr, C.c_int, C.c_float, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, C.c_void_p]),
     "savsr_scale_residual": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int64, C.c_void_p]),
     "savsr_se_scale_residual": (C.c_int, [fptr, C.c_int, C.c_float, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int64, C.c_void_p]),
+    "savsr_se_scale_residual_batch": (C.c_int, [fptr, C.c_int, C.c_float, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int64, C.c_int,
+                                                C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "savsr_avgpool2": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "savsr_upsample2x": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "savsr_pack_windows": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

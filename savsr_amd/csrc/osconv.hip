@@ -621,10 +621,19 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* partial, int
 // pooled partial sums (a 59 KB read from L2 and a few thousand MACs per workgroup, one workgroup per CU) and then scales its
 // share of the pixels: out[px][c] = r[px][c] * gate[c] + x[px][c].  Replaces the se_gate -> scale_residual pair: one launch
 // boundary and one dependent kernel less per RCAB (32 per frame).
+// blockIdx.y = clip of a batched launch sequence (ABI 26: savsr_se_scale_residual_batch); the `*_bs` are BYTES from one clip's operand to the next.
 __global__ __launch_bounds__(1024) void se_scale_residual_kernel(const float* partial, int nblk, float inv_n, const float* w1, const float* b1,
                                                                const float* w2, const float* b2, int c, int cmid, const f32x4* __restrict__ r,
-                                                               const f32x4* __restrict__ x, f32x4* __restrict__ out, long long n4) {
+                                                               const f32x4* __restrict__ x, f32x4* __restrict__ out, long long n4,
+                                                               long long part_bs, long long r_bs, long long x_bs, long long out_bs) {
     __shared__ __attribute__((aligned(16))) float g[128];
+    {
+        const long long cb = blockIdx.y;
+        partial = reinterpret_cast<const float*>(reinterpret_cast<const char*>(partial) + cb * part_bs);
+        r = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(r) + cb * r_bs);
+        x = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x) + cb * x_bs);
+        out = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(out) + cb * out_bs);
+    }
     // The streaming operands do not depend on the gate: the loads of this thread's first SE_UNROLL elements (all of them at
     // 180x320: 3.5 per thread) go out before the gate is evaluated and land under it -- one memory round trip per thread instead
     // of one per element (the loop used to issue two loads, wait, store: 11.5 us for 44 MB).  The result is read by the next
@@ -751,9 +760,12 @@ extern "C" int savsr_se_gate(const float* partial, int nblk, float inv_n, const 
     return check_launch("se_gate_kernel");
 }
 
-extern "C" int savsr_se_scale_residual(const float* partial, int nblk, float inv_n, const float* w1, const float* b1, const float* w2,
-                                       const float* b2, int c, int cmid, const float* r, const float* x, float* out, int64_t npx, void* stream) {
+extern "C" int savsr_se_scale_residual_batch(const float* partial, int nblk, float inv_n, const float* w1, const float* b1, const float* w2,
+                                             const float* b2, int c, int cmid, const float* r, const float* x, float* out, int64_t npx, int nclip,
+                                             int64_t partial_stride, int64_t r_stride, int64_t x_stride, int64_t out_stride, void* stream) {
     if (!partial || !w1 || !b1 || !w2 || !b2 || !r || !x || !out) return fail_arg("se_scale_residual: null pointer");
+    if (nclip < 1 || nclip > 64 || ((partial_stride | r_stride | x_stride | out_stride) & 15) || (nclip > 1 && out_stride == 0))
+        return fail_arg("se_scale_residual_batch: 1..64 clips, strides multiples of 16 bytes, distinct outputs");
     if (c < 4 || c > 128 || (c % 4) || cmid < 1 || cmid > 64 || nblk < 1 || npx < 1) return fail_arg("se_scale_residual: shape (c a multiple of 4, <= 128)");
     if ((reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) {
         set_error("se_scale_residual: r / x / out must be 16-byte aligned");
@@ -762,9 +774,15 @@ extern "C" int savsr_se_scale_residual(const float* partial, int nblk, float inv
     const long long n4 = npx * (c / 4);
     long long g = (n4 + 1023) / 1024;
     if (g > 256) g = 256;                                              // one workgroup per CU: each re-evaluates the gate
-    hipLaunchKernelGGL(se_scale_residual_kernel, dim3((unsigned)g), dim3(1024), 0, static_cast<hipStream_t>(stream), partial, nblk, inv_n, w1, b1, w2, b2,
-                       c, cmid, reinterpret_cast<const f32x4*>(r), reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(out), n4);
+    hipLaunchKernelGGL(se_scale_residual_kernel, dim3((unsigned)g, (unsigned)nclip), dim3(1024), 0, static_cast<hipStream_t>(stream), partial, nblk, inv_n, w1, b1, w2, b2,
+                       c, cmid, reinterpret_cast<const f32x4*>(r), reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(out), n4,
+                       (long long)partial_stride, (long long)r_stride, (long long)x_stride, (long long)out_stride);
     return check_launch("se_scale_residual_kernel");
+}
+
+extern "C" int savsr_se_scale_residual(const float* partial, int nblk, float inv_n, const float* w1, const float* b1, const float* w2,
+                                       const float* b2, int c, int cmid, const float* r, const float* x, float* out, int64_t npx, void* stream) {
+    return savsr_se_scale_residual_batch(partial, nblk, inv_n, w1, b1, w2, b2, c, cmid, r, x, out, npx, 1, 0, 0, 0, 0, stream);
 }
 
 extern "C" int savsr_scale_residual(const float* r, const float* gate, const float* x, float* out, int c, int64_t npx, void* stream) {

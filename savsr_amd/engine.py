@@ -1009,10 +1009,10 @@ class HipEngine:
         w1, b1, w2, b2, cm = self.se[pfx]
         st = self._stream()
         assert x.pix == nf and out.pix == nf
-        pbs = self._bs(part)
-        for b in range(self.nb):                 # (a per-clip kernel: looped over the clips of a batched launch sequence)
-            _lib.check(self.lib.savsr_se_scale_residual(part.data_ptr() + b * pbs, nblk, 1.0 / (hp * wp), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                                        nf, cm, r2.ptr + b * r2.bs, x.ptr + b * x.bs, out.ptr + b * out.bs, hp * wp, st), "savsr_se_scale_residual")
+        # (one launch for all clips of a batched launch sequence: grid.y = clip, byte strides between the clips' operands)
+        _lib.check(self.lib.savsr_se_scale_residual_batch(part.data_ptr(), nblk, 1.0 / (hp * wp), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                          nf, cm, r2.ptr, x.ptr, out.ptr, hp * wp, self.nb, self._bs(part), r2.bs, x.bs, out.bs, st),
+                   "savsr_se_scale_residual")
         return out
 
     def osadapt(self, g: int, x: Src, share: Optional[Src], out: Src, hp: int, wp: int, scale, pooled: bool = False) -> Src:
