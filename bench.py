@@ -685,7 +685,7 @@ def run_run_test(args, rank, world, dev, dist):
             mine = ds.shard(rank, world)
             items = [ds[i]["lq"] for i in mine]
             net.set_scale(dso["downsampling_scale"])
-            g = eng.n_streams
+            g = eng.n_streams * eng.clip_batch              # what a validation call hands forward_many: every stream a unit of clip_batch clips
 
             def region2():
                 for k0 in range(0, len(items), g):

@@ -544,7 +544,7 @@ class HipEngine:
             e.osc[k] = c
         e.se_gate = torch.empty_like(self.se_gate)
         e._init_caches()
-        e.max_shapes, e.max_scales, e._budget = self.max_shapes, self.max_scales, self._budget
+        e.max_shapes, e.max_scales, e._budget, e._axes = self.max_shapes, self.max_scales, self._budget, self._axes
         e.satu_events, e.use_graphs, e.census, e._st = None, self.use_graphs, self.census, None
         e.capture_after, e.host_stats = self.capture_after, self.host_stats
         e.conv_algo = _lib.CONV_DIRECT
@@ -682,7 +682,9 @@ class HipEngine:
             else:
                 arena = owner.setdefault("arena", [])
                 if not arena or arena[-1][1] + nbytes > arena[-1][0].numel():
-                    arena.append([torch.empty(max(nbytes, owner.get("chunk", self.ARENA_CHUNK)), device=self.dev, dtype=torch.uint8), 0])
+                    # (nb clips per launch sequence: nb x the chunk, so that a batched context costs the same handful of allocations -- 26 64-MiB
+                    # hipMallocs inside a capture were 40 ms of a 45 ms capture)
+                    arena.append([torch.empty(max(nbytes, owner.get("chunk", self.ARENA_CHUNK * self.nb)), device=self.dev, dtype=torch.uint8), 0])
                     self._charge(owner, arena[-1][0].numel())
                 chunk, off = arena[-1]
                 raw = chunk[off:off + nbytes]
@@ -1054,11 +1056,24 @@ class HipEngine:
             ent = dict(H=H, W=W, n_uh=len(uh), n_uw=len(uw), uh=up(uh, np.float32), uw=up(uw, np.float32),
                        ih=up(ih.reshape(-1), np.int32), iw=up(iw.reshape(-1), np.int32), gyn=up(gyn, np.float32), gxn=up(gxn, np.float32))
             self._plan_hr_tiling(ent, h, w, scale)
+            # The tables are a function of (size, scale, weights): ONE set for the engines of all streams (the dict is shared with the
+            # siblings: three streams used to build every set three times, 11 ms of host work each).  Another stream's first use waits for
+            # the event below (everything that filled the tables is ordered before it on this engine's stream).
+            ent["ready"] = torch.cuda.Event()
+            ent["ready"].record(torch.cuda.current_stream())
+            ent["seen"] = {id(self)}
             self._axes[key] = ent
             while len(self._axes) > min(64, max(self.max_shapes, self.max_scales)):      # (live graphs hold their own reference: _forward_graphed)
                 self._axes.popitem(last=False)
         else:
             self._axes.move_to_end(key)
+            if id(self) not in ent["seen"] and not torch.cuda.is_current_stream_capturing():
+                cs = torch.cuda.current_stream()
+                cs.wait_event(ent["ready"])
+                for v in ent.values():               # (allocator bookkeeping: this stream reads the tables too)
+                    if isinstance(v, torch.Tensor) and v.is_cuda:
+                        v.record_stream(cs)
+                ent["seen"].add(id(self))
         return ent
 
     HR_TABLE_LDS = 256          # phase tables up to this size live whole in LDS (mirrors satu.hip)
@@ -1471,7 +1486,9 @@ class HipEngine:
             else:
                 self.satu_hr(self.buf("satu.lrcat_tail", h_, w_, _lib.SATU_LRCAT_TAIL), h_, w_, scale,
                              self.sbuf("satu.p27", _lib.TAIL_PLANES, plane_), plane_, tail_form=True)
-            torch.cuda.current_stream().synchronize()
+            # (no host synchronisation here: the capture stream waits for this one -- `_capture` --, and a plan that had to be MEASURED has
+            # synchronised on its own events.  A sync per new context stalled the host behind the units already queued on this stream, 38 ms a
+            # time with three streams in flight: 2.6 s of a 6.5 s cold pass of the YAML workflow, during which the other streams got nothing new.)
             _t1 = _time.perf_counter()
             graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
             ev = self.satu_events
@@ -1561,8 +1578,13 @@ class HipEngine:
                     groups.setdefault((tuple(lq.shape), float(sc[0]), float(sc[1])), []).append(i)
                 else:
                     units.append([i])
-            for idxs in groups.values():
-                units += [idxs[k:k + self.clip_batch] for k in range(0, len(idxs), self.clip_batch)]
+            for idxs in groups.values():       # balanced units (10 clips -> 3 + 3 + 2 + 2, not 3 + 3 + 3 + 1: a lone clip would need a capture of its own)
+                k = -(-len(idxs) // self.clip_batch)
+                base, rem, a = len(idxs) // k, len(idxs) % k, 0
+                for u in range(k):
+                    n = base + (1 if u < rem else 0)
+                    units.append(idxs[a:a + n])
+                    a += n
             units.sort(key=lambda u: u[0])
         else:
             units = [[i] for i in range(len(items))]

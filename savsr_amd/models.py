@@ -136,6 +136,9 @@ class VideoBaseModel(BaseModel):
         # launch takes the same form in both modes (small frames), within the rounding of the direct vs Winograd-y conv forms (~1e-5) otherwise.
         net = self.net_g.module if hasattr(self.net_g, "module") else self.net_g
         group = max(1, int(getattr(net.engine(), "n_streams", 1))) if hasattr(net, "forward_many") else 1
+        # ... and up to `clip_batch` clips of the folder per launch sequence (HipEngine.nb): a call hands forward_many streams x clip_batch clips
+        unit = max(1, int(getattr(net.engine(), "clip_batch", 1))) if group > 1 else 1
+        group_full = group * unit
         folders_all = dataset.data_info["folder"]
         my_folders = list(dict.fromkeys(folders_all[i] for i in mine))
         if hasattr(dataset, "prefetch") and my_folders:
@@ -155,7 +158,11 @@ class VideoBaseModel(BaseModel):
             k1 = k
             while k1 < len(mine) and folders_all[mine[k1]] == f0:
                 k1 += 1
-            g_f = group if k1 - k >= 4 * group else (min(group, 2) if k1 - k >= 6 else 1)
+            n_f = k1 - k
+            if unit > 1:        # every stream a unit of `unit` clips per call; a shorter block goes to forward_many whole (it cuts balanced units: 4 -> 2 + 2)
+                g_f = group_full if n_f >= 2 * group_full else n_f
+            else:
+                g_f = group if n_f >= 4 * group else (min(group, 2) if n_f >= 6 else 1)
             fc = [(a, min(a + g_f, k1)) for a in range(k, k1, g_f)]
             if g_f > 1 and len(fc) >= 2 and fc[-1][1] - fc[-1][0] == 1:
                 # a lone leftover frame (34 or 40 frames over 3 streams) would go through test() = the one-clip graphs, a second set of
