@@ -1,0 +1,108 @@
+"""Soak run of the product path: a long, randomised stream of clips through `forward_many` under a byte budget that forces evictions, and
+what a production user would watch for afterwards (`gpurun -- python3 tools/soak.py [--seconds 120] [--cache-gb 6]`).
+
+Stream: seeded draws from BASELINE config 5's training list (51 LR shapes x 60 scale pairs at GT 256x448, savsr_amd/utils/workloads.py), every
+eighth call a block of Vid4-sized clips (180x320, a YAML scale) so that batched contexts (3 clips per launch sequence) and large arenas are
+created and dropped between the small ones.  A clip's pixels are a function of (shape, k) with k in 0..2, so every (shape, scale, k) recurs.
+
+Checks (the exit code is non-zero if one fails):
+  * every output equals the first output of the same (shape, scale, k) -- across evictions, re-captures, other streams: BITWISE when the
+    launch sequence chose the same conv forms, and within 3e-5 otherwise (the engine picks Winograd-y or the direct kernel per LAUNCH by its tile
+    count, savsr_amd/engine.py conv_launch, so a clip that travels with two equal-shaped clips can take the other form for some convs; with
+    SAVSR_CONV_WY=0 in the environment there is one form and the run demands bitwise equality throughout);
+  * the budget account equals the sum of the engines' resident contexts and never exceeds limit + the contexts in use;
+  * device memory (torch reserved, and the driver's used bytes) in the last quarter of the run is not above the first quarter's peak by more
+    than one context -- i.e. nothing grows with the number of clips;
+  * no exception on the way.
+Prints one JSON line (kept as profiles/rNN_soak.json)."""
+import argparse, json, os, random, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0)
+ap.add_argument("--cache-gb", type=float, default=6.0)
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+os.environ["SAVSR_CACHE_GB"] = str(args.cache_gb)
+
+import torch
+import savsr_amd
+from savsr_amd.utils import synth, workloads as W
+
+dev = torch.device("cuda:0")
+sd = synth.synth_state_dict(seed=0)
+net = savsr_amd.build_network(dict(type="SAVSR")).eval()
+net.load_state_dict(sd)
+net = net.to(dev)
+eng = net.engine()
+rng = random.Random(args.seed)
+
+
+def clip(h, w, k):
+    return synth.synth_clip(7, 3, h, w, seed=1000 * h + w + 7919 * k)[0].to(dev)
+
+
+def digest(t):
+    """64-bit fingerprint of an output's bits (two independent integer sums of the fp32 bit patterns): bitwise-equal outputs, equal digests."""
+    b = t.contiguous().view(torch.int32).to(torch.int64).flatten()
+    idx = torch.arange(b.numel(), device=b.device, dtype=torch.int64)
+    return int(b.sum().item()), int((b * ((idx % 8191) + 1)).sum().item())
+
+
+first, clips_done, calls, mism = {}, 0, 0, []
+strict = os.environ.get("SAVSR_CONV_WY", "1") == "0"
+n_form, worst_form = 0, 0.0
+mem, acct_bad, largest = [], [], 0
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < args.seconds:
+    calls += 1
+    if calls % 8 == 0:
+        sc = W.YAML_SCALES[rng.randrange(len(W.YAML_SCALES))]
+        items = [(180, 320, sc, rng.randrange(3)) for _ in range(rng.choice((3, 6, 9)))]
+    else:
+        items = [(h, w, sc, rng.randrange(3)) for (h, w, sc) in W.config5_cases(rng.choice((4, 9, 14)), seed=rng.randrange(1 << 30))]
+    with torch.no_grad():
+        outs = net.forward_many([clip(h, w, k) for (h, w, sc, k) in items], [sc for (_, _, sc, _) in items])
+    for it, o in zip(items, outs):
+        d = digest(o)
+        d0, o0 = first.setdefault(it, (d, o.clone()))
+        if d0 != d:
+            err = float((o - o0).abs().max())
+            if strict or not err < 3e-5:
+                mism.append(f"{it}: max-abs {err:.3g}")
+            else:
+                n_form += 1
+                worst_form = max(worst_form, err)
+    clips_done += len(items)
+    st = eng.cache_stats()
+    total = sum(e.cache_stats()["bytes"] for e in [eng] + eng._siblings)
+    largest = max([largest] + [e._ctx_bytes(c) for e in [eng] + eng._siblings for c in e._ctx.values()])
+    if total != st["budget_used"]:
+        acct_bad.append((calls, total, st["budget_used"]))
+    free_b, total_b = torch.cuda.mem_get_info()
+    mem.append((time.perf_counter() - t0, torch.cuda.memory_reserved(), total_b - free_b, st["budget_used"]))
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+q = max(1, len(mem) // 4)
+peak = lambda rows, i: max(r[i] for r in rows)
+st = eng.cache_stats()
+hs = {k: round(v, 3) if isinstance(v, float) else v for k, v in eng.host_stats.items()} if hasattr(eng, "host_stats") else {}
+grow_reserved = peak(mem[-q:], 1) - peak(mem[:q], 1)
+grow_used = peak(mem[-q:], 2) - peak(mem[:q], 2)
+one_ctx = 2 << 30
+res = {"tool": "soak", "seconds": round(wall, 1), "calls": calls, "clips": clips_done, "clips_per_s": round(clips_done / wall, 1),
+       "distinct_shape_scale_clip": len(first), "mismatches": len(mism), "mismatch_sample": mism[:5], "bitwise_demanded": strict,
+       "other_conv_form_revisits": n_form, "other_conv_form_worst_max_abs": worst_form,
+       "cache_gb": args.cache_gb, "evictions": st["evictions"], "resident_shapes_end": st["shapes"],
+       "budget_used_peak_gb": round(peak(mem, 3) / 2**30, 3), "budget_limit_gb": round(st["budget_limit"] / 2**30, 3),
+       "account_mismatches": len(acct_bad),
+       "reserved_gb_first_quarter_peak": round(peak(mem[:q], 1) / 2**30, 3), "reserved_gb_last_quarter_peak": round(peak(mem[-q:], 1) / 2**30, 3),
+       "device_used_gb_first_quarter_peak": round(peak(mem[:q], 2) / 2**30, 3), "device_used_gb_last_quarter_peak": round(peak(mem[-q:], 2) / 2**30, 3),
+       "host_stats": hs}
+res["largest_context_gb"] = round(largest / 2**30, 3)
+over_budget = peak(mem, 3) > st["budget_limit"] + (1 + len(eng._siblings)) * largest        # (limit + what the streams have in use)
+res["over_budget"] = bool(over_budget)
+ok = not mism and not acct_bad and not over_budget and grow_reserved <= one_ctx and grow_used <= one_ctx
+res["ok"] = bool(ok)
+print(json.dumps(res), flush=True)
+sys.exit(0 if ok else 1)
