@@ -38,6 +38,18 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.savsr_version()
 
 
+def test_every_entry_point_has_a_row_in_integration_md():
+    """INTEGRATION.md shows the reference-side binding: every product entry point of the header is named there beside what it replaces."""
+    hdr = open(os.path.join(ROOT, "include", "savsr_hip.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    hdr = re.sub(r"#ifdef SAVSR_DIAG\n(.*?)#endif /\* SAVSR_DIAG \*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(savsr_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) > 40
+    missing = sorted(n for n in declared if n not in doc)
+    assert not missing, missing
+
+
 def test_pack_index_matches_c_abi():
     lib = _lib.load()
     rng = np.random.RandomState(0)
