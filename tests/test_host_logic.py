@@ -136,6 +136,24 @@ def test_axis_tables_match_oracle_bitwise():
         assert np.array_equal(b[2], g.numpy())
 
 
+def test_axis_tables_match_oracle_bitwise_on_every_listed_scale():
+    """The same bit-for-bit comparison (fp32 coordinate features, integer LR grid, output size) on every scale pair the reference's lists hold,
+    at the sizes they are used on: the 42 YAML pairs at LR 180x320 and 144x180 (Vid4's two LR sizes at x4), the 60 training pairs at the LR
+    size their as-mod-crop of the 256x448 GT gives (the integer coordinate grid is bit-exact)."""
+    from oracle import savsr_oracle as O
+    from savsr_amd.utils import workloads as WL
+    cases = [(h, w, sc) for sc in WL.YAML_SCALES for (h, w) in ((180, 320), (144, 180))]
+    cases += [WL.lr_shape(WL.VIMEO_GT, sc) + (sc,) for sc in WL.TRAIN_SCALES]
+    assert len(cases) == 2 * 42 + 60
+    for h, w, sc in cases:
+        H, W, ch, cw, fh, fw = O.satu_coords(h, w, sc)
+        assert (H, W) == E.get_hw(h, w, sc), (h, w, sc)
+        a = E.satu_axis_tables(H, h, sc[0])
+        b = E.satu_axis_tables(W, w, sc[1])
+        assert np.array_equal(a[0], ch.numpy()) and np.array_equal(b[0], cw.numpy()), (h, w, sc)
+        assert np.array_equal(a[1], np.asarray(fh).reshape(-1)) and np.array_equal(b[1], np.asarray(fw).reshape(-1)), (h, w, sc)
+
+
 def test_registry_and_state_dict_surface():
     net = savsr_amd.build_network(dict(type="SAVSR", num_in_ch=3, num_feat=64, num_frame=7, slid_win=3, fusion_win=5,
                                        interval=0, w1_num_block=4, w2_num_block=2, n_resgroups=4, n_resblocks=8,
