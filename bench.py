@@ -469,8 +469,24 @@ def run_config2(args, rank, world, dev, dist):
     if world == 1 and not args.no_cpu_baseline:
         threads = effective_cpus()
         cb, ref, lq_c = cpu_baseline(sd, threads)
-        got = net(lq_c.to(dev))
-        cb["gpu_vs_oracle_max_abs_on_sample"] = float((got.cpu() - ref).abs().max())
+        # The oracle on the path the headline TIMES: clips[0][0] is the oracle sample's clip (seed 0), so the output of one more step of the timed
+        # configuration (b = cps clips: n_streams streams x clip_batch clips per launch sequence, throughput tiling, ~99 % Winograd-y) is compared
+        # with it directly; the one-clip latency flow's figure (another tiling, other per-launch form choices) stays beside it under its own name.
+        assert torch.equal(clips[0][0].cpu(), lq_c[0]), "clips[0][0] of the timed step is the oracle sample's clip"
+        got_t = step(0, False)[0].cpu()
+        got_1 = net(lq_c.to(dev))[0].cpu()
+        from savsr_amd.metrics import calculate_psnr, calculate_ssim, tensor2img
+        gti = tensor2img(gt.cpu())
+        m = {k: (calculate_psnr(tensor2img(v), gti, 0, test_y_channel=True), calculate_ssim(tensor2img(v), gti, 0, test_y_channel=True))
+             for k, v in (("gpu", got_t), ("oracle", ref[0]))}
+        cb["gpu_vs_oracle_max_abs_timed_path"] = float((got_t - ref[0]).abs().max())
+        cb["gpu_vs_oracle_max_abs_on_sample"] = cb["gpu_vs_oracle_max_abs_timed_path"]
+        cb["gpu_vs_oracle_max_abs_one_clip_flow"] = float((got_1 - ref[0]).abs().max())
+        cb["d_psnr_y_timed_path_vs_oracle"] = abs(m["gpu"][0] - m["oracle"][0])
+        cb["d_ssim_y_timed_path_vs_oracle"] = abs(m["gpu"][1] - m["oracle"][1])
+        cb["timed_path_note"] = (f"clip 0 of a step of the timed configuration ({cps} clips per step, {min(cps, eng.n_streams)} streams x {eng.clip_batch} clips per launch "
+                                 "sequence) against the oracle's output for the same clip; PSNR-Y / SSIM-Y of both against the synthetic GT (host metrics)")
+        line["gpu_vs_oracle_max_abs_timed_path"] = cb["gpu_vs_oracle_max_abs_timed_path"]
         line["cpu_baseline"] = cb
     print(json.dumps(line), flush=True)
 
@@ -568,6 +584,24 @@ def run_config5(args, rank, world, dev, dist):
                      "resident_contexts_all_streams": sum(e.cache_stats()["scales"] for e in [eng] + eng._siblings),
                      "note": "product defaults: SAVSR_CACHE_GB unset = half of the free HBM at engine build, shared by the stream engines"}
     line["roofline"] = None
+    if world == 1 and not args.no_cpu_baseline:
+        # the oracle on the timed path: the two most frequent (shape, scale) groups of the stream, each clip 0 of its group as a step of the timed
+        # region delivers it (bucketed, batched into launch sequences), against the oracle's output for the same clip
+        from collections import Counter
+        from oracle import savsr_oracle as O
+        torch.set_num_threads(effective_cpus())
+        checks = []
+        for k, cnt in Counter(draws).most_common(2):
+            i = next(i for i in range(args.steps) if k in draws[i * cps:(i + 1) * cps])
+            ks = draws[i * cps:(i + 1) * cps]
+            outs = net.forward_many([clips[q][0] for q in ks], [q[2] for q in ks])
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                ref = O.forward(sd, clips[k].cpu(), k[2])
+            checks.append({"lr": [k[0], k[1]], "scale": list(k[2]), "clips_of_this_pair_in_the_step": ks.count(k), "draws_of_this_pair": cnt,
+                           "max_abs": float((outs[ks.index(k)].cpu() - ref[0]).abs().max())})
+        line["gpu_vs_oracle_timed_path"] = checks
+        line["gpu_vs_oracle_max_abs_timed_path"] = max(c["max_abs"] for c in checks)
     print(json.dumps(line), flush=True)
 
 
@@ -576,22 +610,36 @@ VID4_SHAPES = [("calendar", 576, 720), ("city", 576, 704), ("foliage", 480, 720)
 RUN_TEST_SCALES = [(4, 4), (3.5, 3.5), (3, 3), (2.5, 2.5), (2, 2), (1.5, 4)]
 
 
-def make_png_tree(root, frames_per_folder):
+VID4_FRAMES = [41, 34, 49, 47]                   # frames of the four Vid4 folders (calendar, city, foliage, walk)
+
+
+def job_dims(args):
+    """(scales, frames per folder) of the synthetic job: --yaml-dims = the shipped Vid4 YAML's own dimensions (42 datasets = 30 symmetric + 12
+    asymmetric scales over folders of 41 / 34 / 49 / 47 frames, options/test/SAVSR/test_SAVSR_Vid4_asBI.yml:24-826), else 6 scales x 4 folders of
+    --frames-per-folder frames."""
+    if args.yaml_dims:
+        from savsr_amd.utils import workloads
+        return list(workloads.YAML_SCALES), list(VID4_FRAMES)
+    return list(RUN_TEST_SCALES), [args.frames_per_folder] * len(VID4_SHAPES)
+
+
+def make_png_tree(root, frames):
     """Synthetic Vid4-shaped ground truth: per folder one smooth base image, each frame a shifted crop of it (a panning
-    camera), written as PNG through the product's own writer."""
+    camera), written as PNG through the product's own writer.  frames: per-folder frame counts."""
     import numpy as np
     from savsr_amd import io as sio
     from savsr_amd.utils import synth
     for k, (name, H, W) in enumerate(VID4_SHAPES):
+        frames_per_folder = frames[k]
         base = (synth.synth_gt(3, H + 2 * frames_per_folder, W + 2 * frames_per_folder, seed=40 + k).numpy() * 255.0).round().astype(np.uint8)
         for i in range(frames_per_folder):
             img = base[:, 2 * i: 2 * i + H, i: i + W].transpose(1, 2, 0)[:, :, ::-1]          # HWC BGR, as cv2 / tensor2img hand it over
             sio.imwrite(np.ascontiguousarray(img), os.path.join(root, "GT", name, f"{i:08d}.png"))
 
 
-def run_test_opt(root, ckpt, save_img):
+def run_test_opt(root, ckpt, save_img, scales=None):
     ds = {}
-    for i, sc in enumerate(RUN_TEST_SCALES):
+    for i, sc in enumerate(scales if scales is not None else RUN_TEST_SCALES):
         ds[f"test_{i + 1:02d}"] = dict(name=f"Vid4_x{sc[0]}_{sc[1]}", type="ASVideoTestDataset", dataroot_gt=os.path.join(root, "GT"),
                                        dataroot_lq=os.path.join(root, "unused"), io_backend=dict(type="disk"), cache_data=False, num_frame=7,
                                        padding="reflection", use_arbitrary_scale_downsampling=True, downsampling_scale=tuple(sc),
@@ -625,13 +673,14 @@ def run_run_test(args, rank, world, dev, dist):
         dist.broadcast_object_list(box, src=0)
         root = box[0]
     try:
+        scales, frames = job_dims(args)
         if rank == 0 and own_tree:
-            make_png_tree(root, args.frames_per_folder)
+            make_png_tree(root, frames)
             sd = synth.synth_state_dict(seed=0)
             torch.save({"params": sd}, os.path.join(root, "net.pth"))
         if dist is not None:
             dist.barrier()
-        opt = run_test_opt(root, os.path.join(root, "net.pth"), args.save_img)
+        opt = run_test_opt(root, os.path.join(root, "net.pth"), args.save_img, scales)
         opt["rank"], opt["world_size"], opt["dist"] = rank, world, dist is not None
         if emu:
             opt["rank"], opt["world_size"], opt["dist"], opt["emulate_world"] = args.emulate_rank, args.emulate_world, False, True    # (no process group)
@@ -640,11 +689,8 @@ def run_run_test(args, rank, world, dev, dist):
         model = M.build_model(opt)            # one model (= one engine, its graphs) across the passes, as in one long YAML
         model_box = {"m": model}
         passes = []
-        n_frames = len(VID4_SHAPES) * args.frames_per_folder * len(RUN_TEST_SCALES)
-        hr_px = sum(round_hw(H, W, sc) for _, H, W in VID4_SHAPES for sc in RUN_TEST_SCALES) * args.frames_per_folder
-        if emu:                                # this rank's share: per folder block [r n / N, (r + 1) n / N)
-            per_folder = ((rank_e + 1) * args.frames_per_folder) // world_e - (rank_e * args.frames_per_folder) // world_e
-            n_frames = len(VID4_SHAPES) * per_folder * len(RUN_TEST_SCALES)
+        n_frames = sum(frames) * len(scales)
+        hr_px = sum(round_hw(H, W, sc) * nf for (_, H, W), nf in zip(VID4_SHAPES, frames) for sc in scales)
         results = None
         for p in range(2):
             if "m" in model_box:
@@ -671,7 +717,14 @@ def run_run_test(args, rank, world, dev, dist):
                            "png_decoded_rank0": st1["decoded"] - st0["decoded"], "uploaded_rank0": st1["uploaded"] - st0["uploaded"],
                            "host_stats_cumulative": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in hs.items()}})
         if emu:                                # the child of --emulate-world: its passes are the result
-            print(json.dumps({"emulated_world": world_e, "emulated_rank": rank_e, "frames": n_frames, "cold_pass": passes[0], "steady_pass": passes[1]}), flush=True)
+            plan = model.last_plan             # (harness.plan_job: the (dataset, folder) segments of this rank)
+            segs = plan["segments"][rank_e]
+            mine = sum(hi - lo for _, _, lo, hi in segs)
+            for ps in passes:
+                ps["frames_per_s"] = round(mine / ps["wall_s"], 2)
+            print(json.dumps({"emulated_world": world_e, "emulated_rank": rank_e, "frames": mine, "segments": len(segs),
+                              "folders": sorted({f for _, f, _, _ in segs}), "planned_cost_share": round(plan["cost"][rank_e] / max(sum(plan["cost"]), 1e-9), 4),
+                              "cold_pass": passes[0], "steady_pass": passes[1]}), flush=True)
             return
         # the same frames through the network alone (inputs resident in HBM, groups of n_streams clips in flight, no metrics):
         # what the workflow would run at if everything around the path were free
@@ -682,7 +735,7 @@ def run_run_test(args, rank, world, dev, dist):
         for dsname, dso in sorted(opt["datasets"].items()):
             from savsr_amd.datasets import build_dataset
             ds = build_dataset(dict(dso))
-            mine = ds.shard(rank, world)
+            mine = ds.shard_frames(model.last_plan["owners"][sorted(opt["datasets"]).index(dsname)][rank])
             items = [ds[i]["lq"] for i in mine]
             net.set_scale(dso["downsampling_scale"])
             g = eng.n_streams * eng.clip_batch              # what a validation call hands forward_many: every stream a unit of clip_batch clips
@@ -700,9 +753,9 @@ def run_run_test(args, rank, world, dev, dist):
             return
         warm = passes[1]
         line = base_line(args, world, hr_px / warm["wall_s"] / 1e6, warm["wall_s"],
-                         "YAML workflow run_test(opt): synthetic Vid4-shaped PNG tree (4 folders), 6 datasets = scales "
-                         + ", ".join(f"x{a}/{b}" for a, b in RUN_TEST_SCALES) + " over one dataroot_gt, ASVideoTestDataset + ASVSRModel, PSNR-Y / SSIM-Y",
-                         {"frames_per_folder": args.frames_per_folder, "frames": n_frames, "save_img": bool(args.save_img),
+                         f"YAML workflow run_test(opt): synthetic Vid4-shaped PNG tree (4 folders of {frames} frames), {len(scales)} datasets = scales "
+                         + ", ".join(f"x{a}/{b}" for a, b in scales) + " over one dataroot_gt, ASVideoTestDataset + ASVSRModel, PSNR-Y / SSIM-Y",
+                         {"frames_per_folder": frames, "frames": n_frames, "save_img": bool(args.save_img),
                           "decode_threads": sio.frame_store().workers, "streams_per_gpu": eng.n_streams})
         line["metric"] = "HR Mpixels/sec (YAML workflow, steady-state pass)"
         line["steps"], line["warmup"], line["ms_per_step"] = 1, 1, round(1e3 * warm["wall_s"], 1)
@@ -727,22 +780,26 @@ def run_run_test(args, rank, world, dev, dist):
 def run_emulate_world(args, argv):
     """`--config run_test --emulate-world N` without --emulate-rank: the part of the 1 -> N strong-scaling curve of the YAML flow that one GPU
     can know in advance.  Fresh child processes (what a rank is: its own decode cache, engine, captures, HR plan choices), one at a time on
-    the one GPU, over ONE PNG tree: the whole job (world 1) and rank 0 / rank N - 1 of a world-size-N run, each its block partition alone
-    (harness.block_partition; the collective -- a [n, 2] all_gather per dataset -- is left out).  predicted efficiency = T(1) / (N x max_r T_r),
-    for the cold pass (what `python -m savsr_amd.test -opt <yaml>` is) and for the steady one."""
+    the one GPU, over ONE PNG tree: the whole job (world 1) and the ranks of a world-size-N run, each its share of the job plan alone
+    (harness.plan_job: (dataset, folder) units, folder-major, cost-balanced; the collective -- ONE all_gather of the metric rows per job -- is
+    left out).  `--emulate-ranks all` (default with --yaml-dims) times every rank, `ends` ranks 0 and N - 1.  predicted efficiency =
+    T(1) / (N x max_r T_r), for the cold pass (what `python -m savsr_amd.test -opt <yaml>` is) and for the steady one."""
     import shutil
     import subprocess
     import tempfile
     from savsr_amd.utils import synth
     n = args.emulate_world
+    scales, frames = job_dims(args)
     root = tempfile.mkdtemp(prefix="savsr_bench_emu_")
     try:
-        make_png_tree(root, args.frames_per_folder)
+        make_png_tree(root, frames)
         torch.save({"params": synth.synth_state_dict(seed=0)}, os.path.join(root, "net.pth"))
         runs = {}
-        for w, r in [(1, 0), (n, 0), (n, n - 1)]:
+        which = args.emulate_ranks or ("all" if args.yaml_dims else "ends")
+        ranks_run = list(range(n)) if which == "all" else sorted({0, n - 1})
+        for w, r in [(1, 0)] + [(n, r) for r in ranks_run]:
             cmd = [sys.executable, os.path.abspath(__file__), "--config", "run_test", "--emulate-world", str(w), "--emulate-rank", str(r),
-                   "--tree", root, "--frames-per-folder", str(args.frames_per_folder)] + (["--save-img"] if args.save_img else [])
+                   "--tree", root, "--frames-per-folder", str(args.frames_per_folder)] + (["--save-img"] if args.save_img else []) + (["--yaml-dims"] if args.yaml_dims else [])
             p = subprocess.run(cmd, capture_output=True, text=True)
             if os.environ.get("SAVSR_BENCH_PROFILE"):
                 print(f"==== world {w} rank {r}\n" + p.stderr[-9000:], file=sys.stderr, flush=True)
@@ -751,25 +808,28 @@ def run_emulate_world(args, argv):
                 sys.exit(p.returncode)
             runs[(w, r)] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
         one = runs[(1, 0)]
-        ranks = [runs[(n, 0)], runs[(n, n - 1)]]
+        ranks = [runs[(n, r)] for r in ranks_run]
         line = {"metric": f"predicted strong-scaling efficiency of the YAML flow at world size {n} (one GPU, ranks emulated one at a time)",
                 "unit": "fraction of linear", "n_gpus": 1, "higher_is_better": True, "bench_config": "run_test --emulate-world",
-                "emulated_world": n, "data": "synthetic", "frames_per_folder": args.frames_per_folder, "world1": one, "ranks": ranks}
+                "emulated_world": n, "data": "synthetic", "frames_per_folder": frames, "datasets": len(scales), "ranks_timed": ranks_run,
+                "partition": "harness.plan_job: (dataset, folder) units folder-major on one line, cut into N pieces of equal modelled cost",
+                "world1": one, "ranks": ranks}
         for name in ("cold_pass", "steady_pass"):
             t1 = one[name]["wall_s"]
             tr = max(x[name]["wall_s"] for x in ranks)
             line["predicted_strong_scaling_eff_" + name.split("_")[0]] = round(t1 / (n * tr), 4)
+            line["rank_wall_s_" + name.split("_")[0]] = [x[name]["wall_s"] for x in ranks]
         slow = max(ranks, key=lambda x: x["cold_pass"]["wall_s"])
         hs = slow["cold_pass"]["host_stats_cumulative"]
         ideal = one["cold_pass"]["wall_s"] / n
         line["value"] = line["predicted_strong_scaling_eff_cold"]
         line["loss_breakdown_cold_slowest_rank"] = {
-            "rank_wall_s": slow["cold_pass"]["wall_s"], "ideal_s (T1 / N)": round(ideal, 3), "graph_capture_s": hs["capture_s"], "hr_plan_timing_s": hs["plan_s"],
+            "rank": slow["emulated_rank"], "rank_wall_s": slow["cold_pass"]["wall_s"], "ideal_s (T1 / N)": round(ideal, 3), "graph_capture_s": hs["capture_s"], "hr_plan_timing_s": hs["plan_s"],
             "captures": hs["captures"], "eager_frames": hs["eager_frames"], "png_decoded": slow["cold_pass"]["png_decoded_rank0"],
-            "gpu_busy_frac": slow["cold_pass"]["gpu_busy_frac"],
-            "note": "what a rank pays per (folder, scale) whatever its share of the frames: PNG decode of its block + window reach, the first frame's "
-                    "buffer plan and table upload, graph captures (after SAVSR_CAPTURE_AFTER eager frames) and HR plan timing (scales missing from "
-                    "savsr_amd/hr_plans.json); the collective (one [n, 2] all_gather per dataset) is not in the emulation"}
+            "gpu_busy_frac": slow["cold_pass"]["gpu_busy_frac"], "frames": slow["frames"], "segments": slow["segments"], "folders": slow["folders"],
+            "note": "what a rank pays per (folder, scale) context it owns whatever its share of the frames: PNG decode of its folders, the first frame's "
+                    "buffer plan and table upload, graph captures and HR plan timing (scales missing from savsr_amd/hr_plans.json); "
+                    "the collective (one all_gather of the job's metric rows) is not in the emulation"}
         print(json.dumps(line), flush=True)
     finally:
         shutil.rmtree(root, ignore_errors=True)
@@ -815,6 +875,9 @@ def main():
     ap.add_argument("--save-img", action="store_true", help="run_test: also write every output frame as PNG (val.save_img)")
     ap.add_argument("--emulate-world", type=int, default=0, help="run_test on ONE GPU: time the whole job and ranks 0 / N-1 of a world-size-N run in fresh "
                                                                  "processes, report the predicted strong-scaling efficiency")
+    ap.add_argument("--yaml-dims", action="store_true", help="run_test: the shipped Vid4 YAML's dimensions (42 scales; folders of 41 / 34 / 49 / 47 frames) "
+                                                            "instead of 6 scales x --frames-per-folder")
+    ap.add_argument("--emulate-ranks", type=str, default="", choices=["", "all", "ends"], help="--emulate-world: time every rank or ranks 0 and N - 1")
     ap.add_argument("--emulate-rank", type=int, default=-1, help="(internal: the child of --emulate-world that runs one rank's share)")
     ap.add_argument("--tree", type=str, default="", help="(internal: an existing synthetic PNG tree + net.pth)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

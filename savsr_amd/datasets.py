@@ -120,6 +120,46 @@ class VideoTestDataset:
         self._resident.clear()
         return owned
 
+    def shard_frames(self, owned: List[int]) -> List[int]:
+        """Like shard(), for ANY set of owned global frame indices (the job plan of a whole YAML, harness.plan_job, hands a rank whole
+        folders of some datasets and nothing of others): from here on this object only decodes / uploads / synthesises the frames the
+        windows of `owned` read."""
+        owned = sorted(int(g) for g in owned)
+        self._need = {}
+        base = 0
+        for name, paths in self.imgs_gt.items():
+            n = len(paths)
+            local = [g - base for g in owned if base <= g < base + n]
+            self._need[name] = needed_frames(local, n, self.opt["num_frame"], self.opt["padding"])
+            base += n
+        self._resident.clear()
+        return owned
+
+    def release_resident(self) -> None:
+        """Drop the folders this object keeps in HBM (the job plan walks (dataset, folder) segments: a dataset is not revisited soon)."""
+        self._resident.clear()
+
+    def _unit_sizes(self, folder: str, H: int, W: int):
+        """(LR size, HR size) of a frame of `folder` whose GT file is H x W (for the job plan's cost model only)."""
+        if self.imgs_lq[folder] is not self.imgs_gt[folder] and self.imgs_lq[folder]:
+            return sio.image_size(self.imgs_lq[folder][0]), (H, W)
+        return (H, W), (H, W)
+
+    def units(self, d: int = 0) -> List[dict]:
+        """The (dataset, folder) units of this dataset for harness.plan_job: folder, first global frame index, frame count, cost of a frame
+        (from the image headers; nothing is decoded) and `group` = the identity of the folder's files, equal for every dataset of a YAML
+        that reads the same `dataroot_gt` folder."""
+        from .harness import frame_cost
+        out, base = [], 0
+        for name, paths in self.imgs_gt.items():
+            n = len(paths)
+            if n:
+                H, W = sio.image_size(paths[0])
+                lr, hr = self._unit_sizes(name, H, W)
+                out.append(dict(dataset=d, folder=name, group=(osp.abspath(self.gt_root), name), base=base, frames=n, cost=frame_cost(lr, hr)))
+            base += n
+        return out
+
     def needed(self, folder: str) -> List[int]:
         """Frames of `folder` this object loads (all of them until shard() narrows it)."""
         need = getattr(self, "_need", None)
@@ -222,6 +262,14 @@ class ASVideoTestDataset(VideoTestDataset):
         if self.opt.get("cache_data"):
             return True
         return bool(self.opt["use_arbitrary_scale_downsampling"])
+
+    def _unit_sizes(self, folder: str, H: int, W: int):
+        scale = self.opt["scale"]
+        scale = tuple(scale) if isinstance(scale, (tuple, list)) else (scale, scale)
+        crop = (not self.cache_data) or self.as_down
+        hr = as_mod_crop_hw(H, W, scale) if crop else (H, W)
+        lr = (round(hr[0] / scale[0]), round(hr[1] / scale[1])) if self._synthesise() else hr
+        return lr, hr
 
     def _read_lists(self, folder: str) -> List[List[str]]:
         return [self.imgs_gt[folder]]                    # GT only: without synthesis the GT frames ARE the network input (video_test_dataset.py:308-313)

@@ -79,7 +79,7 @@ def conv_pack_index(cout: int, cin: int, ks: int):
         group = (((cob * nchunk + chunk) * taps + tap) * ksteps + kstep) * nt + t
         idx = group * 512 + (kh * 32 + row) * 8 + j
         total = ncob * nchunk * taps * kc * cot
-        _PACK_IDX_CACHE[key] = (np.ascontiguousarray(np.broadcast_to(idx, (cout, cin, taps))).reshape(-1), total)
+        _PACK_IDX_CACHE[key] = (np.array(np.broadcast_to(idx, (cout, cin, taps))).reshape(-1), total)      # (a writable copy: torch.from_numpy warns on read-only views)
     return _PACK_IDX_CACHE[key]
 
 
@@ -153,7 +153,7 @@ def conv_wy_pack_index(cout: int, cin: int):
         group = (((cob * nchunk + chunk) * 2 + hf) * 6 + (vr * 3 + kx)) * 2 + t
         idx = group * 512 + (kh * 32 + row) * 8 + j
         total = (cout // 64) * nchunk * 12 * 16 * 64
-        _WY_IDX_CACHE[key] = (np.ascontiguousarray(np.broadcast_to(idx, (4, cout, cin, 3))).reshape(-1), total)
+        _WY_IDX_CACHE[key] = (np.array(np.broadcast_to(idx, (4, cout, cin, 3))).reshape(-1), total)
     return _WY_IDX_CACHE[key]
 
 
@@ -219,10 +219,14 @@ class HipEngine:
         # each whatever its size (tools/probe_small_clips.py) -- and more than three streams do not help (a conv workgroup holds its CU's LDS).  With
         # nb clips in one launch sequence every named buffer holds nb copies (`_bstride`: bytes between them), every conv / OSConv descriptor is
         # issued once per clip INSIDE the same batched launch (savsr_conv2d_batch takes 18 convs since ABI 26) and the per-clip kernels (SE gate,
-        # SATU, tail, ...) are looped: 151 + 63 + nb x ~116 launches for nb clips instead of nb x 330.  Results are those of the one-clip
-        # sequence bit for bit (the convs of a batched launch are independent).  forward_many groups equal (shape, scale) clips up to
+        # SATU, tail, ...) are looped: 151 + 63 + nb x ~116 launches for nb clips instead of nb x 330.  Results are those of a one-clip launch
+        # sequence of the SAME flow bit for bit (the convs of a batched launch are independent and their form is chosen by `form_nb`, not `nb`).  forward_many groups equal (shape, scale) clips up to
         # SAVSR_CLIP_BATCH (default 3) when the LR frame has at most SAVSR_CLIP_BATCH_MAX_PX pixels.
         self.nb = 1
+        # Clips the conv-form rule of a launch counts (conv_launch): `clip_batch` for every frame of the throughput flow whose shape is eligible for
+        # batching, 1 otherwise -- whatever `nb` the launch sequence at hand really carries.  A unit of 1, 2 or 3 clips of a folder therefore takes
+        # the same form in every launch, and a clip's output does not depend on its group (remainders of a folder, the world-size partition).
+        self.form_nb = 1
         self._bstride: Dict[int, int] = {}
         self.clip_batch = max(1, min(self.NB_MAX, int(os.environ.get("SAVSR_CLIP_BATCH", "3"))))
         self.clip_batch_max_px = int(os.environ.get("SAVSR_CLIP_BATCH_MAX_PX", str(200 * 352)))
@@ -537,6 +541,7 @@ class HipEngine:
         e.satu_tail_t, e.satu_w_tail = self.satu_tail_t, self.satu_w_tail
         e.satu_tailq_t, e.satu_w_tailq, e.satu_q = self.satu_tailq_t, self.satu_w_tailq, self.satu_q
         e.nb, e._bstride, e.clip_batch, e.clip_batch_max_px = 1, {}, self.clip_batch, self.clip_batch_max_px
+        e.form_nb = 1
         e.osc = {}
         for k, ent in self.osc.items():
             c = dict(ent)
@@ -826,6 +831,7 @@ class HipEngine:
         st = self._stream()
         for i in range(0, len(descs), 6):
             chunk = descs[i:i + 6]
+            per_clip = len(chunk)
             if self.nb > 1:
                 chunk = [self._clip_desc(d, b) for b in range(self.nb) for d in chunk]
             # Winograd-y form when every conv of the launch has the image and its 16-row x 32-px x 64-channel tiles fill the chip: measured on
@@ -833,7 +839,9 @@ class HipEngine:
             # direct tiling, -4 % against the 16-row direct tiling of the throughput mode
             d0 = chunk[0]
             if all(getattr(c, "_wy", None) for c in chunk) and d0.algo in (_lib.CONV_DIRECT, _lib.CONV_DIRECT_THROUGHPUT):
-                tiles = len(chunk) * (d0.cout // 64) * ((d0.h + 15) // 16) * ((d0.w + 31) // 32)
+                # (the count is the launch's when `form_nb` clips share it -- a property of the frame's shape and flow, NOT of how many clips
+                # happen to be batched: a clip's result never depends on the clips it was grouped with)
+                tiles = per_clip * self.form_nb * (d0.cout // 64) * ((d0.h + 15) // 16) * ((d0.w + 31) // 32)
                 if tiles >= (self.wy_min_tiles_tp if d0.algo == _lib.CONV_DIRECT_THROUGHPUT else self.wy_min_tiles):
                     for c in chunk:
                         c.wpacked, c.algo = c._wy, _lib.CONV_WINOGRAD_Y
@@ -887,7 +895,7 @@ class HipEngine:
         """Whether the dynamic convs of a launch of `n_convs` OSConvs run in the Winograd-y form (the rule of conv_launch)."""
         if not self.conv_wy or cout % 64:
             return False
-        tiles = n_convs * self.nb * (cout // 64) * ((h + 15) // 16) * ((w + 31) // 32)
+        tiles = n_convs * self.form_nb * (cout // 64) * ((h + 15) // 16) * ((w + 31) // 32)
         return tiles >= (self.wy_min_tiles_tp if self.conv_algo == _lib.CONV_DIRECT_THROUGHPUT else self.wy_min_tiles)
 
     def osconv_desc(self, key: str, srcs: List[Src], h: int, w: int, scale, pooled: bool = False, wy: bool = False) -> OSConvAttnDesc:
@@ -1455,11 +1463,20 @@ class HipEngine:
         finally:
             self.nb = 1
 
+    def _set_flow(self, lq: torch.Tensor, throughput: bool) -> None:
+        """The two flows of a frame.  Latency (one clip in flight, `net(lq)` with b = 1): 8-row direct conv tiles, Winograd-y from 200 tiles.
+        Throughput (several clips in flight: b >= 2, forward_many): 16-row tiles, Winograd-y from 100 tiles, counted as if `clip_batch` clips
+        shared every launch when the shape is eligible for batching (`form_nb`).  Each flow is bitwise reproducible and independent of the
+        grouping; the two differ from each other by the conv forms' rounding (~1e-5)."""
+        self.conv_algo = _lib.CONV_DIRECT_THROUGHPUT if throughput else _lib.CONV_DIRECT
+        h, w = int(lq.shape[-2]), int(lq.shape[-1])
+        self.form_nb = self.clip_batch if (throughput and self.cfg["interval"] == 0 and h * w <= self.clip_batch_max_px) else 1
+
     def _forward_graphed_impl(self, lq: torch.Tensor, scale, out: torch.Tensor, throughput: bool = False):
         sc = self._select(lq.shape, scale)
         if sc["graphs"] is None:
             sc["graphs"] = {}
-        self.conv_algo = _lib.CONV_DIRECT_THROUGHPUT if throughput else _lib.CONV_DIRECT
+        self._set_flow(lq, throughput)
         g = sc["graphs"].get(throughput)
         if g is None:
             used = sc.setdefault("uses", {}).get(throughput, 0)
@@ -1564,9 +1581,12 @@ class HipEngine:
     def forward_many(self, items) -> List[torch.Tensor]:
         """A stream of independent clips of MIXED shapes / scales (BASELINE config 5): items = [(lq [T, 3, h, w], (sh, sw))] ->
         [out [3, H, W]].  Clip i runs on HIP stream i % n_streams with that stream's sibling engine, so small clips (whose ~360
-        launches are latency-bound) overlap; results are those of forward() clip by clip."""
-        if not self.use_graphs or self.n_streams < 2 or len(items) < 2:
+        launches are latency-bound) overlap.  Every clip's result is that of the throughput flow (`_set_flow`) whatever
+        the grouping: forward_many(items)[i] == forward_many([items[i]])[0] bit for bit; against the one-clip latency flow of `forward` it
+        agrees to the conv forms' rounding (~1e-5) where a launch takes another form."""
+        if not self.use_graphs or self.n_streams < 2:
             return [self.forward(lq.unsqueeze(0), sc)[0] for lq, sc in items]
+        # (a lone clip takes the throughput flow too: what forward_many returns for a clip does not depend on how many came with it)
         # Launch units: clips of equal (shape, scale) whose LR frame is small enough to be launch-latency-bound go out up to `clip_batch` at a
         # time in ONE launch sequence (see `nb`); everything else one clip per unit, as before.  Units are dealt round-robin over the streams.
         units: List[List[int]] = []
@@ -1614,6 +1634,8 @@ class HipEngine:
                         outs[i] = outb[j]
         for k in range(ns):
             cur.wait_stream(self._streams[k])
+        for o in {id(t._base if t._base is not None else t): (t._base if t._base is not None else t) for t in outs if t is not None}.values():
+            o.record_stream(cur)       # allocated under a side stream, handed to the caller's: its block is not recycled on the side stream while `cur` still reads it
         return outs
 
     def forward(self, lq: torch.Tensor, scale, taps: Optional[dict] = None) -> torch.Tensor:
@@ -1645,7 +1667,7 @@ class HipEngine:
             for k in range(ns):
                 cur.wait_stream(self._streams[k])
             return out
-        self.conv_algo = _lib.CONV_DIRECT
+        self.conv_algo, self.form_nb = _lib.CONV_DIRECT, 1
         for i in range(b):      # samples are independent (OSConv groups=b, savsr_arch.py:166-167)
             if self.use_graphs and taps is None:
                 self._forward_graphed(lq[i], scale, out[i])

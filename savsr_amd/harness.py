@@ -60,6 +60,100 @@ def block_partition(folder_sizes: Sequence[int], rank: int, world: int) -> List[
     return out
 
 
+# ---- the job plan of a whole YAML: (dataset, folder) units cut over the ranks ---------------------------------------------------------
+# A shipped YAML is MANY datasets over one set of folders (test_SAVSR_Vid4_asBI.yml: 42 datasets = 42 scales x the 4 Vid4 folders = 168
+# (dataset, folder) units of 34-49 frames).  Cutting every folder of every dataset into `world` blocks (block_partition, round 5) makes every
+# rank visit every (folder, scale) context: 126 graph-capture contexts for ~860 frames at world 8, 4-6 frames each, every folder decoded on
+# every rank.  The plan below lays the units out FOLDER-MAJOR on one line (all datasets of folder 0, then of folder 1, ...), weighs every
+# frame with a cost model and cuts the line into `world` contiguous pieces of equal cost: a rank owns ~units / world WHOLE units (at most
+# two partial ones, at the ends of its piece), sees one or two folders, captures a context for ~40 frames instead of ~5 and decodes only the
+# folders its piece touches.  Frames stay the independent unit (video_base_model.py:50: hidden state restarts per window), results are
+# identical under any partition, and the only collective is the gather of the metric rows at the end of the job.
+
+LR_PX_FLOOR = 12000.0        # below this many LR pixels a frame is launch-latency-bound: its cost stops falling with its size
+HR_PX_WEIGHT = 0.012         # cost of one HR pixel (SATU HR stage + tail + metrics) in LR-pixel units: 84 us / 0.92 MP against 7.2 ms / 57.6 kpx
+UNIT_FIXED_LR_PX = 150000.0  # what entering a (folder, scale) context costs (buffer plan, table upload, graph capture: ~20 ms) in LR-pixel units
+MIN_SPLIT_FRAMES = 4         # a cut closer than this to a unit's edge moves to the edge (a 2-frame splinter is not worth its capture)
+
+
+def frame_cost(lr_hw: Tuple[int, int], hr_hw: Tuple[int, int]) -> float:
+    """Relative GPU cost of one frame of a unit.  The network body is LR-sized (146 ns per LR pixel at 180x320 and at 480x318 alike,
+    profiles/r05_bench_config3.json / config4.json), SATU's HR stage + the tail + the metrics are HR-sized and small."""
+    return max(float(lr_hw[0] * lr_hw[1]), LR_PX_FLOOR) + HR_PX_WEIGHT * float(hr_hw[0] * hr_hw[1])
+
+
+def plan_job(units: Sequence[dict], world: int, min_split: int = MIN_SPLIT_FRAMES) -> dict:
+    """units: one dict per (dataset, folder) in dataset-major `data_info` order --
+         {"dataset": d, "folder": name, "group": hashable identity of the folder's files (equal across the datasets that read them),
+          "base": global index of the folder's first frame inside dataset d, "frames": n, "cost": cost of one frame (frame_cost)}.
+    Returns {"segments": [per rank: ordered [(d, folder, lo, hi)] with GLOBAL frame indices [lo, hi) of dataset d],
+             "owners":   [per dataset: [per rank: sorted global frame indices]],
+             "cost":     [per rank: planned cost], "order": the folder-major unit order (indices into units)}.
+    Deterministic and rank-independent: every rank computes the same plan from the same YAML."""
+    if world < 1:
+        raise ValueError("world >= 1")
+    seen: dict = {}
+    for u in units:
+        seen.setdefault(u["group"], len(seen))
+    order = sorted(range(len(units)), key=lambda i: (seen[units[i]["group"]], units[i]["dataset"], units[i]["base"]))
+    n_ds = 1 + max((u["dataset"] for u in units), default=-1)
+    segments: List[List[tuple]] = [[] for _ in range(world)]
+    owners: List[List[List[int]]] = [[[] for _ in range(world)] for _ in range(n_ds)]
+    cost = [0.0] * world
+    total = sum(u["frames"] * u["cost"] + UNIT_FIXED_LR_PX for u in units if u["frames"] > 0)
+    if total <= 0:
+        return {"segments": segments, "owners": owners, "cost": cost, "order": order}
+    share = total / world
+    cum = 0.0
+    for i in order:
+        u = units[i]
+        n = int(u["frames"])
+        if n <= 0:
+            continue
+        # rank of every frame by the midpoint of its cost interval on the line; the unit's fixed cost is spread over its frames (every piece
+        # of a split unit pays its own capture: charging the first piece alone would hand it fewer frames than the second)
+        fc = u["cost"] + UNIT_FIXED_LR_PX / n
+        ranks = [min(world - 1, int((cum + (k + 0.5) * fc) / share)) for k in range(n)]
+        cum += n * fc
+        # cuts inside the unit: positions where the rank changes; a cut within min_split frames of an edge (or of the previous cut) snaps away
+        cuts = [k for k in range(1, n) if ranks[k] != ranks[k - 1]]
+        ms = max(1, min(min_split, int(share / fc / 2)))       # (a rank's whole share is a few frames: small pieces are all there is)
+        pieces, lo = [], 0
+        for c in cuts:
+            if c - lo < ms or n - c < ms:
+                continue
+            pieces.append((lo, c, ranks[(lo + c - 1) // 2]))
+            lo = c
+        pieces.append((lo, n, ranks[(lo + n - 1) // 2]))
+        for a, b, r in pieces:
+            segments[r].append((u["dataset"], u["folder"], u["base"] + a, u["base"] + b))
+            owners[u["dataset"]][r].extend(range(u["base"] + a, u["base"] + b))
+            cost[r] += (b - a) * u["cost"] + UNIT_FIXED_LR_PX * (b - a) / n
+    for d in range(n_ds):
+        for r in range(world):
+            owners[d][r].sort()
+    return {"segments": segments, "owners": owners, "cost": cost, "order": order}
+
+
+def chunk_block(n_f: int, streams: int, clip_batch: int) -> List[Tuple[int, int]]:
+    """How a block of n_f consecutive frames of ONE folder goes to forward_many: [(start, end)] offsets into the block.
+    clip_batch > 1 (frames small enough to share launch sequences): every call hands over streams x clip_batch frames, a block shorter than
+    two such calls goes whole (forward_many cuts balanced units: 4 -> 2 + 2).  clip_batch == 1 (large frames: one clip per launch sequence):
+    `streams` frames per call, fewer for short blocks -- every stream's engine captures its own graphs, which only pays back over enough
+    frames (n_f < 6: one at a time).  A lone leftover frame joins the previous call."""
+    if n_f <= 0:
+        return []
+    if clip_batch > 1:
+        g = streams * clip_batch
+        g = g if n_f >= 2 * g else n_f
+    else:
+        g = streams if n_f >= 4 * streams else (min(streams, 2) if n_f >= 6 else 1)
+    out = [(a, min(a + g, n_f)) for a in range(0, n_f, g)]
+    if g > 1 and len(out) >= 2 and out[-1][1] - out[-1][0] == 1:
+        out[-2:] = [(out[-2][0], out[-1][1])]
+    return out
+
+
 def needed_frames(owned_local: Sequence[int], n: int, num_frames: int = 7, padding: str = "reflection") -> List[int]:
     """Frames of an n-frame folder that the windows of `owned_local` read (sorted): the block + a halo of num_frames // 2
     on each side, folded back inside the folder by the padding rule."""

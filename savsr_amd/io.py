@@ -117,6 +117,13 @@ from concurrent.futures import Future, ThreadPoolExecutor  # noqa: E402
 from typing import Dict, Iterable                     # noqa: E402
 
 
+def image_size(path: str) -> Tuple[int, int]:
+    """(H, W) of an image file from its header (nothing is decoded: PIL reads lazily)."""
+    with Image.open(path) as im:
+        w, h = im.size
+    return int(h), int(w)
+
+
 def decode_rgb_u8(path: str) -> np.ndarray:
     """One image file -> HWC RGB uint8 (what cv2.imread returns, channel order reversed)."""
     return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB")))
@@ -143,6 +150,7 @@ class FrameStore:
         self.stats = {"decoded": 0, "host_hits": 0, "uploaded": 0, "device_hits": 0}
         self._inflight = 0                                            # decodes submitted to the pool and not settled yet
         self._pending: "deque[tuple]" = deque()                       # (key, path) requested beyond the in-flight cap, oldest first
+        self._counted: set = set()                                    # the Futures `_inflight` counts
 
     @staticmethod
     def _key(path: str) -> tuple:
@@ -171,19 +179,21 @@ class FrameStore:
     def _settle(self, k, fut: Future) -> None:
         """A decode has finished (worker thread or the waiting caller, whoever comes first): the array replaces its Future and is
         counted against SAVSR_DECODE_CACHE_GB; a failed decode is dropped so that the next request tries again.  The pool is then topped
-        up from the pending queue."""
+        up from the pending queue.  Every Future `_submit` counted is un-counted exactly once -- also when its table entry has been
+        replaced or cleared meanwhile (clear() during a prefetch): `_inflight` cannot stick at the cap."""
         with self._lock:
-            if self._host.get(k) is not fut:
-                return
-            self._inflight -= 1
-            if fut.cancelled() or fut.exception() is not None:
-                self._host.pop(k, None)
-            else:
-                img = fut.result()
-                self._host[k] = img
-                self._host_bytes += img.nbytes
-                self._shape[k] = (int(img.shape[0]), int(img.shape[1]))
-                self._evict_host(k)
+            if fut in self._counted:
+                self._counted.discard(fut)
+                self._inflight -= 1
+            if self._host.get(k) is fut:
+                if fut.cancelled() or fut.exception() is not None:
+                    self._host.pop(k, None)
+                else:
+                    img = fut.result()
+                    self._host[k] = img
+                    self._host_bytes += img.nbytes
+                    self._shape[k] = (int(img.shape[0]), int(img.shape[1]))
+                    self._evict_host(k)
         self._top_up()
 
     def _submit(self, k, path: str) -> Future:
@@ -191,6 +201,7 @@ class FrameStore:
         fut = self._pool.submit(self._decode, path)
         self._host[k] = fut
         self._inflight += 1
+        self._counted.add(fut)
         return fut
 
     def _top_up(self) -> None:
@@ -298,9 +309,12 @@ class FrameStore:
         return torch.stack(out, 0)
 
     def clear(self):
+        """Forget everything decoded, queued or uploaded.  Decodes still running in the pool finish into nowhere: their Futures stay counted
+        until they settle (`_settle` un-counts a Future it finds replaced), so the in-flight cap keeps meaning what it says."""
         with self._lock:
             self._host.clear()
             self._host_bytes = 0
+            self._pending.clear()
         self._dev.clear()
         self._dev_files.clear()
         self._dev_bytes = 0

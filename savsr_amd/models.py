@@ -25,7 +25,7 @@ import torch
 
 from . import io as sio
 from .archs import build_network
-from .harness import aggregate_rows, block_partition, frame_indices, gather_rows
+from .harness import aggregate_rows, block_partition, chunk_block, frame_indices, gather_rows, plan_job
 from .metrics import tensor2img
 from .registry import METRIC_REGISTRY, MODEL_REGISTRY
 from .resize_gpu import resize_bicubic_aa
@@ -108,14 +108,104 @@ class VideoBaseModel(BaseModel):
         does not touch the network's scale (video_base_model.py / sr_model.py:200-212): whatever was set last stays."""
         return tuple(net.scale)
 
-    def dist_validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
-        from .metrics_gpu import psnr_ssim_y
-        dataset = getattr(dataloader, "dataset", dataloader)
+    def _dataset_prologue(self, dataset):
+        """What dist_validation does before its frame loop (video_base_model.py:19-37)."""
         if dataset.opt.get("downsampling_scale", 0) != 0:             # :21-22
             self.opt["scale"] = dataset.opt["downsampling_scale"]
-        dataset_name = dataset.opt["name"]
         metrics_opt = self.opt["val"].get("metrics")
         with_metrics = metrics_opt is not None
+        names = list(metrics_opt.keys()) if with_metrics else []
+        crop, ych = _gpu_metric_plan(metrics_opt) if with_metrics else (None, True)
+        return metrics_opt, with_metrics, names, crop, ych
+
+    def _run_frames(self, dataset, mine, rows, save_img=False, next_folder=None):
+        """The frame loop of video_base_model.py:50-98 over the global frame indices `mine` of `dataset` (this rank's share, folder by
+        folder); the PSNR / SSIM rows go to rows[k] for mine[k] and stay in HBM.
+
+        Frames are independent units (the hidden state restarts per window, savsr_arch.py:705-706): instead of one frame at a time
+        (video_base_model.py:51-53) they go through the network several at a time, each launch unit on its own HIP stream
+        (SAVSR.forward_many) -- the launch-latency-bound parts of one frame run under another's convolutions.  Every frame takes the
+        throughput flow of the engine (HipEngine._set_flow), whose result for a frame does not depend on the frames that came with it:
+        metric tables and saved images are identical for every world size and partition.
+        next_folder: (dataset, folder) the caller runs next -- its files are decoded in the background meanwhile."""
+        from .metrics_gpu import psnr_ssim_y
+        metrics_opt, with_metrics, names, crop, ych = self._dataset_prologue(dataset)
+        dataset_name = dataset.opt["name"]
+        net = self.net_g.module if hasattr(self.net_g, "module") else self.net_g
+        many = hasattr(net, "forward_many")
+        eng = net.engine() if many else None
+        streams = max(1, int(getattr(eng, "n_streams", 1))) if many else 1
+        folders_all = dataset.data_info["folder"]
+        my_folders = list(dict.fromkeys(folders_all[i] for i in mine))
+        if hasattr(dataset, "prefetch") and my_folders:
+            dataset.prefetch(my_folders[0])
+        if streams > 1:
+            net.eval()                                                # once per call (a recursive walk over ~300 modules: 3 ms)
+        timing = bool(self.opt.get("profile_gpu_time"))
+        ev = []                                                        # (start, end) HIP events around the device work of a group
+        k = 0
+        while k < len(mine):
+            # a block: this rank's consecutive frames of ONE folder (a folder is one LR shape = one set of captured graphs per stream)
+            f0 = folders_all[mine[k]]
+            k1 = k
+            while k1 < len(mine) and folders_all[mine[k1]] == f0:
+                k1 += 1
+            nxt = my_folders.index(f0) + 1
+            if hasattr(dataset, "prefetch"):                          # the pool decodes the NEXT folder meanwhile
+                if nxt < len(my_folders):
+                    dataset.prefetch(my_folders[nxt])
+                elif next_folder is not None:
+                    next_folder[0].prefetch(next_folder[1])
+            first = dataset[mine[k]]
+            h, w = int(first["lq"].shape[-2]), int(first["lq"].shape[-1])
+            # clips per launch sequence only where the engine batches them (small frames); large frames keep the one-clip-per-stream rule
+            unit = max(1, int(getattr(eng, "clip_batch", 1))) if (streams > 1 and h * w <= int(getattr(eng, "clip_batch_max_px", 0))
+                                                                  and net.engine().cfg.get("interval", 0) == 0) else 1
+            for a, b in (chunk_block(k1 - k, streams, unit) if streams > 1 else [(i, i + 1) for i in range(k1 - k)]):
+                k0, k_end = k + a, k + b
+                vals = [first if idx == mine[k] else dataset[idx] for idx in mine[k0:k_end]]
+                if timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                if streams > 1:        # (a lone frame too: forward_many's result for a frame does not depend on the frames that came with it)
+                    outs = net.forward_many([v["lq"] for v in vals], [self._group_scale(net)] * len(vals))
+                else:
+                    outs = None
+                for j, val in enumerate(vals):
+                    val["lq"] = val["lq"].unsqueeze(0)
+                    val["gt"] = val["gt"].unsqueeze(0)
+                    self.feed_data(val)
+                    if outs is None:
+                        self.test()
+                    else:
+                        self.output = outs[j].unsqueeze(0)
+                    vis = self.get_current_visuals()
+                    if save_img:
+                        path = sio.result_img_path(self.opt["path"]["visualization"], dataset_name, val["folder"], val["lq_path"],
+                                                   self.opt["name"], self.opt["val"].get("suffix"))
+                        sio.imwrite_async(tensor2img(vis["result"]), path)
+                    if with_metrics:
+                        psnr_ssim_y(vis["result"][0], vis["gt"][0], crop, out=rows[k0 + j], test_y_channel=ych)
+                    del self.lq, self.output, self.gt
+                if timing:
+                    e1.record()
+                    ev.append((e0, e1))
+            k = k1
+        if timing and ev:
+            self._gpu_events = getattr(self, "_gpu_events", []) + ev
+
+    def _settle_gpu_time(self):
+        ev = getattr(self, "_gpu_events", None)
+        if ev:
+            torch.cuda.synchronize()
+            self.gpu_ms = getattr(self, "gpu_ms", 0.0) + sum(a.elapsed_time(b) for a, b in ev)
+            self._gpu_events = []
+
+    def dist_validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
+        """ONE dataset (video_base_model.py:18-118): this rank's frames, the gather of the metric rows, the table.  A whole YAML goes
+        through `validate_job`, which partitions all its datasets at once."""
+        dataset = getattr(dataloader, "dataset", dataloader)
+        metrics_opt, with_metrics, names, crop, ych = self._dataset_prologue(dataset)
         rank, world = self.opt.get("rank", 0), self.opt.get("world_size", 1)
         n = len(dataset)
         # Frame partition (:50).  The reference deals frames round-robin, which makes every rank read every file; a dataset
@@ -126,89 +216,11 @@ class VideoBaseModel(BaseModel):
         else:
             mine = frame_indices(n, rank, world)
             owners = None
-        names = list(metrics_opt.keys()) if with_metrics else []
-        crop, ych = _gpu_metric_plan(metrics_opt) if with_metrics else (None, True)
         rows = torch.zeros(len(mine), 2, dtype=torch.float64, device=self.device)
-        # Frames are independent units (the hidden state restarts per window, savsr_arch.py:705-706): instead of one frame at a
-        # time (video_base_model.py:51-53) this rank's frames go through the network `group` at a time, each on its own HIP
-        # stream (SAVSR.forward_many) -- the launch-latency-bound parts of one frame run under another's convolutions
-        # (+12 % frames/s at 180x320 x4).  Per-frame results are those of the one-at-a-time flow (`test()`) -- bit for bit where every conv
-        # launch takes the same form in both modes (small frames), within the rounding of the direct vs Winograd-y conv forms (~1e-5) otherwise.
-        net = self.net_g.module if hasattr(self.net_g, "module") else self.net_g
-        group = max(1, int(getattr(net.engine(), "n_streams", 1))) if hasattr(net, "forward_many") else 1
-        # ... and up to `clip_batch` clips of the folder per launch sequence (HipEngine.nb): a call hands forward_many streams x clip_batch clips
-        unit = max(1, int(getattr(net.engine(), "clip_batch", 1))) if group > 1 else 1
-        group_full = group * unit
-        folders_all = dataset.data_info["folder"]
-        my_folders = list(dict.fromkeys(folders_all[i] for i in mine))
-        if hasattr(dataset, "prefetch") and my_folders:
-            dataset.prefetch(my_folders[0])
-        if group > 1:
-            net.eval()                                                # once per dataset (a recursive walk over ~300 modules: 3 ms)
-        cur_folder = None
-        ev = []                                                        # (start, end) HIP events around the device work of a group
-        timing = bool(self.opt.get("profile_gpu_time"))
-        # Groups never straddle folders (a folder is one LR shape = one captured graph set per stream), and a folder block with few
-        # frames -- a rank's share at world size 8 is ~5 frames of a 41-frame Vid4 folder -- keeps fewer clips in flight: every
-        # stream's engine captures its own graphs (~5 ms each), which only pays back over enough frames.
-        chunks = []
-        k = 0
-        while k < len(mine):
-            f0 = folders_all[mine[k]]
-            k1 = k
-            while k1 < len(mine) and folders_all[mine[k1]] == f0:
-                k1 += 1
-            n_f = k1 - k
-            if unit > 1:        # every stream a unit of `unit` clips per call; a shorter block goes to forward_many whole (it cuts balanced units: 4 -> 2 + 2)
-                g_f = group_full if n_f >= 2 * group_full else n_f
-            else:
-                g_f = group if n_f >= 4 * group else (min(group, 2) if n_f >= 6 else 1)
-            fc = [(a, min(a + g_f, k1)) for a in range(k, k1, g_f)]
-            if g_f > 1 and len(fc) >= 2 and fc[-1][1] - fc[-1][0] == 1:
-                # a lone leftover frame (34 or 40 frames over 3 streams) would go through test() = the one-clip graphs, a second set of
-                # captures per (folder, scale) for a single frame: it joins the previous group instead (forward_many takes any count)
-                fc[-2:] = [(fc[-2][0], fc[-1][1])]
-            chunks += fc
-            k = k1
-        for k0, k_end in chunks:
-            f0 = folders_all[mine[k0]]
-            if f0 != cur_folder:                                      # entering a folder: the pool decodes the NEXT one meanwhile
-                cur_folder = f0
-                nxt = my_folders.index(f0) + 1
-                if hasattr(dataset, "prefetch") and nxt < len(my_folders):
-                    dataset.prefetch(my_folders[nxt])
-            vals = [dataset[idx] for idx in mine[k0:k_end]]
-            if timing:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            if group > 1 and len(vals) > 1:
-                outs = net.forward_many([v["lq"] for v in vals], [self._group_scale(net)] * len(vals))
-            else:
-                outs = None
-            for j, val in enumerate(vals):
-                val["lq"] = val["lq"].unsqueeze(0)
-                val["gt"] = val["gt"].unsqueeze(0)
-                self.feed_data(val)
-                if outs is None:
-                    self.test()
-                else:
-                    self.output = outs[j].unsqueeze(0)
-                vis = self.get_current_visuals()
-                if save_img:
-                    path = sio.result_img_path(self.opt["path"]["visualization"], dataset_name, val["folder"], val["lq_path"],
-                                               self.opt["name"], self.opt["val"].get("suffix"))
-                    sio.imwrite_async(tensor2img(vis["result"]), path)
-                if with_metrics:
-                    psnr_ssim_y(vis["result"][0], vis["gt"][0], crop, out=rows[k0 + j], test_y_channel=ych)
-                del self.lq, self.output, self.gt
-            if timing:
-                e1.record()
-                ev.append((e0, e1))
+        self._run_frames(dataset, mine, rows, save_img)
         if save_img:
             sio.flush_writes()
-        if timing:
-            torch.cuda.synchronize()
-            self.gpu_ms = getattr(self, "gpu_ms", 0.0) + sum(a.elapsed_time(b) for a, b in ev)
+        self._settle_gpu_time()
         if not with_metrics:
             return None
         if self.opt.get("emulate_world"):
@@ -219,10 +231,65 @@ class VideoBaseModel(BaseModel):
                 allrows[torch.as_tensor(list(mine), device=rows.device)] = rows
         else:
             allrows = gather_rows(rows, n, rank, world, owners)       # the one collective of the dataset (:108-113)
+        return self._table(dataset, allrows, metrics_opt, names)
+
+    def _table(self, dataset, allrows, metrics_opt, names):
         cols = [(m, 0 if metrics_opt[m]["type"] == "calculate_psnr" else 1) for m in names]
-        self.last_validation = aggregate_rows(allrows, cols, folders_all, dataset_name, self.opt.get("scale"))   # :125-167
+        scale = dataset.opt["downsampling_scale"] if dataset.opt.get("downsampling_scale", 0) != 0 else self.opt.get("scale")
+        self.last_validation = aggregate_rows(allrows, cols, dataset.data_info["folder"], dataset.opt["name"], scale)   # :125-167
         self.metric_results = self.last_validation["frames"]
         return self.last_validation
+
+    def validate_job(self, datasets, current_iter=None, tb_logger=None, save_img=False):
+        """Every dataset of a YAML as ONE job (what lbasicsr/test.py:37-48 loops over, dataset by dataset).  The (dataset, folder) units of
+        all datasets are cut over the ranks by harness.plan_job -- folder-major, cost-balanced, whole units wherever possible --, a rank runs
+        its segments back to back (one folder decoded once, one graph capture per (folder, scale) it owns, ~40 frames per capture instead
+        of ~5), and the metric rows of ALL datasets travel in ONE collective at the end (RCCL all_gather_into_tensor of the padded
+        [rows, 2] block; the reference reduces once per folder, :108-113).  Returns the per-dataset tables in dataset order, identical
+        on every rank and identical to what world size 1 returns."""
+        rank, world = self.opt.get("rank", 0), self.opt.get("world_size", 1)
+        units = [u for d, ds in enumerate(datasets) for u in ds.units(d)]
+        plan = plan_job(units, world)
+        self.last_plan = plan
+        sizes = [len(ds) for ds in datasets]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        mine_d = [plan["owners"][d][rank] if d < len(plan["owners"]) else [] for d in range(len(datasets))]
+        for ds, mine in zip(datasets, mine_d):
+            ds.shard_frames(mine)
+        pos = [{g: k for k, g in enumerate(m)} for m in mine_d]
+        rows = [torch.zeros(len(m), 2, dtype=torch.float64, device=self.device) for m in mine_d]
+        segs = plan["segments"][rank]
+        any_metrics = self.opt["val"].get("metrics") is not None
+        for si, (d, folder, lo, hi) in enumerate(segs):
+            ds = datasets[d]
+            nxt = (datasets[segs[si + 1][0]], segs[si + 1][1]) if si + 1 < len(segs) and hasattr(datasets[segs[si + 1][0]], "prefetch") else None
+            k0 = pos[d][lo]
+            self._run_frames(ds, list(range(lo, hi)), rows[d][k0:k0 + (hi - lo)], save_img, next_folder=nxt)
+            if hasattr(ds, "release_resident") and (nxt is None or nxt[0] is not ds):
+                ds.release_resident()
+        if save_img:
+            sio.flush_writes()
+        self._settle_gpu_time()
+        if not any_metrics:
+            return [None] * len(datasets)
+        # ONE collective for the job: global row index = dataset offset + frame index
+        local = torch.cat(rows, 0) if rows else torch.zeros(0, 2, dtype=torch.float64, device=self.device)
+        total = offs[-1]
+        if self.opt.get("emulate_world"):                             # (bench.py --emulate-world: no process group, the others' rows stay zero)
+            allrows = torch.zeros(total, 2, dtype=local.dtype, device=local.device)
+            idx = [offs[d] + g for d in range(len(datasets)) for g in mine_d[d]]
+            if idx:
+                allrows[torch.as_tensor(idx, device=local.device)] = local
+        else:
+            owners = [[offs[d] + g for d in range(len(datasets)) for g in plan["owners"][d][r]] for r in range(world)]
+            allrows = gather_rows(local, total, rank, world, owners)
+        results = []
+        for d, ds in enumerate(datasets):
+            metrics_opt, with_metrics, names, crop, ych = self._dataset_prologue(ds)
+            results.append(self._table(ds, allrows[offs[d]:offs[d + 1]], metrics_opt, names))
+        return results
 
     def nondist_validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
         return self.dist_validation(dataloader, current_iter, tb_logger, save_img)       # :120-123

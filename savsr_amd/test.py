@@ -74,9 +74,13 @@ def run_test(opt: Union[str, dict], root_path: str = ".", model=None) -> List[di
             if "path" in opt:
                 model.opt.setdefault("path", {}).update({k: v for k, v in opt["path"].items() if k != "pretrain_network_g"})
             model.opt["rank"], model.opt["world_size"], model.opt["dist"] = opt["rank"], opt["world_size"], opt["dist"]
+        save_img = opt["val"].get("save_img", False)
+        if hasattr(model, "validate_job") and all(hasattr(ds, "units") for ds in test_sets) and os.environ.get("SAVSR_JOB_PLAN", "1") != "0":
+            # all datasets of the YAML as one job: (dataset, folder) units cut over the ranks, ONE gather of the metric rows (models.validate_job)
+            return model.validate_job(test_sets, current_iter=opt["name"], tb_logger=None, save_img=save_img)
         results = []
-        for ds in test_sets:                                                              # :37-48
-            results.append(model.validation(ds, current_iter=opt["name"], tb_logger=None, save_img=opt["val"].get("save_img", False)))
+        for ds in test_sets:                                                              # :37-48, dataset by dataset (SAVSR_JOB_PLAN=0)
+            results.append(model.validation(ds, current_iter=opt["name"], tb_logger=None, save_img=save_img))
         return results
     finally:
         if own_group:

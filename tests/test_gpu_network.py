@@ -88,7 +88,7 @@ def test_psnr_ssim_tolerance(net, synth_sd):
     assert abs(p1 - p2) <= 1e-3 and abs(s1 - s2) <= 1e-4
 
 
-def test_full_size_config2(net, synth_sd):
+def test_full_size_config2(net, synth_sd, oracle_config2):
     """BASELINE config 2 (7x3x180x320, x4 -> 720x1280): shape, finiteness, bitwise rerun
     determinism, and parity with the CPU oracle on the same clip (max-abs, PSNR-Y, SSIM-Y)."""
     from savsr_amd.metrics import calculate_psnr, calculate_ssim, tensor2img
@@ -98,14 +98,73 @@ def test_full_size_config2(net, synth_sd):
     assert tuple(a.shape) == (1, 3, 720, 1280) and bool(torch.isfinite(a).all())
     b = net(lq.to("cuda:0"))
     assert torch.equal(a, b)
-    with torch.no_grad():
-        ref = O.forward(synth_sd, lq, (4, 4))
+    ref = oracle_config2(0)
     err = float((a.cpu() - ref).abs().max())
     gt = tensor2img(synth.synth_gt(3, 720, 1280, seed=0))
     dp = abs(calculate_psnr(tensor2img(a[0].cpu()), gt, 0, test_y_channel=True) - calculate_psnr(tensor2img(ref[0]), gt, 0, test_y_channel=True))
     ds = abs(calculate_ssim(tensor2img(a[0].cpu()), gt, 0, test_y_channel=True) - calculate_ssim(tensor2img(ref[0]), gt, 0, test_y_channel=True))
     print("config2 max-abs", err, "dPSNR", dp, "dSSIM", ds)
     assert err < 5e-5 and dp <= 1e-3 and ds <= 1e-4
+
+
+def test_headline_configuration_vs_oracle(net, oracle_config2):
+    """The configuration bench.py's headline times (savsr_arch.py:692-742 on a batch, video_base_model.py:51-53 with several frames in
+    flight): `net(lq)` with b = 9 at 180x320 x4 under product defaults -- three HIP streams x three clips per launch sequence, throughput
+    conv tiling, ~99 % of the conv MACs in the Winograd-y form.  Three distinct clips, each once per stream and once per position inside a
+    batched launch: every output < 5e-5 from the oracle, and the three copies of a clip bit-identical (a clip's result does not depend on
+    the stream, on its position in the launch sequence or on the clips it shares the launches with)."""
+    eng = net.engine()
+    assert eng.n_streams == 3 and eng.clip_batch == 3 and eng.use_graphs and eng.conv_wy, "product defaults"
+    seeds = [0, 1, 2]
+    clips = {s: synth.synth_clip(7, 3, 180, 320, seed=s) for s in seeds}
+    order = [0, 1, 2, 1, 2, 0, 2, 0, 1]
+    lq = torch.cat([clips[s] for s in order], 0).to("cuda:0")
+    net.set_scale((4, 4))
+    eng.census = {}
+    try:
+        out = net(lq)
+        out2 = net(lq)          # replay
+        torch.cuda.synchronize()
+        cen = dict(eng.census)
+    finally:
+        eng.census = None
+    assert tuple(out.shape) == (9, 3, 720, 1280) and torch.equal(out, out2)
+    if cen.get("alg_tp"):       # (filled while the launch sequences are captured: empty when an earlier test already captured this context)
+        assert cen["frames_tp"] % 3 == 0 and cen["wy_alg_tp"] / cen["alg_tp"] > 0.98, cen
+    first = {}
+    for i, s in enumerate(order):
+        err = float((out[i].cpu() - oracle_config2(s)[0]).abs().max())
+        print("headline configuration: clip", i, "seed", s, "max-abs vs oracle", err)
+        assert err < 5e-5, (i, s, err)
+        if s in first:
+            assert torch.equal(out[i], out[first[s]]), (i, first[s])
+        first.setdefault(s, i)
+
+
+def test_forward_many_group_of_seven_vs_oracle(net, synth_sd):
+    """A small-clip group as the YAML workflow / config 5 hands it over: forward_many with 7 clips of 64x112 at x2 -> launch units of
+    3 + 2 + 2 clips on three streams.  Every clip < 5e-5 from the oracle; equal clips bit-identical whatever unit they ran in; and each
+    clip's result equals that of forward_many called with that clip alone (the conv form of a launch is chosen by the flow, not the group)."""
+    sc = (2, 2)
+    clips = [synth.synth_clip(7, 3, 64, 112, seed=20 + k) for k in range(3)]
+    order = [0, 1, 2, 0, 1, 2, 0]
+    items = [clips[k][0].to("cuda:0") for k in order]
+    outs = net.forward_many(items, [sc] * 7)
+    torch.cuda.synchronize()
+    refs = []
+    with torch.no_grad():
+        for c in clips:
+            refs.append(O.forward(synth_sd, c, sc)[0])
+    for i, k in enumerate(order):
+        err = float((outs[i].cpu() - refs[k]).abs().max())
+        print("group of seven: clip", i, "max-abs vs oracle", err)
+        assert err < 5e-5, (i, err)
+        assert torch.equal(outs[i], outs[order.index(k)]), i
+    for k in range(3):
+        alone = net.forward_many([items[k]], [sc])[0]
+        pair = net.forward_many([items[k], items[(k + 1) % 3]], [sc] * 2)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(alone, outs[k]) and torch.equal(pair, outs[k]), k
 
 
 def test_full_size_satu_linearity(net):
@@ -208,8 +267,9 @@ def test_clip_batched_launch_sequence_bitwise(synth_sd, monkeypatch):
     """SAVSR_CLIP_BATCH: clips of one (shape, scale) run as ONE launch sequence (every named buffer holds a copy per clip, every conv / OSConv
     descriptor goes out once per clip inside the same batched launch, the per-clip kernels are looped).  The convs of a batched launch are
     independent, so with ONE conv form everywhere (SAVSR_CONV_WY=0) every clip's output equals the unbatched stream's bit for bit -- groups of
-    3 and 2, a lone clip, odd sizes, an expanded-table scale, captured and replayed; with the product's per-launch form choice (a batched launch
-    has nb x the tiles, so it may take the Winograd-y form where the one-clip launch takes the direct one) the two agree to the forms' rounding."""
+    3 and 2, a lone clip, odd sizes, an expanded-table scale, captured and replayed; with the product's per-launch form choice the form is a function of the flow and of
+    SAVSR_CLIP_BATCH (`form_nb`), so the clip_batch = 3 engine agrees with the clip_batch = 1 engine to the forms' rounding, and with ITSELF bit for
+    bit under any grouping (alone, pairs, the batched stream)."""
     import random
     import savsr_amd
 
@@ -243,3 +303,13 @@ def test_clip_batched_launch_sequence_bitwise(synth_sd, monkeypatch):
                 err = float((a[i] - b[i]).abs().max())
                 assert err <= tol, (wy, rep, i, tuple(clips[i].shape), scales[i], err)
         assert three.engine().host_stats["captures"] < one.engine().host_stats["captures"]      # fewer, fatter launch sequences
+        # With ONE setting of SAVSR_CLIP_BATCH a clip's result does not depend on its group (the form rule counts `form_nb` clips, not the
+        # nb at hand): the batched stream against every clip alone and against pairs, bit for bit, in both form settings
+        for i in range(len(clips)):
+            alone = three.forward_many([clips[i]], [scales[i]])[0]
+            torch.cuda.synchronize()
+            assert torch.equal(alone, a[i]), (wy, i, tuple(clips[i].shape), scales[i])
+        for i in range(0, len(clips) - 1, 2):
+            pair = three.forward_many(clips[i:i + 2], scales[i:i + 2])
+            torch.cuda.synchronize()
+            assert torch.equal(pair[0], a[i]) and torch.equal(pair[1], a[i + 1]), (wy, i)

@@ -147,3 +147,34 @@ def test_frame_store_host_cap_counts_prefetched_files(tmp_path):
     assert all(big.host(p).shape == (32, 48, 3) for p in paths) and big.stats["decoded"] == len(paths)      # all host hits
     big.request(paths)                                     # already decoded: nothing queued
     assert not big._pending and big._inflight == 0
+
+
+def test_frame_store_clear_during_prefetch_keeps_the_inflight_account(tmp_path):
+    """clear() while decodes are running or queued: the queue is dropped, the running decodes are un-counted when they finish (their table
+    entries are gone), and the pool keeps accepting work afterwards -- `_inflight` returns to 0 instead of sticking at the cap, which would
+    push every later decode onto the consumer thread."""
+    import time
+    rng = np.random.RandomState(5)
+    paths = []
+    for i in range(24):
+        p = str(tmp_path / f"{i:03d}.png")
+        io.imwrite(rng.randint(0, 255, (64, 64, 3), dtype=np.uint8), p)
+        paths.append(p)
+    store = io.FrameStore(host_bytes=1 << 30, device_bytes=1 << 30, workers=1)
+    for rep in range(3):
+        store.request(paths)
+        assert store._inflight >= 1
+        store.clear()
+        assert not store._pending and not store._host
+    for _ in range(1000):
+        if store._inflight == 0:
+            break
+        time.sleep(0.01)
+    assert store._inflight == 0 and not store._counted
+    store.request(paths)                                  # the pool still takes work: everything is decoded by it, nobody calls host()
+    for _ in range(1000):
+        if store._inflight == 0 and not store._pending and len(store._host) == len(paths):
+            break
+        time.sleep(0.01)
+    assert store._inflight == 0 and len(store._host) == len(paths)
+    assert all(isinstance(v, np.ndarray) for v in store._host.values())
