@@ -402,6 +402,7 @@ def run_config2(args, rank, world, dev, dist):
     value = world * args.steps * cps * hr_mpx / elapsed
     line = base_line(args, world, value, elapsed, "BASELINE config 2: synthetic 7x3x180x320 clips, scale x4 -> 720x1280, key-seeded random-init weights",
                      {"frames_per_step": cps, "streams_per_gpu": min(cps, eng.n_streams), "clips_per_launch_sequence": eng.clip_batch})
+    line["config"]["knobs"] = eng.knobs.knobs()          # non-default SAVSR_* switches of the engine (savsr_amd/config.py); empty = product configuration
     line["metric"] = "HR Mpixels/sec (Vid4-shape x4, 7-frame window)"
     line["timed_region_s"] = round(elapsed, 3)
     vals = sorted(world * args.steps * cps * hr_mpx / e for e in regions)
@@ -524,6 +525,7 @@ def run_cases(args, rank, world, dev, dist, cases, workload, config_id):
     if rank != 0:
         return
     line = base_line(args, world, total_px / total_t / 1e6, total_t, workload, {"frames_per_case": args.steps, "cases": len(cases), "batch": 1})
+    line["config"]["knobs"] = eng.knobs.knobs()          # non-default SAVSR_* switches of the engine (savsr_amd/config.py); empty = product configuration
     line["ms_per_step"] = round(1e3 * total_t / (args.steps * len(cases)), 3)
     line["bench_config"] = config_id
     line["per_case"] = per_case
@@ -574,6 +576,7 @@ def run_config5(args, rank, world, dev, dist):
                      "BASELINE config 5: synthetic Vimeo90K-shape clips (GT 256x448), (sh, sw) drawn from the 60-entry training list, random-init weights",
                      {"frames_per_step": cps, "distinct_shape_scale_pairs": len(uniq), "streams_per_gpu": eng.n_streams,
                       "clips_per_launch_sequence": eng.clip_batch, "bucketed_by_shape_and_scale": not args.no_bucket})
+    line["config"]["knobs"] = eng.knobs.knobs()          # non-default SAVSR_* switches of the engine (savsr_amd/config.py); empty = product configuration
     line["bench_config"] = 5
     line["clips_per_s"] = round(world * cps * args.steps / el, 2)
     st = eng.cache_stats()
@@ -757,6 +760,7 @@ def run_run_test(args, rank, world, dev, dist):
                          + ", ".join(f"x{a}/{b}" for a, b in scales) + " over one dataroot_gt, ASVideoTestDataset + ASVSRModel, PSNR-Y / SSIM-Y",
                          {"frames_per_folder": frames, "frames": n_frames, "save_img": bool(args.save_img),
                           "decode_threads": sio.frame_store().workers, "streams_per_gpu": eng.n_streams})
+        line["config"]["knobs"] = eng.knobs.knobs()          # non-default SAVSR_* switches of the engine (savsr_amd/config.py); empty = product configuration
         line["metric"] = "HR Mpixels/sec (YAML workflow, steady-state pass)"
         line["steps"], line["warmup"], line["ms_per_step"] = 1, 1, round(1e3 * warm["wall_s"], 1)
         line["bench_config"] = "run_test"

@@ -41,6 +41,9 @@
 #ifndef WY_VALU
 #define WY_VALU 6                 // vector instructions the scheduler may put behind every MFMA of a step
 #endif
+#ifndef WY_BUF
+#define WY_BUF 1                  // 1: activation rows by buffer loads (uniform 64-bit row base in the resource, one constant per-lane column offset, out-of-range
+#endif                            //    lanes / rows answered with zeros by the bounds check): no per-load address arithmetic on the vector unit.  0: flat global loads (round 4)
 
 namespace savsr {
 
@@ -117,20 +120,61 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     // Per lane and tile: the pixel index of (input row d0, its column) for the two full rounds (column = (px c, channel quad q4):
     // c = lane / 4 + 16 r, q4 = lane % 4) and for the tail (the 8 columns of c = 32, 33: lanes < 32 hold ONE (row, column) each).
     f32x4 d[2][4], dx;
+#if !WY_BUF
     int st_pxb[2], st_pxt;                                    // pixel index of (row d0 [+ own row for the tail], x), or INVALID
     constexpr int INVALID = -(1 << 30);
+#endif
     const float* st_base = nullptr;
     const bf16x8* st_w = nullptr;
     int st_pix = 0, st_cb = 0, st_src = 0, st_conv = 0, st_row0 = 0;
     const int q4 = lane & 3;
+#if WY_BUF
+    // Buffer-load form: the ROW and the channel chunk go into the resource's 64-bit base (scalar arithmetic), the lane keeps ONE byte offset per
+    // round -- its column inside a row, (x * pix + 4 q4) * 4, constant over the tile's phases of a source -- and everything that must read as zero
+    // is out of range: columns outside the image carry the offset OOB (>= num_records), rows outside the image get num_records = 0.
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned st_vcol[2], st_vtail;
+    int st_x0 = 0;
+    auto stage_cols = [&]() {                                  // per tile and per source (the pixel pitch may differ between the sources of a conv)
+#pragma unroll
+        // (branch-free on purpose: a per-lane BRANCH here joins in the block where the cursor's scalar fields merge, and hipcc's uniformity
+        // analysis then takes those for divergent too -- single unsigned compares and selects instead of short-circuit conditions)
+        for (int r = 0; r < 2; ++r) {
+            const int x = st_x0 - 1 + (lane >> 2) + 16 * r;
+            const unsigned v = (unsigned)(x * st_pix + 4 * q4) * 4u;
+            st_vcol[r] = (unsigned)x < (unsigned)W ? v : OOB;
+        }
+        const int x = st_x0 - 1 + 32 + ((lane & 7) >> 2), rr = (lane >> 3) & 3, row = st_row0 + rr;
+        const unsigned vt = (unsigned)((rr * W + x) * st_pix + 4 * q4) * 4u;
+        const bool okt = (lane < 32) & ((unsigned)x < (unsigned)W) & ((unsigned)row < (unsigned)H);
+        st_vtail = okt ? vt : OOB;
+    };
+#endif
+#if WY_BUF
+    // (the cursor's fields are wave-uniform by construction; saying so keeps them -- and the resources built from them -- in scalar registers:
+    // without it hipcc carries them in vector registers and wraps every buffer load in a readfirstlane "waterfall" loop)
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni_ptr = [](const float* q) {
+        const unsigned long long a = (unsigned long long)(uintptr_t)q;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+        return (const float*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+#else
+    auto uni = [](int v) { return v; };
+    auto uni_ptr = [](const float* q) { return q; };
+#endif
     auto stage_begin_tile = [&](const TileInfo& ti) {
         st_conv = ti.conv;
         st_src = 0;
         st_cb = 0;
-        st_base = mp.c[ti.conv].src[0];
-        st_pix = mp.c[ti.conv].src_pix[0];
+        st_base = uni_ptr(mp.c[ti.conv].src[0]);
+        st_pix = uni(mp.c[ti.conv].src_pix[0]);
         st_w = reinterpret_cast<const bf16x8*>(mp.c[ti.conv].wimg) + (long long)ti.cob * mp.nchunk * W_PHASE;
-        st_row0 = ti.y0 + 2 * wave_s - 1;                     // image row of d0 (scalar)
+        st_row0 = uni(ti.y0 + 2 * wave_s - 1);                // image row of d0 (scalar)
+#if WY_BUF
+        st_x0 = ti.x0;
+        stage_cols();
+#else
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int x = ti.x0 - 1 + (lane >> 2) + 16 * r;
@@ -140,6 +184,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
             const int x = ti.x0 - 1 + 32 + ((lane & 7) >> 2), row = st_row0 + ((lane >> 3) & 3);
             st_pxt = (lane < 32 && x >= 0 && x < W && row >= 0 && row < H) ? row * W + x : INVALID;
         }
+#endif
     };
     auto stage_advance = [&]() {
         st_cb += 16;
@@ -147,8 +192,13 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
         if (st_cb >= mp.src_ch) {
             st_cb = 0;
             ++st_src;
-            st_base = mp.c[st_conv].src[st_src];
+            st_base = uni_ptr(mp.c[st_conv].src[st_src]);
+#if WY_BUF
+            const int pix_new = uni(mp.c[st_conv].src_pix[st_src]);
+            if (pix_new != st_pix) { st_pix = pix_new; stage_cols(); }
+#else
             st_pix = mp.c[st_conv].src_pix[st_src];
+#endif
         }
     };
     int st_tile = blockIdx.x, st_chunk = 0;
@@ -163,6 +213,22 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     // one load instruction per call and lane, always (padding reads 16 B of zeros): hipcc's wait insertion then counts exactly.  (Asm loads with
     // hand-counted waits -- hipcc does not see the LDS-DMAs queued behind the rows, so its counts are short of them -- were tried: 304 k -> 322 k
     // cycles per 6 x 128->64 launch, the 64-bit address pairs cost registers the loop does not have.)
+#if WY_BUF
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    auto row_rsrc = [&](int i, bool whole) {                  // resource of image row st_row0 + i, channels from st_cb on (all scalar); whole: no row check (the tail's lanes carry their own)
+        const int off = ((st_row0 + i) * W * st_pix + st_cb) * 4;      // (32-bit: every tensor of a launch spans < 2 GiB; row -1 gives a negative offset that is never dereferenced)
+        const bool row_ok = whole || (st_row0 + i >= 0 && st_row0 + i < H);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)st_base + off), (short)0, row_ok ? 0x7fffffff : 0, 0x00020000);
+    };
+    auto issue_row = [&](int r, int i) {                      // round r of the cursor's phase, row d_i of this lane's column
+        d[r][i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(row_rsrc(i, false), (int)st_vcol[r], 0, 0));
+    };
+    auto issue_d = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_row(r, i);
+    };
+    auto issue_dx = [&]() { dx = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(row_rsrc(0, true), (int)st_vtail, 0, 0)); };
+#else
     auto load_at = [&](int pixel, bool ok) -> f32x4 {
         const SAVSR_GLOBAL float* src = ok ? (const SAVSR_GLOBAL float*)st_base + (pixel * st_pix + st_cb + 4 * q4)
                                            : (const SAVSR_GLOBAL float*)g_wy_zero16;
@@ -177,6 +243,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
         for (int i = 0; i < 4; ++i) issue_row(r, i);
     };
     auto issue_dx = [&]() { dx = load_at(st_pxt, st_pxt != INVALID); };
+#endif
     // LDS byte offsets of this lane's staging stores inside a (hf, vr, part) plane of its wave's V region
     bf16x8* vwave = smem + wave * V_WAVE;
     constexpr int PLANE_B = V_PLANE * 16;                     // bytes per plane; plane index = (hf * 2 + vr) * 2 + part
@@ -233,12 +300,19 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     auto store_vt23 = [&]() { tail_store(1, dx); };           // (half A)
     // weight slab half hf of the cursor's phase: 24 pieces of 1 KiB, 3 per wave, straight into LDS (the packed image IS the LDS image)
     bf16x8* wlds = smem + 8 * V_WAVE;
+    [[maybe_unused]] const unsigned lane16 = (unsigned)lane * 16u;
     auto issue_w = [&](int j, int hf) {
         const int piece = wave_s * 3 + j;
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(wlds + hf * W_HALF + piece * 64));
         unsigned keep;
+#if WY_BUF
+        // scalar 64-bit piece address + one constant per-lane byte offset (the cursor is scalar: no 64-bit vector address per piece)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(st_w + hf * W_HALF + piece * 64), "s"(dst) : "memory");
+#else
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(st_w + hf * W_HALF + piece * 64 + lane), "s"(dst) : "memory");
+#endif
     };
 
     // Fragment registers: per step s = (position-in-half, kx) one activation pair (hi, lo) and per sub-step (s, t) one weight pair; both
@@ -293,7 +367,10 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[pz][t][i] = 0.f;
-        const bool rows_in = __builtin_amdgcn_readfirstlane(y0 + 2 * wave < H ? 1 : 0) != 0;      // the pair's first row inside the image
+        // the pair's first row inside the image.  From wave_s (scalar), not through a readfirstlane of the comparison: hipcc folds that into
+        // readfirstlane.i1, which its uniformity analysis does not know to be uniform -- the branch below then counts as divergent and every
+        // field of the staging cursor that the two phase bodies advance is carried in VECTOR registers from there on
+        const bool rows_in = y0 + 2 * wave_s < H;
         for (int chunk = 0; chunk < mp.nchunk; ++chunk) {
             auto phase = [&](auto mm) {
                 constexpr bool MM = decltype(mm)::value;      // false: both rows below the image -> no matrix work (everything else as usual)

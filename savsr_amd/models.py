@@ -139,7 +139,7 @@ class VideoBaseModel(BaseModel):
         my_folders = list(dict.fromkeys(folders_all[i] for i in mine))
         if hasattr(dataset, "prefetch") and my_folders:
             dataset.prefetch(my_folders[0])
-        if streams > 1:
+        if many:
             net.eval()                                                # once per call (a recursive walk over ~300 modules: 3 ms)
         timing = bool(self.opt.get("profile_gpu_time"))
         ev = []                                                        # (start, end) HIP events around the device work of a group
@@ -159,15 +159,15 @@ class VideoBaseModel(BaseModel):
             first = dataset[mine[k]]
             h, w = int(first["lq"].shape[-2]), int(first["lq"].shape[-1])
             # clips per launch sequence only where the engine batches them (small frames); large frames keep the one-clip-per-stream rule
-            unit = max(1, int(getattr(eng, "clip_batch", 1))) if (streams > 1 and h * w <= int(getattr(eng, "clip_batch_max_px", 0))
-                                                                  and net.engine().cfg.get("interval", 0) == 0) else 1
-            for a, b in (chunk_block(k1 - k, streams, unit) if streams > 1 else [(i, i + 1) for i in range(k1 - k)]):
+            unit = max(1, int(getattr(eng, "clip_batch", 1))) if (many and h * w <= int(getattr(eng, "clip_batch_max_px", 0))
+                                                                  and eng.cfg.get("interval", 0) == 0) else 1
+            for a, b in (chunk_block(k1 - k, streams, unit) if many else [(i, i + 1) for i in range(k1 - k)]):
                 k0, k_end = k + a, k + b
                 vals = [first if idx == mine[k] else dataset[idx] for idx in mine[k0:k_end]]
                 if timing:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                if streams > 1:        # (a lone frame too: forward_many's result for a frame does not depend on the frames that came with it)
+                if many:               # (a lone frame too: forward_many's result for a frame does not depend on the frames that came with it)
                     outs = net.forward_many([v["lq"] for v in vals], [self._group_scale(net)] * len(vals))
                 else:
                     outs = None

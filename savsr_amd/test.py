@@ -15,7 +15,7 @@ Command line (lbasicsr/test.py's `-opt`), with the real-data checker:
 
 runs the unchanged YAML (weights at path.pretrain_network_g, frames at datasets.*.dataroot_gt), prints the per-dataset metric table
 and, with --check-readme, each dataset's difference to the numbers the reference publishes for `savsr_best.pth`
-(/root/reference/README.md:86-124, committed as data in tests/golden/readme_psnr.json); exits 1 when any dataset is further than
+(/root/reference/README.md:86-124, committed as data in savsr_amd/data/readme_psnr.json); exits 1 when any dataset is further than
 0.01 dB / 1e-4 (+ half a unit of the published rounding) from its README entry, 2 when a dataset has no README entry.
 """
 from __future__ import annotations
@@ -89,7 +89,7 @@ def run_test(opt: Union[str, dict], root_path: str = ".", model=None) -> List[di
 
 
 # ----------------------------------------------------------------------------------------------- real-data checker
-README_TABLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "readme_psnr.json")
+README_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "readme_psnr.json")
 TOL_PSNR, TOL_SSIM = 0.01, 1e-4                 # north_star: Vid4 x4 PSNR within 0.01 dB of the reference; SSIM 1e-4
 ROUND_PSNR, ROUND_SSIM = 0.005, 0.00005         # the README prints 2 / 4 decimals
 

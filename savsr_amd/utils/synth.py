@@ -16,8 +16,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-_MANIFEST = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
-                         "tests", "golden", "state_manifest.json")
+_MANIFEST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "state_manifest.json")
 
 
 def load_manifest(path: str | None = None):

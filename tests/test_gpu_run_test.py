@@ -144,8 +144,9 @@ def test_run_test_yaml_to_metric_table(workdir, synth_sd):
 
 
 def test_frames_in_flight_equal_one_at_a_time(workdir, monkeypatch):
-    """The validation loop keeps SAVSR_STREAMS frames in flight on HIP streams; per-frame results are bitwise those of the
-    reference's one-frame-at-a-time flow (video_base_model.py:51-53)."""
+    """The validation loop keeps SAVSR_STREAMS launch units in flight on HIP streams; per-frame results are bitwise those of one stream
+    carrying the frames one launch unit after the other (the reference's flow, video_base_model.py:51-53, is one frame at a time): every
+    frame takes the engine's throughput flow, whose result does not depend on the grouping or the stream count."""
     from savsr_amd.test import run_test
     opt = _opt(workdir)
     opt["val"]["save_img"] = False
@@ -158,6 +159,32 @@ def test_frames_in_flight_equal_one_at_a_time(workdir, monkeypatch):
         assert a["metrics"] == b["metrics"]
         for f in a["frames"]:
             assert torch.equal(a["frames"][f], b["frames"][f])
+
+
+def test_job_plan_equals_dataset_by_dataset(workdir, monkeypatch):
+    """run_test's default (models.validate_job: all datasets of the YAML as one job, folder-major segments, ONE gather) returns exactly the
+    tables of the reference's dataset-by-dataset loop (lbasicsr/test.py:37-48; SAVSR_JOB_PLAN=0), and so does every rank's share of an
+    emulated world of three put together (rows a rank does not own stay zero in an emulated run)."""
+    from savsr_amd.test import run_test
+    opt = _opt(workdir)
+    opt["val"]["save_img"] = False
+    job = run_test(opt)
+    monkeypatch.setenv("SAVSR_JOB_PLAN", "0")
+    loop = run_test(_opt(workdir) | {"val": dict(opt["val"])})
+    monkeypatch.delenv("SAVSR_JOB_PLAN")
+    for a, b in zip(job, loop):
+        assert a["dataset"] == b["dataset"] and a["scale"] == b["scale"] and a["metrics"] == b["metrics"] and a["folders"] == b["folders"]
+        assert all(torch.equal(a["frames"][f], b["frames"][f]) for f in a["frames"])
+    acc = None
+    for r in range(3):
+        o = _opt(workdir)
+        o["val"]["save_img"] = False
+        o["rank"], o["world_size"], o["dist"], o["emulate_world"] = r, 3, False, True
+        part = run_test(o)
+        acc = [{f: t["frames"][f].clone() for f in t["frames"]} for t in part] if acc is None else \
+            [{f: x[f] + t["frames"][f] for f in x} for x, t in zip(acc, part)]
+    for a, x in zip(job, acc):
+        assert all(torch.equal(a["frames"][f], x[f]) for f in x)
 
 
 def test_post_resize_when_output_and_gt_differ(workdir):
@@ -230,7 +257,7 @@ def test_rccl_single_rank_gather(workdir):
             got = run_test(opt)
         finally:
             dist.all_gather_into_tensor = orig
-        assert len(calls) == 2, "one collective per dataset"
+        assert len(calls) == 1, "ONE collective for the job (both datasets' rows in one all_gather_into_tensor)"
         for a, b in zip(base, got):
             assert a["metrics"] == b["metrics"]
             for f in a["frames"]:
@@ -286,9 +313,9 @@ def test_sharded_datasets_read_their_block_only(workdir, monkeypatch):
 
 def test_two_ranks_on_one_gpu(workdir, tmp_path):
     """The N > 1 flow end to end on the hardware at hand: TWO ranks (fresh processes from torch.distributed.run, both on cuda:0,
-    gloo group because RCCL refuses two ranks on one device) run run_test(opt) over the PNG tree -- per-folder block partition,
-    every rank reading only its block + window reach, ONE gather per dataset, aggregation -- and both return exactly the
-    single-process table."""
+    gloo group because RCCL refuses two ranks on one device) run run_test(opt) over the PNG tree -- the job plan of harness.plan_job
+    ((dataset, folder) units cut over the ranks), every rank reading only its segments + window reach, ONE gather of the job's rows,
+    aggregation -- and both return exactly the single-process table."""
     import subprocess
     import sys
     from savsr_amd.test import run_test
@@ -351,7 +378,8 @@ def test_bench_emulate_world_predicts_strong_scaling():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["bench_config"] == "run_test --emulate-world" and d["emulated_world"] == 2 and d["n_gpus"] == 1
-    assert d["world1"]["frames"] == 4 * 4 * 6 and [x["frames"] for x in d["ranks"]] == [4 * 2 * 6, 4 * 2 * 6]
+    assert d["world1"]["frames"] == 4 * 4 * 6 and sum(x["frames"] for x in d["ranks"]) == 4 * 4 * 6 and all(x["frames"] > 0 for x in d["ranks"])
+    assert d["ranks_timed"] == [0, 1] and all(len(x["folders"]) <= 3 for x in d["ranks"])      # (the job plan: folder-major pieces)
     for k in ("predicted_strong_scaling_eff_cold", "predicted_strong_scaling_eff_steady"):
         assert 0.05 < d[k] < 1.3, (k, d[k])
     loss = d["loss_breakdown_cold_slowest_rank"]

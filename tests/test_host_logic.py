@@ -289,3 +289,27 @@ def test_hr_plans_table_is_wellformed():
         assert len(p) == 5 and all(isinstance(v, int) for v in p), (k, p)
         variant, rows, cols32, h, w = p
         assert 0 <= variant < 5 and rows % 4 == 0 and 4 <= rows <= 64 and 1 <= cols32 <= 8 and h >= 2 and w >= 2, (k, p)
+
+
+def test_engine_config_reads_every_switch_once(monkeypatch):
+    """savsr_amd/config.py is the ONE place the engine's SAVSR_* switches are read: defaults = the product configuration (no knobs), the
+    environment changes fields, knobs() lists exactly the changed ones, and none of the engine modules looks at the environment itself."""
+    import os
+    from savsr_amd.config import EngineConfig
+    for k in list(os.environ):
+        if k.startswith("SAVSR_"):
+            monkeypatch.delenv(k)
+    c = EngineConfig.from_env()
+    assert c == EngineConfig() and c.knobs() == {}
+    assert (c.streams, c.clip_batch, c.graphs, c.conv_wy, c.satu_q, c.cache_gb) == (3, 3, True, True, True, None)
+    monkeypatch.setenv("SAVSR_STREAMS", "2")
+    monkeypatch.setenv("SAVSR_CLIP_BATCH", "4")
+    monkeypatch.setenv("SAVSR_CONV_WY", "0")
+    monkeypatch.setenv("SAVSR_CACHE_GB", "6.5")
+    monkeypatch.setenv("SAVSR_HR_VARIANT", "1")
+    c = EngineConfig.from_env()
+    assert c.knobs() == {"streams": 2, "clip_batch": 4, "conv_wy": False, "cache_gb": 6.5, "hr_variant": 1}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mod in ("engine", "cache", "launch", "packing"):
+        src = open(os.path.join(root, "savsr_amd", mod + ".py")).read()
+        assert "os.environ" not in src and "getenv" not in src, mod

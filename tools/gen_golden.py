@@ -46,7 +46,7 @@ def main():
     ref = ref_import.load_reference_arch()
     net = ref.SAVSR().eval()
     manifest = synth.manifest_of(net.state_dict())
-    with open(os.path.join(GOLD, "state_manifest.json"), "w") as f:
+    with open(os.path.join(ROOT, "savsr_amd", "data", "state_manifest.json"), "w") as f:
         json.dump(manifest, f)
     sd = synth.synth_state_dict(manifest, seed=0)
     net.load_state_dict(sd, strict=True)

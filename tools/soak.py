@@ -6,10 +6,9 @@ eighth call a block of Vid4-sized clips (180x320, a YAML scale) so that batched 
 created and dropped between the small ones.  A clip's pixels are a function of (shape, k) with k in 0..2, so every (shape, scale, k) recurs.
 
 Checks (the exit code is non-zero if one fails):
-  * every output equals the first output of the same (shape, scale, k) -- across evictions, re-captures, other streams: BITWISE when the
-    launch sequence chose the same conv forms, and within 3e-5 otherwise (the engine picks Winograd-y or the direct kernel per LAUNCH by its tile
-    count, savsr_amd/engine.py conv_launch, so a clip that travels with two equal-shaped clips can take the other form for some convs; with
-    SAVSR_CONV_WY=0 in the environment there is one form and the run demands bitwise equality throughout);
+  * every output equals the first output of the same (shape, scale, k) BITWISE -- across evictions, re-captures, other streams and other
+    groupings (since round 6 the conv form of a launch is a function of the flow and the shape, not of the clips batched with a frame:
+    savsr_amd/engine.py `form_nb`);
   * the budget account equals the sum of the engines' resident contexts and never exceeds limit + the contexts in use;
   * device memory (torch reserved, and the driver's used bytes) in the last quarter of the run is not above the first quarter's peak by more
     than one context -- i.e. nothing grows with the number of clips;
@@ -22,7 +21,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--cache-gb", type=float, default=6.0)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--mode", default="budget", choices=["budget", "count-evict"],
+                help="count-evict: the variant that would catch an eviction-safety violation -- 540x960-class clips (5 GB per context), SAVSR_CACHE_SHAPES=2 "
+                     "against 5 shapes, a byte budget ABOVE the working set (empty_cache() never runs: dropped contexts' memory goes straight back to the "
+                     "allocator's cache, from where the next capture takes it), three streams, the host four calls ahead of any check")
 args = ap.parse_args()
+if args.mode == "count-evict":
+    os.environ["SAVSR_CACHE_SHAPES"] = "2"
+    os.environ["SAVSR_STREAMS"] = "3"
+    args.cache_gb = max(args.cache_gb, 200.0)
 os.environ["SAVSR_CACHE_GB"] = str(args.cache_gb)
 
 import torch
@@ -49,13 +56,52 @@ def digest(t):
     return int(b.sum().item()), int((b * ((idx % 8191) + 1)).sum().item())
 
 
+BIG = [(540, 960), (536, 960), (540, 952), (532, 944), (528, 960)]
+BIG_SCALES = [(4.0, 4.0), (2.0, 2.0), (3.5, 2.0)]
+_clip_cache = {}
+
+
+def big_clip(h, w, k):
+    if (h, w, k) not in _clip_cache:
+        _clip_cache[(h, w, k)] = clip(h, w, k)
+    return _clip_cache[(h, w, k)]
+
+
 first, clips_done, calls, mism = {}, 0, 0, []
-strict = os.environ.get("SAVSR_CONV_WY", "1") == "0"
+strict = True
 n_form, worst_form = 0, 0.0
 mem, acct_bad, largest = [], [], 0
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < args.seconds:
     calls += 1
+    if args.mode == "count-evict":
+        # four calls enqueued back to back (no host wait in between: ~25 large frames of 20-70 ms each in flight behind the host), every call
+        # walking more shapes than SAVSR_CACHE_SHAPES holds, so contexts whose graphs are still replaying are dropped and their memory re-captured
+        burst = []
+        for _ in range(4):
+            items = []
+            for _ in range(rng.choice((5, 6, 7))):
+                h, w = BIG[rng.randrange(len(BIG))]
+                items.append((h, w, BIG_SCALES[rng.randrange(len(BIG_SCALES))], rng.randrange(2)))
+            with torch.no_grad():
+                outs = net.forward_many([big_clip(h, w, k) for (h, w, sc, k) in items], [sc for (_, _, sc, _) in items])
+            burst.append((items, outs))
+        for items, outs in burst:
+            for it, o in zip(items, outs):
+                d = digest(o)
+                d0 = first.setdefault(it, d)
+                if d0 != d:
+                    mism.append(f"{it}: digest differs from the first visit")
+            clips_done += len(items)
+        del burst
+        st = eng.cache_stats()
+        total = sum(e.cache_stats()["bytes"] for e in [eng] + eng._siblings)
+        largest = max([largest] + [e._ctx_bytes(c) for e in [eng] + eng._siblings for c in e._ctx.values()])
+        if total != st["budget_used"]:
+            acct_bad.append((calls, total, st["budget_used"]))
+        free_b, total_b = torch.cuda.mem_get_info()
+        mem.append((time.perf_counter() - t0, torch.cuda.memory_reserved(), total_b - free_b, st["budget_used"]))
+        continue
     if calls % 8 == 0:
         sc = W.YAML_SCALES[rng.randrange(len(W.YAML_SCALES))]
         items = [(180, 320, sc, rng.randrange(3)) for _ in range(rng.choice((3, 6, 9)))]
@@ -100,6 +146,10 @@ res = {"tool": "soak", "seconds": round(wall, 1), "calls": calls, "clips": clips
        "device_used_gb_first_quarter_peak": round(peak(mem[:q], 2) / 2**30, 3), "device_used_gb_last_quarter_peak": round(peak(mem[-q:], 2) / 2**30, 3),
        "host_stats": hs}
 res["largest_context_gb"] = round(largest / 2**30, 3)
+res["mode"], res["limbo_peak"], res["limbo_end"] = args.mode, st.get("limbo_peak"), st.get("limbo")
+res["cache_shapes"] = eng.max_shapes
+if args.mode == "count-evict":
+    one_ctx = 8 << 30                       # (540x960: ~5 GB per context and stream; the limbo holds a few while their replays finish)
 over_budget = peak(mem, 3) > st["budget_limit"] + (1 + len(eng._siblings)) * largest        # (limit + what the streams have in use)
 res["over_budget"] = bool(over_budget)
 ok = not mism and not acct_bad and not over_budget and grow_reserved <= one_ctx and grow_used <= one_ctx
