@@ -7,7 +7,7 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Config 2 (default): a "step" is one pass of the hot path (SAVSR.forward) over one batch of `--clips-per-step` synthetic
-7x3x180x320 clips already resident in HBM, scale x4 -> 720x1280 (the batch keeps 3 clips in flight on 3 HIP streams), followed by
+7x3x180x320 clips already resident in HBM, scale x4 -> 720x1280 (16 clips: two HIP streams x four clips per launch sequence x two units), followed by
 the GPU PSNR-Y / SSIM-Y of every output frame against a synthetic ground truth.  Clips are independent, so for N > 1
 every rank runs its own K steps (weak scaling, no data-path collective); the only collective is ONE RCCL all_gather of the
 per-frame [PSNR-Y, SSIM-Y] rows, as the reference reduces its metric tensor once per dataset
@@ -401,7 +401,7 @@ def run_config2(args, rank, world, dev, dist):
     hr_mpx = H * W / 1e6
     value = world * args.steps * cps * hr_mpx / elapsed
     line = base_line(args, world, value, elapsed, "BASELINE config 2: synthetic 7x3x180x320 clips, scale x4 -> 720x1280, key-seeded random-init weights",
-                     {"frames_per_step": cps, "streams_per_gpu": min(cps, eng.n_streams), "clips_per_launch_sequence": eng.clip_batch})
+                     {"frames_per_step": cps, "streams_per_gpu": min(cps, eng.streams_for(LR_H * LR_W)), "clips_per_launch_sequence": eng.clip_batch})
     line["config"]["knobs"] = eng.knobs.knobs()          # non-default SAVSR_* switches of the engine (savsr_amd/config.py); empty = product configuration
     line["metric"] = "HR Mpixels/sec (Vid4-shape x4, 7-frame window)"
     line["timed_region_s"] = round(elapsed, 3)
@@ -485,7 +485,7 @@ def run_config2(args, rank, world, dev, dist):
         cb["gpu_vs_oracle_max_abs_one_clip_flow"] = float((got_1 - ref[0]).abs().max())
         cb["d_psnr_y_timed_path_vs_oracle"] = abs(m["gpu"][0] - m["oracle"][0])
         cb["d_ssim_y_timed_path_vs_oracle"] = abs(m["gpu"][1] - m["oracle"][1])
-        cb["timed_path_note"] = (f"clip 0 of a step of the timed configuration ({cps} clips per step, {min(cps, eng.n_streams)} streams x {eng.clip_batch} clips per launch "
+        cb["timed_path_note"] = (f"clip 0 of a step of the timed configuration ({cps} clips per step, {min(cps, eng.streams_for(LR_H * LR_W))} streams x {eng.clip_batch} clips per launch "
                                  "sequence) against the oracle's output for the same clip; PSNR-Y / SSIM-Y of both against the synthetic GT (host metrics)")
         line["gpu_vs_oracle_max_abs_timed_path"] = cb["gpu_vs_oracle_max_abs_timed_path"]
         line["cpu_baseline"] = cb
@@ -886,8 +886,8 @@ def main():
     ap.add_argument("--tree", type=str, default="", help="(internal: an existing synthetic PNG tree + net.pth)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--regions", type=int, default=3, help="config 2: timed regions of K steps each (value = the median region)")
-    ap.add_argument("--clips-per-step", type=int, default=18,
-                    help="independent clips per step (3 in flight on separate HIP streams; 18 keeps a 20-step timed region at ~3 s)")
+    ap.add_argument("--clips-per-step", type=int, default=16,
+                    help="independent clips per step (two HIP streams x four clips per launch sequence x two units; 16 keeps a 20-step timed region at ~2.3 s)")
     ap.add_argument("--scales", type=str, default="", help="config 3: comma-separated subset, e.g. 1.1,2.5,4")
     ap.add_argument("--no-bucket", action="store_true", help="config 5: keep the draw order instead of grouping equal (shape, scale) clips")
     args = ap.parse_args()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 26
+#define SAVSR_ABI_VERSION 27
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -134,8 +134,8 @@ int64_t savsr_conv_wy_packed_elems(int cout, int cin);
 int64_t savsr_conv_wy_pack_index(int cout, int cin, int co, int ci, int pos, int kx);
 int savsr_conv_pool_blocks(int h, int w);
 int savsr_conv2d(const savsr_conv_desc* d, void* stream);
-/* n (1..savsr_conv2d_max_batch() = 18; 6 up to ABI 25) independent convs of identical geometry (ksize, nsrc, src_ch, h, w, cout) in ONE launch:
- * e.g. the per-stream convs of a ResidualBlock (savsr_arch.py:402,413) of both propagation directions -- and, since ABI 26, of up to three
+/* n (1..savsr_conv2d_max_batch() = 24 since ABI 27; 18 in ABI 26, 6 before) independent convs of identical geometry (ksize, nsrc, src_ch, h, w, cout) in ONE launch:
+ * e.g. the per-stream convs of a ResidualBlock (savsr_arch.py:402,413) of both propagation directions -- and, since ABI 26 / 27, of up to three / four
  * clips of one (shape, scale) whose launch sequences the caller runs as one (small clips are launch-latency-bound).  More workgroups than CUs, so workgroups run out of phase and the
  * load/store bursts of one overlap the MFMA phases of another. */
 int savsr_conv2d_max_batch(void);
@@ -183,9 +183,9 @@ typedef struct savsr_osconv_attn_desc {
                                                 than the three launches on MI355X; the engine leaves it off */
 } savsr_osconv_attn_desc;
 int savsr_osconv_weights(const savsr_osconv_attn_desc* d, void* stream);
-/* n (1..6) independent OSConvs of identical cin / cout / hidden / knum in one set of launches (the two
- * propagation directions of a ResidualBlock pair, savsr_arch.py:399-415). */
-int savsr_osconv_weights_max_batch(void);     /* 6 */
+/* n (1..savsr_osconv_weights_max_batch() = 8 since ABI 27; 6 before) independent OSConvs of identical cin / cout / hidden / knum in one set of
+ * launches (the two propagation directions of a ResidualBlock pair, savsr_arch.py:399-415, x up to four clips of a batched launch sequence). */
+int savsr_osconv_weights_max_batch(void);     /* 8 */
 int savsr_osconv_weights_batch(const savsr_osconv_attn_desc* descs, int n, void* stream);
 
 /* RCAN ChannelAttention gate (savsr_arch.py:514-520): gate = sigmoid(W2 ReLU(W1 mean + b1) + b2) */

@@ -18,7 +18,7 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 26
+ABI_VERSION = 27
 CONV_DIRECT, CONV_DIRECT_THROUGHPUT, CONV_WINOGRAD_Y = 0, 2, 3
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27

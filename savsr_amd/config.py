@@ -21,8 +21,10 @@ def _flag(name: str, default: bool) -> bool:
 @dataclass
 class EngineConfig:
     # ---- flow ------------------------------------------------------------------------------------------------------------------
-    streams: int = 3                       # SAVSR_STREAMS: launch units of a batch / of forward_many in flight on separate HIP streams
-    clip_batch: int = 3                    # SAVSR_CLIP_BATCH: clips of one (shape, scale) per launch sequence (capped by the library's batch limits)
+    streams: int = 3                       # SAVSR_STREAMS: launch units of a batch / of forward_many in flight on separate HIP streams (small frames)
+    streams_large: int = 2                 # SAVSR_STREAMS_LARGE: ... when the LR frames of a call average at least `streams_large_px` pixels
+    streams_large_px: int = 40000          # SAVSR_STREAMS_LARGE_PX
+    clip_batch: int = 4                    # SAVSR_CLIP_BATCH: clips of one (shape, scale) per launch sequence (capped by the library's batch limits: 24 convs / 8 OSConvs per launch)
     clip_batch_max_px: int = 200 * 352     # SAVSR_CLIP_BATCH_MAX_PX: LR frames up to this many pixels share launch sequences
     graphs: bool = True                    # SAVSR_GRAPHS: replay captured hipGraphs (0: issue every launch from Python -- diagnostics)
     capture_after: int = 0                 # SAVSR_CAPTURE_AFTER: a context's first n frames run eagerly, then the graphs are captured
@@ -52,7 +54,9 @@ class EngineConfig:
         var = e("SAVSR_HR_VARIANT")
         return cls(
             streams=max(1, int(e("SAVSR_STREAMS", "3"))),
-            clip_batch=max(1, int(e("SAVSR_CLIP_BATCH", "3"))),
+            streams_large=max(1, int(e("SAVSR_STREAMS_LARGE", e("SAVSR_STREAMS", "2")))),
+            streams_large_px=int(e("SAVSR_STREAMS_LARGE_PX", "40000")),
+            clip_batch=max(1, int(e("SAVSR_CLIP_BATCH", "4"))),
             clip_batch_max_px=int(e("SAVSR_CLIP_BATCH_MAX_PX", str(200 * 352))),
             graphs=_flag("SAVSR_GRAPHS", True),
             capture_after=max(0, int(e("SAVSR_CAPTURE_AFTER", "0"))),

@@ -25,10 +25,10 @@ struct ConvParams {
 };
 
 #ifndef SAVSR_CONV_MAX_BATCH
-#define SAVSR_CONV_MAX_BATCH 18
+#define SAVSR_CONV_MAX_BATCH 24
 #endif
-constexpr int CONV_MAX_BATCH = SAVSR_CONV_MAX_BATCH;     // convs of identical geometry per launch: 6 (both propagation directions x 3 streams of a block) x up to 3 CLIPS of one
-                                       // (shape, scale) batched into the launches (round 5); 18 x 160 B of descriptors + 36 B < the 4 KB a kernel argument may have
+constexpr int CONV_MAX_BATCH = SAVSR_CONV_MAX_BATCH;     // convs of identical geometry per launch: 6 (both propagation directions x 3 streams of a block) x up to 4 CLIPS of one
+                                       // (shape, scale) batched into the launches (round 5: 3, round 6: 4); 24 x 160 B of descriptors + 36 B = 3 876 B < the 4 KB a kernel argument may have
 constexpr int CONV_WIDE_MIN_TILES = 200;       // 16-row tiles are used when a launch has at least this many of them ...
 constexpr int CONV_WIDE_MIN_TILES_TP = 100;    // ... or this many in throughput mode (SAVSR_CONV_DIRECT_THROUGHPUT)
 constexpr int CONV_PERSISTENT_BLOCKS = 256;   // one resident workgroup per CU (117-154 KB of LDS each)

@@ -47,6 +47,10 @@
 //    step, which cut each step into its own basic block; A/B in one process, round 4: 6 x 128->64 150.6 -> 147.6 us, 6 x 64->64 88.6 -> 87.8);
 //  * a wave with NO row inside the image runs a phase body without MFMAs (a third, one-row body spilled 69 VGPRs in the 16-row kernel).
 
+#ifndef CONV_BUF
+#define CONV_BUF 1                // 1: activation fetch by buffer loads off a scalar staging cursor (round 6); 0: flat global loads with per-load 64-bit vector addresses
+#endif
+
 namespace savsr {
 
 // Diagnostics (not used by the product path): per-workgroup s_memtime stamps, enabled by
@@ -111,6 +115,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     const bool dbg_nost = dbg_all & 64, dbg_nolds = dbg_all & 128;      // epilogue without its global stores / without the LDS transpose
 
     f32x4 b_reg[B_IT];
+    [[maybe_unused]] const unsigned tid16 = (unsigned)tid * 16u;
 
     struct TileInfo { int conv, cob, x0, y0, tx, ty; };
     auto decode = [&](int tile) {
@@ -133,14 +138,50 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
     const float* st_base = nullptr;
     const f32x4* st_w = nullptr;
     int st_pix = 0, st_cb = 0, st_src = 0, st_conv = 0;
+#if CONV_BUF
+    // Buffer-load form of the activation fetch (round 6, as in conv_wy.hip): the source base and the channel chunk go into the resource's 64-bit
+    // base (scalar ALU), a thread keeps ONE byte offset per staged item -- its pixel inside the tensor, (pixel * pix + 4 c8) * 4, constant over the
+    // K loop of a source -- and halo pixels outside the image carry the offset OOB (>= num_records), which the bounds check answers with zeros.
+    // Everything per-lane here is BRANCH-FREE: a per-lane branch joins in the block where the cursor's scalar fields merge, and hipcc's
+    // uniformity analysis then takes st_base / st_pix / st_cb / st_tile for divergent and carries them in vector registers.
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned st_voff[B_IT];
+    int st_x0 = 0, st_y0 = 0;
+    auto stage_offsets = [&]() {
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int e = tid + i * NTHR;
+            const int pl = e / PER, c8 = e - pl * PER;              // pixel of the tile, float4 of the chunk
+            const int r = pl / IC, c = pl - r * IC;
+            const int gy = st_y0 - HALO + r, gx = st_x0 - HALO + c;
+            const bool ok = (e < B_ITEMS) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+            const unsigned v = (unsigned)((gy * W + gx) * st_pix + c8 * 4) * 4u;
+            st_voff[i] = ok ? v : OOB;
+        }
+    };
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni_ptr = [](const float* q) {
+        const unsigned long long a = (unsigned long long)(uintptr_t)q;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+        return (const float*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+#else
     int st_pixoff[B_IT];
+    auto uni = [](int v) { return v; };
+    auto uni_ptr = [](const float* q) { return q; };
+#endif
     auto stage_begin_tile = [&](const TileInfo& ti) {
         st_conv = ti.conv;
         st_src = 0;
         st_cb = 0;
-        st_base = mp.c[ti.conv].src[0];
-        st_pix = mp.c[ti.conv].src_pix[0];
+        st_base = uni_ptr(mp.c[ti.conv].src[0]);
+        st_pix = uni(mp.c[ti.conv].src_pix[0]);
         st_w = reinterpret_cast<const f32x4*>(mp.c[ti.conv].wimg) + (long long)ti.cob * mp.nchunk * W_UNITS;
+#if CONV_BUF
+        st_x0 = ti.x0;
+        st_y0 = ti.y0;
+        stage_offsets();
+#else
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int e = tid + i * NTHR;
@@ -153,6 +194,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             }
             st_pixoff[i] = off;
         }
+#endif
     };
     auto stage_advance = [&]() {
         st_cb += KC;
@@ -160,8 +202,13 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
         if (st_cb >= mp.src_ch) {
             st_cb = 0;
             ++st_src;
-            st_base = mp.c[st_conv].src[st_src];
+            st_base = uni_ptr(mp.c[st_conv].src[st_src]);
+#if CONV_BUF
+            const int pix_new = uni(mp.c[st_conv].src_pix[st_src]);
+            if (pix_new != st_pix) { st_pix = pix_new; stage_offsets(); }
+#else
             st_pix = mp.c[st_conv].src_pix[st_src];
+#endif
         }
     };
     // Loads of the cursor's phase.  issue_w(g, wbuf): 1 KiB per wave of the weight slab straight into LDS buffer `wbuf`
@@ -175,10 +222,22 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
             const unsigned dst = __builtin_amdgcn_readfirstlane(
                 (unsigned)(uintptr_t)(smem + 2 * B_UNITS + wbuf * W_UNITS + g * NTHR + wave * 64));
             unsigned keep;
+#if CONV_BUF
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(tid16), "s"(st_w + g * NTHR), "s"(dst) : "memory");
+#else
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(st_w + e), "s"(dst) : "memory");
+#endif
         }
     };
+#if CONV_BUF
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    auto issue_b_to = [&](int i, f32x4 (&dstreg)[B_IT]) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(st_base + st_cb), (short)0, 0x7fffffff, 0x00020000);
+        dstreg[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)st_voff[i], 0, 0));
+    };
+#else
     auto issue_b_to = [&](int i, f32x4 (&dstreg)[B_IT]) {
         const int e = tid + i * NTHR;
         const int c8 = e % PER;                                         // float4 of the chunk
@@ -189,6 +248,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                                                : (const SAVSR_GLOBAL float*)st_base + (po * st_pix + st_cb + c8 * 4);
         dstreg[i] = *(const SAVSR_GLOBAL f32x4*)src;
     };
+#endif
     auto issue_b = [&](int i) { issue_b_to(i, b_reg); };
     auto stage_issue = [&](int j, int wbuf) {
         if (j < W_IT) issue_w(j, wbuf);
@@ -873,7 +933,7 @@ extern "C" int savsr_conv2d_max_batch(void) { return CONV_MAX_BATCH; }
 
 extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* stream) {
     if (!descs) return fail_arg("conv: null descriptor");
-    if (n < 1 || n > CONV_MAX_BATCH) return fail_arg("conv: batch size must be 1..18 (savsr_conv2d_max_batch())");
+    if (n < 1 || n > CONV_MAX_BATCH) return fail_arg("conv: batch size must be 1..24 (savsr_conv2d_max_batch())");
     MultiConvParams mp;
     for (int i = 0; i < n; ++i) {
         const int rc = fill_params(descs + i, mp.c[i]);

@@ -59,9 +59,9 @@ __device__ __forceinline__ float wave_dot(const float* __restrict__ w, const flo
 // Up to OSC_MAX_BATCH OSConvs of identical geometry per launch (blockIdx.y picks one): the two propagation
 // directions' OSConvs are independent, and these kernels are launch/latency-bound (a few dozen workgroups each).
 #ifndef SAVSR_OSC_MAX_BATCH
-#define SAVSR_OSC_MAX_BATCH 6
+#define SAVSR_OSC_MAX_BATCH 8
 #endif
-constexpr int OSC_MAX_BATCH = SAVSR_OSC_MAX_BATCH;      // (2 OSConvs of a block pair x up to 3 clips of a batched launch sequence)
+constexpr int OSC_MAX_BATCH = SAVSR_OSC_MAX_BATCH;      // (2 OSConvs of a block pair x up to 4 clips of a batched launch sequence)
 struct OscBatch { savsr_osconv_attn_desc d[OSC_MAX_BATCH]; };
 constexpr int OSC_PARTS = 32;      // interleaved row slices of the pooled-sum reduction
 

@@ -96,12 +96,17 @@ class HipEngine(WeightPacking, ContextCache, Launcher):
         self.reuse_buffers = kn.reuse_buffers      # liveness-planned LR buffers (release()); 0: every name its own memory
         self.wy_min_tiles = kn.wy_min_tiles          # launches with at least this many 16-row tiles take the Winograd form ...
         self.wy_min_tiles_tp = kn.wy_min_tiles_tp    # ... or this many with several clips in flight (throughput tiling)
-        self.n_streams = kn.streams   # clips of a batch in flight concurrently
+        self.n_streams = kn.streams   # launch units of a batch in flight concurrently ...
+        # ... fewer when the frames are large (streams_for): a launch of a >= 40 kpx frame fills the chip on its own, a second stream fills the
+        # launch boundaries and the conv tails, a third only adds contention (config 2, 16-24 clips per step on one lease: 4 clips x 2 streams
+        # 130.4-130.9, x 3 streams 130.1 HR Mpixel/s; the YAML workflow 151 vs 145 frames/s); small clips are launch-latency-bound and want the
+        # third (config 5: 329 clips/s with 3 streams, 311 with 2)
+        self.n_streams_large, self.streams_large_px = kn.streams_large, kn.streams_large_px
         self._siblings: List["HipEngine"] = []
         self._streams: List[torch.cuda.Stream] = []
         self._pack_all({k: v.detach() for k, v in state.items()})
 
-    NB_MAX = 3                  # (class default; the instance reads the library's batch limits: 18 convs / 6 OSConvs per launch => 3 clips)
+    NB_MAX = 4                  # (class default; the instance reads the library's batch limits: 24 convs / 8 OSConvs per launch => 4 clips)
 
     HR_PLANS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hr_plans.json")
 
@@ -140,6 +145,7 @@ class HipEngine(WeightPacking, ContextCache, Launcher):
         e.satu_tail_t, e.satu_w_tail = self.satu_tail_t, self.satu_w_tail
         e.satu_tailq_t, e.satu_w_tailq, e.satu_q = self.satu_tailq_t, self.satu_w_tailq, self.satu_q
         e.nb, e._bstride, e.clip_batch, e.clip_batch_max_px = 1, {}, self.clip_batch, self.clip_batch_max_px
+        e.n_streams, e.n_streams_large, e.streams_large_px = self.n_streams, self.n_streams_large, self.streams_large_px
         e.form_nb = 1
         e.osc = {}
         for k, ent in self.osc.items():
@@ -582,6 +588,10 @@ class HipEngine(WeightPacking, ContextCache, Launcher):
                 gc.enable()
         cur.wait_stream(cap)
 
+    def streams_for(self, px: float) -> int:
+        """HIP streams (launch units in flight) for frames of `px` LR pixels on average."""
+        return self.n_streams_large if px >= self.streams_large_px else self.n_streams
+
     def _ensure_streams(self, ns: int):
         while len(self._siblings) < ns - 1:
             self._siblings.append(self.clone_for_stream())
@@ -626,7 +636,7 @@ class HipEngine(WeightPacking, ContextCache, Launcher):
             units.sort(key=lambda u: u[0])
         else:
             units = [[i] for i in range(len(items))]
-        ns = min(self.n_streams, len(units))
+        ns = min(self.streams_for(sum(lq.shape[-2] * lq.shape[-1] for lq, _ in items) / len(items)), len(units))
         engines = self._ensure_streams(max(ns, 1))
         cur = torch.cuda.current_stream()
         outs: List[Optional[torch.Tensor]] = [None] * len(items)
@@ -670,7 +680,7 @@ class HipEngine(WeightPacking, ContextCache, Launcher):
             # ... and up to `clip_batch` consecutive clips per launch sequence (see `nb`): the batch shares one (shape, scale)
             cb = self.clip_batch if (self.cfg["interval"] == 0 and h * w <= self.clip_batch_max_px) else 1
             units = [(i0, min(i0 + cb, b)) for i0 in range(0, b, cb)]
-            ns = min(self.n_streams, len(units))
+            ns = min(self.streams_for(h * w), len(units))
             engines = self._ensure_streams(ns)
             cur = torch.cuda.current_stream()
             for k in range(ns):

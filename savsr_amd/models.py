@@ -159,6 +159,8 @@ class VideoBaseModel(BaseModel):
             first = dataset[mine[k]]
             h, w = int(first["lq"].shape[-2]), int(first["lq"].shape[-1])
             # clips per launch sequence only where the engine batches them (small frames); large frames keep the one-clip-per-stream rule
+            if many and hasattr(eng, "streams_for"):
+                streams = max(1, int(eng.streams_for(h * w)))             # (fewer launch units in flight for large frames)
             unit = max(1, int(getattr(eng, "clip_batch", 1))) if (many and h * w <= int(getattr(eng, "clip_batch_max_px", 0))
                                                                   and eng.cfg.get("interval", 0) == 0) else 1
             for a, b in (chunk_block(k1 - k, streams, unit) if many else [(i, i + 1) for i in range(k1 - k)]):

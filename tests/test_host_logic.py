@@ -301,14 +301,14 @@ def test_engine_config_reads_every_switch_once(monkeypatch):
             monkeypatch.delenv(k)
     c = EngineConfig.from_env()
     assert c == EngineConfig() and c.knobs() == {}
-    assert (c.streams, c.clip_batch, c.graphs, c.conv_wy, c.satu_q, c.cache_gb) == (3, 3, True, True, True, None)
+    assert (c.streams, c.streams_large, c.clip_batch, c.graphs, c.conv_wy, c.satu_q, c.cache_gb) == (3, 2, 4, True, True, True, None)
     monkeypatch.setenv("SAVSR_STREAMS", "2")
-    monkeypatch.setenv("SAVSR_CLIP_BATCH", "4")
+    monkeypatch.setenv("SAVSR_CLIP_BATCH", "2")
     monkeypatch.setenv("SAVSR_CONV_WY", "0")
     monkeypatch.setenv("SAVSR_CACHE_GB", "6.5")
     monkeypatch.setenv("SAVSR_HR_VARIANT", "1")
     c = EngineConfig.from_env()
-    assert c.knobs() == {"streams": 2, "clip_batch": 4, "conv_wy": False, "cache_gb": 6.5, "hr_variant": 1}
+    assert c.knobs() == {"streams": 2, "clip_batch": 2, "conv_wy": False, "cache_gb": 6.5, "hr_variant": 1}      # (streams_large follows SAVSR_STREAMS when that is set: 2 = its default)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mod in ("engine", "cache", "launch", "packing"):
         src = open(os.path.join(root, "savsr_amd", mod + ".py")).read()
