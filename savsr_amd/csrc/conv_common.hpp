@@ -31,7 +31,10 @@ constexpr int CONV_MAX_BATCH = SAVSR_CONV_MAX_BATCH;     // convs of identical g
                                        // (shape, scale) batched into the launches (round 5: 3, round 6: 4); 24 x 160 B of descriptors + 36 B = 3 876 B < the 4 KB a kernel argument may have
 constexpr int CONV_WIDE_MIN_TILES = 200;       // 16-row tiles are used when a launch has at least this many of them ...
 constexpr int CONV_WIDE_MIN_TILES_TP = 100;    // ... or this many in throughput mode (SAVSR_CONV_DIRECT_THROUGHPUT)
-constexpr int CONV_PERSISTENT_BLOCKS = 256;   // one resident workgroup per CU (117-154 KB of LDS each)
+#ifndef SAVSR_CONV_BLOCKS
+#define SAVSR_CONV_BLOCKS 256
+#endif
+constexpr int CONV_PERSISTENT_BLOCKS = SAVSR_CONV_BLOCKS;   // one resident workgroup per CU (117-154 KB of LDS each)
 struct MultiConvParams {
     ConvParams c[CONV_MAX_BATCH];     // convs of identical geometry:
     int h, w, cout, nchunk, src_ch;   //   shared shape (fixed kernarg offsets: read once, not per tile)
