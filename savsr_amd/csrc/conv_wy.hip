@@ -41,6 +41,9 @@
 #ifndef WY_VALU
 #define WY_VALU 6                 // vector instructions the scheduler may put behind every MFMA of a step
 #endif
+#ifndef WY_FAST_EPILOGUE
+#define WY_FAST_EPILOGUE 1        // 1: launches whose convs all have a max-form activation, no mask and no second residual run the straight-line epilogue (conv_wy_kernel<true>)
+#endif
 #ifndef WY_BUF
 #define WY_BUF 1                  // 1: activation rows by buffer loads (uniform 64-bit row base in the resource, one constant per-lane column offset, out-of-range
 #endif                            //    lanes / rows answered with zeros by the bounds check): no per-load address arithmetic on the vector unit.  0: flat global loads (round 4)
@@ -92,6 +95,10 @@ __device__ __forceinline__ void wy_split_store(const f32x4& v, bf16x4* hi_dst, b
     *lo_dst = lo;
 }
 
+// FAST: every conv of the launch has an activation of the max form (none / ReLU / LeakyReLU with 0 <= slope <= 1), no per-pixel mask and no second
+// residual -- all conv launches of the network but OSAdapt's final one.  The epilogue is then straight-line code: no activation dispatch, no
+// joins whose phi copies cost 8 v_mov each (the generic epilogue carries ~480 of them and is half of the kernel's vector instructions).
+template <bool FAST>
 __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) {
     using namespace wy;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -560,7 +567,14 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(ep + ((lane >> 3) + 16 * ih + 8 * i) * EPS + 4 * c4);
                         v[i] = a4 + b4;
                     }
-                    if (e_act == SAVSR_ACT_NONE) {
+                    if constexpr (FAST) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const f32x4 sv = v[i] * slope_eff;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[i][q] = vmax_raw(v[i][q], sv[q]);
+                        }
+                    } else if (e_act == SAVSR_ACT_NONE) {
                     } else if (act_as_max) {
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
@@ -579,14 +593,14 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
 #pragma unroll
                             for (int q = 0; q < 4; ++q) v[i][q] = sigmoidf_(v[i][q]);
                     }
-                    if (e_mul) {
+                    if (!FAST && e_mul) {
                         const float m0 = ok0 ? ldg1(e_mul, (unsigned)p0) : 0.f, m1 = ok1 ? ldg1(e_mul, (unsigned)(p0 + 8)) : 0.f;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { v[0][q] *= m0; v[1][q] *= m1; }
                     }
                     v[0] += rr[gi % RR][2 * ih];
                     v[1] += rr[gi % RR][2 * ih + 1];
-                    if (e_r2) {
+                    if (!FAST && e_r2) {
                         f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
                         if (ok0) ra = ldg4(e_r2, 4u * (unsigned)(p0 * e_r2pix + co));
                         if (ok1) rb = ldg4(e_r2, 4u * (unsigned)((p0 + 8) * e_r2pix + co));
@@ -649,14 +663,22 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
 }
 
 int launch_conv_wy(const MultiConvParams& mp, hipStream_t st) {
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wy_kernel), (int)wy::LDS_BYTES, "conv_wy")) return rc;
+    if (int rc = conv_wy_prepare_device()) return rc;
     const int total = mp.nconv * mp.ncob * mp.ntx * mp.nty;
     const int grid = total < CONV_PERSISTENT_BLOCKS ? total : CONV_PERSISTENT_BLOCKS;
-    hipLaunchKernelGGL(conv_wy_kernel, dim3(grid), dim3(wy::NTHR), wy::LDS_BYTES, st, mp);
+    bool fast = WY_FAST_EPILOGUE != 0;
+    for (int i = 0; i < mp.nconv && fast; ++i) {
+        const ConvParams& c = mp.c[i];
+        const bool as_max = c.act == SAVSR_ACT_NONE || c.act == SAVSR_ACT_RELU || (c.act == SAVSR_ACT_LRELU && c.slope >= 0.f && c.slope <= 1.f);
+        fast = as_max && !c.mul_px && !c.res2;
+    }
+    if (fast) hipLaunchKernelGGL(conv_wy_kernel<true>, dim3(grid), dim3(wy::NTHR), wy::LDS_BYTES, st, mp);
+    else hipLaunchKernelGGL(conv_wy_kernel<false>, dim3(grid), dim3(wy::NTHR), wy::LDS_BYTES, st, mp);
     return check_launch("conv_wy_kernel");
 }
 int conv_wy_prepare_device() {
-    return ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wy_kernel), (int)wy::LDS_BYTES, "conv_wy");
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wy_kernel<true>), (int)wy::LDS_BYTES, "conv_wy")) return rc;
+    return ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wy_kernel<false>), (int)wy::LDS_BYTES, "conv_wy");
 }
 
 }  // namespace savsr
