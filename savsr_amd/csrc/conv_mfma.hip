@@ -47,9 +47,6 @@
 //    step, which cut each step into its own basic block; A/B in one process, round 4: 6 x 128->64 150.6 -> 147.6 us, 6 x 64->64 88.6 -> 87.8);
 //  * a wave with NO row inside the image runs a phase body without MFMAs (a third, one-row body spilled 69 VGPRs in the 16-row kernel).
 
-#ifndef CONV_FAST_EPILOGUE
-#define CONV_FAST_EPILOGUE 1      // 1: launches whose convs all have a max-form activation, no mask and no second residual run the straight-line epilogue
-#endif
 #ifndef CONV_BUF
 #define CONV_BUF 1                // 1: activation fetch by buffer loads off a scalar staging cursor (round 6); 0: flat global loads with per-load 64-bit vector addresses
 #endif
@@ -79,9 +76,9 @@ __device__ __forceinline__ void stamp(int on, int slot) {
 
 // DIAG: the instrumented build (section stamps, timing experiments), launched only while savsr_debug_conv_stamps is on;
 // as run-time switches the diagnostics cost scalar registers (and spills) in every step of the product kernel.
-// FAST (round 6, as conv_wy_kernel<true>): every conv of the launch has a max-form activation, no per-pixel mask and no second residual ->
-// the whole-record epilogue path is straight-line code (no activation dispatch, none of its phi copies).
-template <int KS, int NT, int PXT, bool DIAG, bool FAST = false>
+// (A straight-line epilogue variant as conv_wy_kernel<true> was built and measured in round 6: 0.4-2.9 % per launch, nothing on the frame or on
+// config 5 -- this kernel is 4 % of the GPU time -- and not kept: profiles/r06_ab_conv_direct_fast_epilogue.log.)
+template <int KS, int NT, int PXT, bool DIAG>
 __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams mp) {
     constexpr int TH = CONV_TH * PXT, NTHR = 64 * CONV_TH;   // wave w owns tile rows w, w + 8, .. (PXT of them)
     constexpr int TAPS = KS * KS, HALO = KS / 2;
@@ -635,14 +632,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
                             else a4 = *reinterpret_cast<const f32x4*>(ep + ((lane >> 3) + 16 * ih + 8 * i) * EPS + 4 * c4);
                             v[i] = a4 + b4;           // (whole-vector forms: two v_pk_add_f32 / v_pk_mul_f32 per quad; written per element
                         }                             //  hipcc issued 4 scalar instructions each, and the epilogue is vector-issue-bound)
-                        if constexpr (FAST) {
-#pragma unroll
-                            for (int i = 0; i < 2; ++i) {
-                                const f32x4 sv = v[i] * slope_eff;
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) v[i][q] = vmax_raw(v[i][q], sv[q]);
-                            }
-                        } else if (e_act == SAVSR_ACT_NONE) {
+                        if (e_act == SAVSR_ACT_NONE) {
                             // nothing to compute (half of the launches: second convs of the residual blocks, merges)
                         } else if (act_as_max) {      // ReLU / LeakyReLU(0..1) as ONE v_max_f32(v, v * s), s = 0 / slope: no branch chain (its
 #pragma unroll                                        // phi copies were 300 v_mov per tile) and no NaN-canonicalising second v_max (fmaxf
@@ -662,14 +652,14 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(const MultiConvParams 
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) v[i][q] = sigmoidf_(v[i][q]);
                         }
-                        if (!FAST && e_mul) {
+                        if (e_mul) {
                             const float m0 = ok0 ? ldg1(e_mul, (unsigned)p0) : 0.f, m1 = ok1 ? ldg1(e_mul, (unsigned)(p0 + 8)) : 0.f;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { v[0][q] *= m0; v[1][q] *= m1; }
                         }
                         v[0] += rr[gi & 1][2 * ih];                                                   // zeros without a residual
                         v[1] += rr[gi & 1][2 * ih + 1];
-                        if (!FAST && e_r2) {
+                        if (e_r2) {
                             f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
                             if (ok0) ra = ldg4(e_r2, 4u * (unsigned)(p0 * e_r2pix + co));
                             if (ok1) rb = ldg4(e_r2, 4u * (unsigned)((p0 + 8) * e_r2pix + co));
@@ -820,35 +810,28 @@ constexpr size_t conv_lds_bytes() {
     return 16ull * 2 * (2 * KSTEPS * 2 * NPX + TAPS * KSTEPS * NT * 2 * 64) + (PXT > 1 ? 0ull : 4ull * CONV_TH * 32 * 36);
 }
 
-template <int KS, int NT, int PXT, bool DIAG, bool FAST>
+template <int KS, int NT, int PXT, bool DIAG>
 static int launch_conv_impl(const MultiConvParams& mp, hipStream_t st) {
     constexpr size_t lds = conv_lds_bytes<KS, NT, PXT>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT, DIAG, FAST>), (int)lds, "conv")) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT, DIAG>), (int)lds, "conv")) return rc;
     const int total = mp.nconv * mp.ncob * mp.ntx * mp.nty;
     const int grid = total < CONV_PERSISTENT_BLOCKS ? total : CONV_PERSISTENT_BLOCKS;   // one resident workgroup per CU
-    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, PXT, DIAG, FAST>), dim3(grid), dim3(64 * CONV_TH), lds, st, mp);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, NT, PXT, DIAG>), dim3(grid), dim3(64 * CONV_TH), lds, st, mp);
     return check_launch("conv_bf16x3_kernel");
 }
 
 template <int KS, int NT, int PXT>
 static int launch_conv(const MultiConvParams& mp, hipStream_t st) {
 #ifdef SAVSR_DIAG
-    if (g_conv_diag_host) return launch_conv_impl<KS, NT, PXT, true, false>(mp, st);
+    if (g_conv_diag_host) return launch_conv_impl<KS, NT, PXT, true>(mp, st);
 #endif
-    bool fast = CONV_FAST_EPILOGUE != 0;
-    for (int i = 0; i < mp.nconv && fast; ++i) {
-        const ConvParams& c = mp.c[i];
-        const bool as_max = c.act == SAVSR_ACT_NONE || c.act == SAVSR_ACT_RELU || (c.act == SAVSR_ACT_LRELU && c.slope >= 0.f && c.slope <= 1.f);
-        fast = as_max && !c.mul_px && !c.res2;
-    }
-    return fast ? launch_conv_impl<KS, NT, PXT, false, true>(mp, st) : launch_conv_impl<KS, NT, PXT, false, false>(mp, st);
+    return launch_conv_impl<KS, NT, PXT, false>(mp, st);
 }
 
 template <int KS, int NT, int PXT>
 static int conv_attr() {
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT, false, true>), (int)conv_lds_bytes<KS, NT, PXT>(), "conv")) return rc;
-    return ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT, false, false>), (int)conv_lds_bytes<KS, NT, PXT>(), "conv");
+    return ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, NT, PXT, false>), (int)conv_lds_bytes<KS, NT, PXT>(), "conv");
 }
 // every product instantiation's dynamic-LDS attribute on the current device (savsr_prepare_device)
 int conv_prepare_device() {
