@@ -211,6 +211,8 @@ class ContextCache:
                     # hipMallocs inside a capture were 40 ms of a 45 ms capture)
                     arena.append([torch.empty(max(nbytes, owner.get("chunk", self.ARENA_CHUNK * self.nb)), device=self.dev, dtype=torch.uint8), 0])
                     self._charge(owner, arena[-1][0].numel())
+                    if self.knobs.poison:      # diagnostics: every fresh chunk full of NaN (inside a capture: a memset node in front of the frame's
+                        arena[-1][0].view(torch.float32).fill_(float("nan"))      # kernels, replayed with it) -- a read of a never-written float shows
                 chunk, off = arena[-1]
                 raw = chunk[off:off + nbytes]
                 arena[-1][1] = off + nbytes

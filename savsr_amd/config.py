@@ -46,6 +46,7 @@ class EngineConfig:
     hr_static: bool = False                # SAVSR_HR_STATIC: static tile order instead of the tile queue
     hr_print_plans: bool = False           # SAVSR_HR_PRINT_PLANS: print what every feasible HR plan measured
     profile_capture: bool = False          # SAVSR_PROFILE_CAPTURE: print the host time of every graph capture
+    poison: bool = False                   # SAVSR_POISON: fresh arena chunks are filled with NaN (a read of a never-written value becomes visible)
 
     @classmethod
     def from_env(cls) -> "EngineConfig":
@@ -75,6 +76,7 @@ class EngineConfig:
             hr_static=e("SAVSR_HR_STATIC") == "1",
             hr_print_plans=bool(e("SAVSR_HR_PRINT_PLANS")),
             profile_capture=bool(e("SAVSR_PROFILE_CAPTURE")),
+            poison=e("SAVSR_POISON") == "1",
         )
 
     def knobs(self) -> dict:

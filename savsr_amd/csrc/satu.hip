@@ -850,11 +850,16 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
     if constexpr (QS) {
         const int px = lane & 31;
         const bool vx = valid0;                                   // this lane's column lies inside the image (X < W)
-        // q = c1 + shr(c0) * m0 + shl(c2) * m31 (wave-wide DPP shifts).  m0 keeps lane 0 of a half from seeing the OTHER half's lane 31,
-        // m31 lane 31 from the other half's lane 0 -- those two terms are the seams' business -- and zeroes the right neighbour's term
+        // q = c1 + shr(c0) [unless px == 0] + shl(c2) [unless px == 31 or the right neighbour lies beyond the image] (wave-wide DPP shifts).
+        // keep_l keeps lane 0 of a half from seeing the OTHER half's lane 31, keep_r lane 31 from the other half's lane 0 -- those two terms are the seams' business -- and zeroes the right neighbour's term
         // where that neighbour lies beyond the image's last column (the tail conv's zero padding; a left neighbour beyond it only
         // feeds pixels that are not stored).
-        const float m0 = px == 0 ? 0.f : 1.f, m31 = (px == 31 || 32 * seg + px + 1 >= p.W) ? 0.f : 1.f;
+        // The neighbours' terms are SELECTED away, not multiplied by 0 (rounds 4-5 used 0 / 1 factors): the lane to the right of the image's
+        // last column -- and lane 31 of a partial last segment, which lane 32 sees as its left neighbour -- are lanes beyond the image, whose
+        // accumulators are computed from whatever lies behind the per-pixel table / coordinate arrays; when that happens to be a NaN or an
+        // infinity, 0 x NaN put a NaN into column W - 1 or into the segment's first column (seen on fresh boxes: ~1 process in 3, a handful of
+        // pixels; tools/soak.py demands finite outputs since round 6).  Same arithmetic for every other lane: x * 1 + y == x + y exactly.
+        const bool keep_l = px != 0, keep_r = !(px == 31 || 32 * seg + px + 1 >= p.W);
 #pragma unroll
         for (int G = 0; G < 2; ++G) {
             const f32x16& acc = G ? b : a;
@@ -871,7 +876,7 @@ __device__ __forceinline__ void hr_tile_px(const HrParams& p, const float* lds, 
             for (int gi = 0; gi < 5; ++gi) {
                 const float l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[3 * gi]), 0x138, 0xf, 0xf, true));        // wave_shr:1: lane i <- lane i - 1
                 const float r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[3 * gi + 2]), 0x130, 0xf, 0xf, true));    // wave_shl:1: lane i <- lane i + 1
-                q[gi] = __builtin_fmaf(r, m31, __builtin_fmaf(l, m0, acc[3 * gi + 1]));
+                q[gi] = (keep_r ? r : 0.f) + ((keep_l ? l : 0.f) + acc[3 * gi + 1]);
             }
             if (valid) {
 #pragma unroll

@@ -696,3 +696,59 @@ def test_weight_images_packed_on_device_equal_host_packing(synth_sd):
     bank = synth_sd["f2p_win.blocks.1.osconv.weight"]
     assert torch.equal(torch.stack([E.pack_conv_part(bank[k].to(dev), dev) for k in range(bank.shape[0])], 0).cpu(),
                        torch.stack([E.pack_conv_part(bank[k]) for k in range(bank.shape[0])], 0))
+
+
+def test_satu_hr_lanes_beyond_the_image_do_not_leak(synth_sd):
+    """Row-summed HR stage, image widths that are no multiple of 32: the lanes of the last 32-pixel segment that lie beyond column W - 1 compute
+    from LDS slots nobody staged (the producers stage the tile's in-image entries only) -- whatever the CU's LDS held before.  Their terms must
+    be SELECTED away, not multiplied by 0: rounds 4-5 multiplied, and 0 x NaN put NaNs into column W - 1 and into the segment's first column
+    whenever the stale LDS bytes happened to be NaNs (fresh boxes: ~1 process in 3; found by tools/soak.py in round 6).  Here every CU's LDS is
+    filled with NaN patterns first (a Winograd conv launch over NaN inputs: 70 KB of split-bf16 NaNs per CU, then the epilogue slices): outputs
+    stay finite and bit-identical to an undisturbed run, in every feasible launch plan."""
+    import savsr_amd
+    from savsr_amd import _lib as L
+    net = savsr_amd.build_network(dict(type="SAVSR")).eval()
+    net.load_state_dict(synth_sd, strict=True)
+    net = net.to("cuda:0")
+    eng = net.engine()
+    dev = torch.device("cuda:0")
+    xnan = torch.full((180, 320, 64), float("nan"), device=dev)
+    sink = [torch.empty(180, 320, 64, device=dev) for _ in range(6)]
+    key = "RG.0.residual_group.0.rcab.0"
+
+    def poison_lds():
+        algo = eng.conv_algo
+        eng.conv_algo = L.CONV_DIRECT_THROUGHPUT
+        try:
+            eng.conv_launch([eng.conv_desc(key, [eng.full(xnan)], eng.full(o), 180, 320) for o in sink], "poison")      # 720 Winograd tiles: every CU
+        finally:
+            eng.conv_algo = algo
+    for (h, w, sc) in [(120, 210, (2.1, 2.1)), (45, 70, (3.7, 3.7)), (60, 75, (2.0, 2.0)), (170, 178, (1.5, 2.5))]:
+        lq = synth.synth_clip(7, 3, h, w, seed=9)[0].to(dev).contiguous()
+        eng.nb = 1
+        eng._set_flow(lq, True)
+        eng._select(lq.shape, sc)
+        c = eng._stage_body(lq, sc)
+        ax = eng.satu_axes(h, w, sc)
+        assert c["W"] % 32 != 0
+        lrcat = eng.satu_lr(c["hfeat"], c["align"], c["wp"], c["h"], c["w"], tail_form=True, q=True)
+        out = torch.empty(3, c["H"], c["W"], device=dev)
+
+        def run(til, poison):
+            c["q9"].fill_(float("nan"))
+            c["seam"].fill_(float("nan"))
+            ax["tiling_tail"] = til
+            if poison:
+                poison_lds()
+            eng.satu_hr(lrcat, h, w, sc, c["q9"], c["plane"], tail_form=True, seam=c["seam"])
+            eng._stage_tail(c, lq, out)
+            torch.cuda.synchronize()
+            return out.clone()
+        plans = ax["tail_plans"]
+        ref = None
+        for til in plans:
+            got = run(til, True)
+            assert bool(torch.isfinite(got).all()), ("NaN leaked from lanes beyond the image", h, w, sc, til.variant, til.tile_rows, til.tile_cols32)
+            if ref is None:
+                ref = got
+            assert torch.equal(got, ref), (h, w, sc, til.variant, til.tile_rows, til.tile_cols32)

@@ -109,7 +109,12 @@ while time.perf_counter() - t0 < args.seconds:
         items = [(h, w, sc, rng.randrange(3)) for (h, w, sc) in W.config5_cases(rng.choice((4, 9, 14)), seed=rng.randrange(1 << 30))]
     with torch.no_grad():
         outs = net.forward_many([clip(h, w, k) for (h, w, sc, k) in items], [sc for (_, _, sc, _) in items])
-    for it, o in zip(items, outs):
+    for j, (it, o) in enumerate(zip(items, outs)):
+        if not bool(torch.isfinite(o).all()):          # (diagnostics: where in the call, how many equal clips came with it, how much of the output)
+            bad = ~torch.isfinite(o)
+            mism.append(f"{it}: NON-FINITE output, call {calls}, item {j} of {len(items)}, {items.count(it)} equal items / {sum(1 for q in items if q[:3] == it[:3])} of its (shape, scale) in the call, "
+                        f"{int(bad.sum())} of {o.numel()} values, first bad row {int(bad.any(dim=-1).any(dim=0).nonzero()[0])}, evictions so far {eng.cache_stats()['evictions']}")
+            continue
         d = digest(o)
         d0, o0 = first.setdefault(it, (d, o.clone()))
         if d0 != d:
@@ -137,7 +142,7 @@ grow_reserved = peak(mem[-q:], 1) - peak(mem[:q], 1)
 grow_used = peak(mem[-q:], 2) - peak(mem[:q], 2)
 one_ctx = 2 << 30
 res = {"tool": "soak", "seconds": round(wall, 1), "calls": calls, "clips": clips_done, "clips_per_s": round(clips_done / wall, 1),
-       "distinct_shape_scale_clip": len(first), "mismatches": len(mism), "mismatch_sample": mism[:5], "bitwise_demanded": strict,
+       "distinct_shape_scale_clip": len(first), "mismatches": len(mism), "mismatch_sample": mism[:12], "bitwise_demanded": strict,
        "other_conv_form_revisits": n_form, "other_conv_form_worst_max_abs": worst_form,
        "cache_gb": args.cache_gb, "evictions": st["evictions"], "resident_shapes_end": st["shapes"],
        "budget_used_peak_gb": round(peak(mem, 3) / 2**30, 3), "budget_limit_gb": round(st["budget_limit"] / 2**30, 3),
