@@ -9,6 +9,8 @@ Checks (the exit code is non-zero if one fails):
   * every output equals the first output of the same (shape, scale, k) BITWISE -- across evictions, re-captures, other streams and other
     groupings (since round 6 the conv form of a launch is a function of the flow and the shape, not of the clips batched with a frame:
     savsr_amd/engine.py `form_nb`);
+  * every output is FINITE (round 6: the row-summed SATU HR stage leaked 0 x NaN from lanes beyond the image when a CU's LDS held NaN patterns
+    -- two events in 9 935 clips of the first strict run; fixed in satu.hip, regression test in tests/test_gpu_kernels.py);
   * the budget account equals the sum of the engines' resident contexts and never exceeds limit + the contexts in use;
   * device memory (torch reserved, and the driver's used bytes) in the last quarter of the run is not above the first quarter's peak by more
     than one context -- i.e. nothing grows with the number of clips;
