@@ -177,13 +177,48 @@ class ContextCache:
             b["last_trim"] = now
         b["trim"] = False
 
+    FORGET_ABOVE = 0.9          # forget() without `always`: only when the shared account stands above this share of its limit
+
+    def forget(self, hw: Tuple[int, int], scale, always: bool = False) -> int:
+        """The caller is DONE with (LR frame size, scale) -- a finished (dataset, folder) unit of a YAML job, which no later dataset revisits
+        (every scale has its own LR size).  With `always` (the job walks many units: models.validate_job) or while the shared account stands above
+        FORGET_ABOVE of its limit, the contexts of that unit are dropped on every engine of the budget -- into the limbo, i.e. released once their
+        last replays are over.  Why: a capture gets slower with the number of contexts ALIVE in the process -- the one-process pass over the
+        shipped Vid4 YAML (168 units, ~640 graph sets alive by the end) spent 19-22 of 83-88 s in 640 captures of 30-35 ms; with finished units
+        forgotten a capture costs 6.5 ms as in a rank of eight and the pass takes 73 s (profiles/r06_emu_world1_forget.json).  Small jobs keep
+        everything resident (a second pass over them replays).  Returns the contexts dropped."""
+        b = self._budget
+        if not always and b["used"] <= self.FORGET_ABOVE * b["limit"]:
+            return 0
+        ckey = (float(scale[0]), float(scale[1]))
+        n = 0
+        for ref in b["engines"]:
+            e = ref()
+            if e is None:
+                continue
+            for skey in [k for k in e._ctx if tuple(k[-2:]) == (int(hw[0]), int(hw[1]))]:
+                ctx = e._ctx[skey]
+                if ckey in ctx["scales"]:
+                    if len(ctx["scales"]) == 1:
+                        e._drop(skey)
+                    else:
+                        e._drop_scale(ctx, ckey)
+                    b["evictions"] -= 1          # (a planned release, not an eviction under pressure)
+                    b["forgotten"] = b.get("forgotten", 0) + 1
+                    n += 1
+                    if e._cur is ctx:
+                        e._cur, e._cur_sc, e._cur_key = e._default_ctx, e._default_sc, None
+        if n:
+            self._reap_limbo()
+        return n
+
     def cache_stats(self) -> dict:
         """Resident contexts of THIS engine; `bytes` = device memory they hold (arena chunks + graph I/O + per-pixel tables), `budget_*` = the
         account shared with the sibling engines."""
         return {"shapes": len(self._ctx), "scales": sum(len(c["scales"]) for c in self._ctx.values()), "axes": len(self._axes),
                 "bytes": sum(self._ctx_bytes(c) for c in self._ctx.values()),
                 "budget_used": self._budget["used"], "budget_limit": self._budget["limit"], "evictions": self._budget["evictions"],
-                "limbo": len(self._budget["limbo"]), "limbo_peak": self._budget["limbo_peak"]}
+                "limbo": len(self._budget["limbo"]), "limbo_peak": self._budget["limbo_peak"], "forgotten": self._budget.get("forgotten", 0)}
 
     ARENA_CHUNK = 64 << 20      # bytes per arena chunk (larger requests get a chunk of their own)
 

@@ -158,6 +158,7 @@ class VideoBaseModel(BaseModel):
                     next_folder[0].prefetch(next_folder[1])
             first = dataset[mine[k]]
             h, w = int(first["lq"].shape[-2]), int(first["lq"].shape[-1])
+            self._last_lr_hw = (h, w)
             # clips per launch sequence only where the engine batches them (small frames); large frames keep the one-clip-per-stream rule
             if many and hasattr(eng, "streams_for"):
                 streams = max(1, int(eng.streams_for(h * w)))             # (fewer launch units in flight for large frames)
@@ -242,6 +243,8 @@ class VideoBaseModel(BaseModel):
         self.metric_results = self.last_validation["frames"]
         return self.last_validation
 
+    FORGET_UNITS = 64      # a rank that walks at least this many (dataset, folder) units releases each unit's engine contexts when it is done with it (cache.forget)
+
     def validate_job(self, datasets, current_iter=None, tb_logger=None, save_img=False):
         """Every dataset of a YAML as ONE job (what lbasicsr/test.py:37-48 loops over, dataset by dataset).  The (dataset, folder) units of
         all datasets are cut over the ranks by harness.plan_job -- folder-major, cost-balanced, whole units wherever possible --, a rank runs
@@ -271,6 +274,11 @@ class VideoBaseModel(BaseModel):
             self._run_frames(ds, list(range(lo, hi)), rows[d][k0:k0 + (hi - lo)], save_img, next_folder=nxt)
             if hasattr(ds, "release_resident") and (nxt is None or nxt[0] is not ds):
                 ds.release_resident()
+            # this rank is done with the unit's (LR size, scale): under memory pressure its engine contexts are recycled now (cache.forget)
+            net = self.net_g.module if hasattr(self.net_g, "module") else self.net_g
+            hw = getattr(self, "_last_lr_hw", None)
+            if hw is not None and hasattr(net, "engine") and hasattr(net.engine(), "forget") and (si + 1 == len(segs) or segs[si + 1][:2] != (d, folder)):
+                net.engine().forget(hw, tuple(net.scale), always=len(segs) >= self.FORGET_UNITS)
         if save_img:
             sio.flush_writes()
         self._settle_gpu_time()

@@ -292,3 +292,32 @@ def test_large_frames_1080p_vs_oracle_and_4k(net, synth_sd):
     assert tuple(out4.shape) == (1, 3, 2160, 3840)
     down = torch.nn.functional.avg_pool2d(out4, 2)
     assert float((down - out2).abs().mean()) < 0.05
+
+
+def test_forget_recycles_a_finished_unit(synth_sd, monkeypatch):
+    """cache.forget((h, w), scale): what the YAML job calls when a rank is done with a (dataset, folder) unit -- under memory pressure (here:
+    forced) the unit's contexts leave every engine of the budget through the limbo, the account stays exact, other units stay resident, and a
+    later visit re-captures to the same bits."""
+    import savsr_amd
+    monkeypatch.setenv("SAVSR_STREAMS", "3")
+    n = savsr_amd.build_network(dict(type="SAVSR")).eval()
+    n.load_state_dict(synth_sd, strict=True)
+    n = n.to("cuda:0")
+    eng = n.engine()
+    a = [synth.synth_clip(7, 3, 24, 40, seed=k)[0].to("cuda:0") for k in range(6)]
+    b = [synth.synth_clip(7, 3, 30, 36, seed=10 + k)[0].to("cuda:0") for k in range(6)]
+    oa = [o.clone() for o in n.forward_many(a, [(2.5, 2.5)] * 6)]
+    ob = [o.clone() for o in n.forward_many(b, [(3.0, 2.0)] * 6)]
+    torch.cuda.synchronize()
+    engs = [eng] + eng._siblings
+    assert eng.forget((24, 40), (2.5, 2.5)) == 0, "far below the budget: nothing is forgotten"
+    before = sum(e.cache_stats()["scales"] for e in engs)
+    dropped = eng.forget((24, 40), (2.5, 2.5), always=True)
+    assert dropped >= 1 and sum(e.cache_stats()["scales"] for e in engs) == before - dropped
+    assert all((24, 40) != tuple(k[-2:]) for e in engs for k in e._ctx) and any((30, 36) == tuple(k[-2:]) for e in engs for k in e._ctx)
+    st = eng.cache_stats()
+    assert st["budget_used"] == sum(e.cache_stats()["bytes"] for e in engs) and st["forgotten"] == dropped and st["evictions"] == 0
+    oa2 = n.forward_many(a, [(2.5, 2.5)] * 6)            # re-captured
+    ob2 = n.forward_many(b, [(3.0, 2.0)] * 6)            # still resident
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(oa, oa2)) and all(torch.equal(x, y) for x, y in zip(ob, ob2))
