@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAVSR_ABI_VERSION 27
+#define SAVSR_ABI_VERSION 28
 
 #define SAVSR_E_ARG   (-1)   /* bad shape / null pointer / unsupported combination */
 #define SAVSR_E_ALIGN (-2)   /* pointer or stride alignment requirement violated  */
@@ -106,7 +106,8 @@ typedef struct savsr_conv_desc {
                                           row t (t < savsr_conv_pool_blocks(h, w)) = channel sums of pixel tile t,
                                           written at pool[t * pool_stride + co]; consumers add rows in order */
     int32_t      pool_stride;
-    int32_t      algo;                 /* SAVSR_CONV_DIRECT, SAVSR_CONV_DIRECT_THROUGHPUT (tiling only; same results) or SAVSR_CONV_WINOGRAD_Y */
+    int32_t      algo;                 /* SAVSR_CONV_DIRECT, SAVSR_CONV_DIRECT_THROUGHPUT (tiling only; same results), SAVSR_CONV_WINOGRAD_Y or
+                                          SAVSR_CONV_WINOGRAD_Y_THROUGHPUT (tiling only; same results as WINOGRAD_Y) */
 } savsr_conv_desc;
 
 #define SAVSR_CONV_DIRECT   0
@@ -119,6 +120,13 @@ typedef struct savsr_conv_desc {
                                             matrix work; conv_wy.hip).  `wpacked` must then be the Winograd-y image (savsr_conv_wy_pack_index):
                                             U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 over the tap ROWS g_ky, per kx.
                                             Results differ from DIRECT by rounding only (max-abs error ~1.5 x DIRECT's) */
+#define SAVSR_CONV_WINOGRAD_Y_THROUGHPUT 4   /* (ABI 28) WINOGRAD_Y for launches with other streams' launches in flight beside them.  The form's
+                                            workgroups walk 16-row tiles; when h % 16 leaves at most 8 rows, those rows can go as STRIP tiles
+                                            (their 1 / 2 / 4 row pairs side by side over 8 / 4 / 2 column segments per workgroup instead of
+                                            one tile per segment with idle waves: 113 instead of 120 tiles per conv and 64 channels at 180
+                                            rows).  WINOGRAD_Y takes strips when they save the persistent grid a round of tiles (what a
+                                            launch running alone pays for); _THROUGHPUT also whenever at most 2 row pairs are left (the tile
+                                            count decides when another launch fills the tail).  Results are bit-identical to WINOGRAD_Y. */
 
 /* Elements PER PART (hi or lo) of the weight image of a (cout, cin, ksize) conv; the bf16 image
  * holds 2x that many 2-byte elements.  -1 for unsupported shapes. */

@@ -18,8 +18,9 @@ MAX_SRC = 5
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 SATU_LRCAT = 160
 SATU_TABLE = 8
-ABI_VERSION = 27
-CONV_DIRECT, CONV_DIRECT_THROUGHPUT, CONV_WINOGRAD_Y = 0, 2, 3
+ABI_VERSION = 28
+CONV_DIRECT, CONV_DIRECT_THROUGHPUT, CONV_WINOGRAD_Y, CONV_WINOGRAD_Y_THROUGHPUT = 0, 2, 3, 4
+CONV_WY_FORMS = (CONV_WINOGRAD_Y, CONV_WINOGRAD_Y_THROUGHPUT)
 SATU_LRCAT_TAIL = 96
 TAIL_PLANES = 27
 

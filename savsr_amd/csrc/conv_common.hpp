@@ -35,10 +35,14 @@ constexpr int CONV_WIDE_MIN_TILES_TP = 100;    // ... or this many in throughput
 #define SAVSR_CONV_BLOCKS 256
 #endif
 constexpr int CONV_PERSISTENT_BLOCKS = SAVSR_CONV_BLOCKS;   // one resident workgroup per CU (117-154 KB of LDS each)
+#ifndef WY_STRIP
+#define WY_STRIP 1                // Winograd-y form: the image's last h % 16 <= 8 rows as strip tiles (conv_wy.hip) where that saves the grid a round of tiles; 0: full tiles only; 2: strips always
+#endif
 struct MultiConvParams {
     ConvParams c[CONV_MAX_BATCH];     // convs of identical geometry:
     int h, w, cout, nchunk, src_ch;   //   shared shape (fixed kernarg offsets: read once, not per tile)
     int nconv, ncob, ntx, nty;        // tile id = ((conv * ncob + cob) * nty + ty) * ntx + tx
+    int wy_tiles, wy_full, wy_strip_l2;   // Winograd-y form: tiles per (conv, cob) = wy_full full tiles (ty * ntx + tx) + strip tiles over the image's last rows, each 2^wy_strip_l2 row pairs x (8 >> wy_strip_l2) segments (conv_wy.hip)
 };
 
 int launch_conv_wy(const MultiConvParams& mp, hipStream_t st);      // conv_wy.hip: the Winograd F(2,3)-along-y form (3x3, cout % 64 == 0)

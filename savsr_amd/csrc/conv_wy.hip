@@ -105,21 +105,35 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
     bf16x8* smem = reinterpret_cast<bf16x8*>(smem_raw);       // [8 waves][V_WAVE] | [2][W_HALF] | epilogue slices
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    const int tiles_per_cob = mp.ntx * mp.nty;
+    const int tiles_per_cob = mp.wy_tiles;
     const int total = mp.nconv * mp.ncob * tiles_per_cob;
     const int H = mp.h, W = mp.w;
 
-    struct TileInfo { int conv, cob, x0, y0, tx, ty; };
+    // A tile is 8 wave tasks, each a (row pair, 32-pixel segment) of the image with everything but the weight slab private to its wave.  Full tiles
+    // stack the 8 row pairs of 16 image rows over ONE segment.  When H % 16 leaves at most 8 rows, the image's last rows are walked by STRIP tiles
+    // (round 6): the 2^l row pairs the strip needs, side by side over 8 >> l segments -- at 180 rows 3 strip tiles instead of 10 tiles whose waves
+    // 2 .. 7 stage zeros and skip their matrix work (113 instead of 120 tiles per conv and channel block).  Every wave task computes what it computed
+    // in a full tile: results bit for bit.  All of this is scalar arithmetic on wave_s and kernel arguments.
+    struct TileInfo { int conv, cob, x0, y0, tx, ty, strip; };      // x0: this WAVE's segment; y0 + 2 wave_s: this wave's first row (>= H: no task); tx: the tile's first segment
     auto decode = [&](int tile) {
-        const int cc = tile / tiles_per_cob, rem = tile - cc * tiles_per_cob;
-        const int ty = rem / mp.ntx, tx = rem - ty * mp.ntx;
+        // (unsigned divisions: a signed one by a loop-invariant divisor keeps the divisor's magnitude and sign beside its reciprocal in scalar registers)
+        const int cc = (int)((unsigned)tile / (unsigned)tiles_per_cob), rem = tile - cc * tiles_per_cob;
+        const bool strip = rem >= mp.wy_full;
+        const int tyf = (int)((unsigned)rem / (unsigned)mp.ntx);
+        const int l2 = strip ? mp.wy_strip_l2 : 3;
+        const int ty = strip ? mp.nty - 1 : tyf;
+        const int tx = strip ? (rem - mp.wy_full) << (3 - l2) : rem - tyf * mp.ntx;
+        const int wx = tx + (wave_s >> l2);
         TileInfo ti;
-        ti.conv = cc / mp.ncob;
+        ti.conv = (int)((unsigned)cc / (unsigned)mp.ncob);
         ti.cob = cc - ti.conv * mp.ncob;
-        ti.x0 = tx * TW;
-        ti.y0 = ty * TH;
+        ti.x0 = (wx < mp.ntx ? wx : tx) * TW;
+        // (the wave's first row as y0 + 2 wave_s, y0 = the tile's row less the row pairs of the segments to the wave's left: hipcc folds the 2 wave_s
+        // term into per-lane constants as it did with full tiles only; a masked wave index in its place cost 11 spilled vector registers)
+        ti.y0 = wx < mp.ntx ? ty * TH - 2 * ((wave_s >> l2) << l2) : mp.nty * TH;
         ti.tx = tx;
         ti.ty = ty;
+        ti.strip = strip ? 1 : 0;
         return ti;
     };
 
@@ -642,13 +656,18 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
 #pragma unroll
                     for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4*>(pl_ + (wave * 2 + r) * COT + 32 * t + 4 * lane) = psum[r][t];
             __syncthreads();
-            if (tid < 2 * COT) {
-                const int bl = tid / COT, ch = tid - bl * COT;
+            // full tile: two bands (waves 4 bl .. 4 bl + 3) of one segment; strip tile: one band, 8 >> l segments of 2^l waves each.  The rows of a
+            // (band, segment) are summed in the same order either way (rows below the image contribute +0 in a full tile, nothing in a strip)
+            const TileInfo pt = decode(tile);           // (tx / ty / strip again, from the tile index: not kept in scalar registers across the tile)
+            const int l2p = pt.strip ? mp.wy_strip_l2 : 2;
+            if (tid < (8 >> l2p) * COT) {
+                const int sg = tid / COT, ch = tid - sg * COT;          // (wave-uniform: COT = 64)
                 float sacc = 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) sacc += pl_[(bl * 8 + k) * COT + ch];       // waves 4 bl .. 4 bl + 3, rows r = 0, 1 each
-                const int band = cur.ty * 2 + bl;
-                if (band * 8 < H) stg1(e_pool, (unsigned)((band * mp.ntx + cur.tx) * p.pool_stride + cob * COT + ch), sacc);
+                for (int k = 0; k < 8; ++k)
+                    if (k < (2 << l2p)) sacc += pl_[(((sg << l2p) * 2) + k) * COT + ch];       // waves sg 2^l .. (sg + 1) 2^l - 1, rows r = 0, 1 each
+                const int band = pt.ty * 2 + (pt.strip ? 0 : sg), ptx = pt.tx + (pt.strip ? sg : 0);
+                if (band * 8 < H && ptx < mp.ntx) stg1(e_pool, (unsigned)((band * mp.ntx + ptx) * p.pool_stride + cob * COT + ch), sacc);
             }
             __syncthreads();                         // the slices are reused by the next tile's epilogue
         }
@@ -664,7 +683,7 @@ __global__ __launch_bounds__(512) void conv_wy_kernel(const MultiConvParams mp) 
 
 int launch_conv_wy(const MultiConvParams& mp, hipStream_t st) {
     if (int rc = conv_wy_prepare_device()) return rc;
-    const int total = mp.nconv * mp.ncob * mp.ntx * mp.nty;
+    const int total = mp.nconv * mp.ncob * mp.wy_tiles;
     const int grid = total < CONV_PERSISTENT_BLOCKS ? total : CONV_PERSISTENT_BLOCKS;
     bool fast = WY_FAST_EPILOGUE != 0;
     for (int i = 0; i < mp.nconv && fast; ++i) {

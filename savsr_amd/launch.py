@@ -118,6 +118,10 @@ class Launcher:
         n._wy = getattr(d, "_wy", None)
         return n
 
+    def _wy_algo(self) -> int:
+        """The Winograd-y form's algo value of the current flow (tiling of the image's last rows only: same bits)."""
+        return _lib.CONV_WINOGRAD_Y_THROUGHPUT if self.conv_algo == _lib.CONV_DIRECT_THROUGHPUT else _lib.CONV_WINOGRAD_Y
+
     def conv_launch(self, descs: List[ConvDesc], label: str = "conv"):
         """Independent convs of identical geometry, up to 6 per launch and clip (savsr_conv2d_batch; x nb clips of a batched launch sequence)."""
         st = self._stream()
@@ -136,7 +140,7 @@ class Launcher:
                 tiles = per_clip * self.form_nb * (d0.cout // 64) * ((d0.h + 15) // 16) * ((d0.w + 31) // 32)
                 if tiles >= (self.wy_min_tiles_tp if d0.algo == _lib.CONV_DIRECT_THROUGHPUT else self.wy_min_tiles):
                     for c in chunk:
-                        c.wpacked, c.algo = c._wy, _lib.CONV_WINOGRAD_Y
+                        c.wpacked, c.algo = c._wy, self._wy_algo()
             if self.census is not None:      # diagnostics (bench.py): matrix work of this launch, by the form it takes
                 self._count_conv(chunk)
             arr = (ConvDesc * len(chunk))(*chunk)
@@ -155,7 +159,7 @@ class Launcher:
             alg = 2.0 * d.h * d.w * d.cin * d.cout * taps
             cot = 64 if d.cout > 32 else 32
             px = (2 * ((d.h + 1) // 2) if d.ksize == 3 else d.h) * (32 * ((d.w + 31) // 32))
-            wy = int(d.algo) == _lib.CONV_WINOGRAD_Y
+            wy = int(d.algo) in _lib.CONV_WY_FORMS
             issued = 2.0 * px * d.cin * (cot * ((d.cout + cot - 1) // cot)) * taps * (2.0 if wy else 3.0)
             for k, v in (("alg_" + mode, alg), ("issued_" + mode, issued), ("direct_eq_" + mode, 3.0 * alg), ("wy_alg_" + mode, alg if wy else 0.0)):
                 c[k] = c.get(k, 0.0) + v
@@ -233,7 +237,7 @@ class Launcher:
                 chunk = clips
             arr = (OSConvAttnDesc * len(chunk))(*chunk)
             _lib.check(self.lib.savsr_osconv_weights_batch(arr, len(chunk), st), f"savsr_osconv_weights_batch[{keys[i]}]")
-        return [(self.osc[k]["wdyn_wy"], None, self.osc[k]["cout"], self.osc[k]["cin"], 3, _lib.CONV_WINOGRAD_Y) if dsc.wy else
+        return [(self.osc[k]["wdyn_wy"], None, self.osc[k]["cout"], self.osc[k]["cin"], 3, self._wy_algo()) if dsc.wy else
                 (self.osc[k]["wdyn"], None, self.osc[k]["cout"], self.osc[k]["cin"], 3) for k, dsc in zip(keys, descs)]
 
     def osconv_weights(self, key: str, srcs: List[Src], h: int, w: int, scale, pooled: bool = False, wy: bool = False):

@@ -147,17 +147,23 @@ def test_conv2d_winograd_y(eng, cin, cout, nsrc, h, w):
     assert errs[0] < 3e-5          # measured 1.0 - 2.3e-5 (direct: 0.8 - 1.8e-5) on outputs of magnitude ~4
 
 
-def test_conv2d_winograd_y_batch_and_pool(eng):
-    """A savsr_conv2d_batch of Winograd-y convs on a ragged image (90 x 330: partial last band and column, rows below the image):
-    each conv vs F.conv2d, bit-identical -- outputs AND fused pool rows -- to the same convs launched one by one, re-run bitwise
-    stable, and the pool rows sum to the output's channel means."""
+@pytest.mark.parametrize("h,w", [(90, 330), (36, 330), (23, 100), (34, 290), (8, 70), (4, 70), (180, 320), (22, 33), (24, 1280), (8, 4128)])
+def test_conv2d_winograd_y_batch_and_pool(eng, h, w):
+    """A savsr_conv2d_batch of Winograd-y convs on ragged images (90 x 330: partial last band and column, rows below the image; the others end
+    in STRIP tiles in at least one of the launches -- the last h % 16 <= 8 rows walked as 1 / 2 / 4 row pairs x 8 / 4 / 2 segments per workgroup:
+    with WINOGRAD_Y_THROUGHPUT whenever <= 2 row pairs are left, with either algo when that saves the grid a round of tiles (24 x 1280 and
+    8 x 4128: 4 row pairs, in the batch but not in the single launches) -- with segment slots beyond the image's last column (36 x 330: 11
+    segments in strips of 4; 34 x 290: 10 in strips of 8), images that are strips only (4 x 70, 8 x 4128) and the headline's 180 x 320): each
+    conv vs F.conv2d, bit-identical -- outputs AND fused pool rows -- to the same convs launched one by one and to the batch with algo
+    WINOGRAD_Y, re-run bitwise stable, the pool rows sum to the output's channel means and equal the direct kernel's pool rows."""
     from savsr_amd import engine as E
     from savsr_amd import _lib
     from savsr_amd._lib import ACT_LRELU
     g = np.random.RandomState(78)
-    h, w, cin, cout, n = 90, 330, 128, 64, 4
+    cin, cout, n = 128, 64, 4 if h * w < 40000 else 2
     rows = eng.pool_rows(h, w)
     xs, descs, singles, outs, outs1, parts, parts1, refs = [], [], [], [], [], [], [], []
+    descs2, outs2, parts2 = [], [], []
     for k in range(n):
         wt = torch.from_numpy((g.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
         bias = torch.from_numpy(g.standard_normal(cout).astype(np.float32))
@@ -166,15 +172,17 @@ def test_conv2d_winograd_y_batch_and_pool(eng):
         refs.append(F.leaky_relu(F.conv2d(x[None], wt, bias, padding=1), 0.2)[0] + res)
         xall, rcl = cl(x), cl(res)
         srcs = [eng.full(xall, 64, 0), eng.full(xall, 64, 64)]
-        weights = (_dev(E.pack_conv_weight_wy(wt)), _dev(bias), cout, cin, 3, _lib.CONV_WINOGRAD_Y)
+        weights = (_dev(E.pack_conv_weight_wy(wt)), _dev(bias), cout, cin, 3, _lib.CONV_WINOGRAD_Y_THROUGHPUT)
+        weights_lat = weights[:5] + (_lib.CONV_WINOGRAD_Y,)
         xs.append((xall, rcl, weights))
-        for outl, partl, dl in ((outs, parts, descs), (outs1, parts1, singles)):
+        for outl, partl, dl, wts in ((outs, parts, descs, weights), (outs1, parts1, singles, weights), (outs2, parts2, descs2, weights_lat)):
             o = torch.full((h, w, cout), float("nan"), device="cuda:0")
             pt = torch.full((rows, cout), float("nan"), device="cuda:0")
             outl.append(o)
             partl.append(pt)
-            dl.append(eng.conv_desc("t", srcs, eng.full(o), h, w, ACT_LRELU, 0.2, res1=eng.full(rcl), weights=weights, pool=(pt, 0, cout)))
+            dl.append(eng.conv_desc("t", srcs, eng.full(o), h, w, ACT_LRELU, 0.2, res1=eng.full(rcl), weights=wts, pool=(pt, 0, cout)))
     eng.conv_launch(descs)
+    eng.conv_launch(descs2)
     for d in singles:
         eng.conv_launch([d])
     torch.cuda.synchronize()
@@ -183,10 +191,20 @@ def test_conv2d_winograd_y_batch_and_pool(eng):
         eng.conv_launch(descs)
     torch.cuda.synchronize()
     for k in range(n):
-        assert _maxerr(pl(outs[k]), refs[k]) < 3e-5
-        assert torch.equal(outs[k], outs1[k]) and torch.equal(outs[k], first[k])
-        assert torch.equal(parts[k], parts1[k])
+        assert torch.equal(outs[k], outs1[k]) and torch.equal(outs[k], first[k]) and torch.equal(outs[k], outs2[k])
+        assert _maxerr(pl(outs[k]), refs[k]) < 3.5e-5          # (the maximum over 2-4 M outputs of magnitude ~4 per conv: 2.3 - 3.0e-5; 1.0 - 2.3e-5 on the small shapes above)
+        assert torch.equal(parts[k], parts1[k]) and torch.equal(parts[k], parts2[k])
         assert _maxerr(parts[k].sum(0).cpu() / (h * w), refs[k].mean(dim=(1, 2))) < 2e-5
+    # the pool rows one by one: the direct kernel writes the same (8-row band, 32-pixel segment) rows
+    xall, rcl, weights = xs[0]
+    wt_direct = torch.from_numpy((np.random.RandomState(78).standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
+    o = torch.full((h, w, cout), float("nan"), device="cuda:0")
+    pt = torch.full((rows, cout), float("nan"), device="cuda:0")
+    eng.conv("t", [eng.full(xall, 64, 0), eng.full(xall, 64, 64)], eng.full(o), h, w, ACT_LRELU, 0.2, res1=eng.full(rcl),
+             weights=(_dev(E.pack_conv_weight(wt_direct)), weights[1], cout, cin, 3), pool=(pt, 0, cout))
+    torch.cuda.synchronize()
+    assert _maxerr(o, outs[0]) < 5e-5
+    assert _maxerr(pt, parts[0]) < 5e-3          # sums of <= 256 outputs of magnitude ~4
 
 
 def test_conv2d_rejects_bad_args(eng):

@@ -70,7 +70,7 @@ def main():
             outs.append(out)
             descs.append(eng.conv_desc("bench", [eng.full(x) for x in xs], eng.full(out), h, w, ACT_LRELU, 0.2, res1=eng.full(res), weights=weights))
             if a.wy:
-                wy = (E.pack_conv_weight_wy(wt).to(dev), weights[1], cout, cin, 3, _lib.CONV_WINOGRAD_Y)
+                wy = (E.pack_conv_weight_wy(wt).to(dev), weights[1], cout, cin, 3, _lib.CONV_WINOGRAD_Y_THROUGHPUT if a.throughput else _lib.CONV_WINOGRAD_Y)
                 keep.append(wy)
                 descs_wy.append(eng.conv_desc("bench", [eng.full(x) for x in xs], eng.full(out), h, w, ACT_LRELU, 0.2, res1=eng.full(res), weights=wy))
         arr0 = (ConvDesc * nb)(*descs)
