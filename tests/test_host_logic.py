@@ -38,6 +38,19 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.savsr_version()
 
 
+def test_header_constants_match_the_binding():
+    """The enumerations the ctypes binding carries are the header's (`#define SAVSR_...`): conv forms, ABI number."""
+    hdr = open(os.path.join(ROOT, "include", "savsr_hip.h")).read()
+    defs = {k: int(v) for k, v in re.findall(r"#define\s+(SAVSR_[A-Z0-9_]+)\s+(-?\d+)\b", hdr)}
+    assert defs["SAVSR_ABI_VERSION"] == _lib.ABI_VERSION
+    for name in ("CONV_DIRECT", "CONV_DIRECT_THROUGHPUT", "CONV_WINOGRAD_Y", "CONV_WINOGRAD_Y_THROUGHPUT"):
+        assert defs["SAVSR_" + name] == getattr(_lib, name), name
+    assert set(_lib.CONV_WY_FORMS) == {defs["SAVSR_CONV_WINOGRAD_Y"], defs["SAVSR_CONV_WINOGRAD_Y_THROUGHPUT"]}
+    for name, val in defs.items():                      # activations, where the binding names them
+        if name.startswith("SAVSR_ACT_") and hasattr(_lib, name[6:]):
+            assert getattr(_lib, name[6:]) == val, name
+
+
 def test_every_entry_point_has_a_row_in_integration_md():
     """INTEGRATION.md shows the reference-side binding: every product entry point of the header is named there beside what it replaces."""
     hdr = open(os.path.join(ROOT, "include", "savsr_hip.h")).read()
