@@ -147,6 +147,10 @@ int savsr_conv2d(const savsr_conv_desc* d, void* stream);
  * clips of one (shape, scale) whose launch sequences the caller runs as one (small clips are launch-latency-bound).  More workgroups than CUs, so workgroups run out of phase and the
  * load/store bursts of one overlap the MFMA phases of another. */
 int savsr_conv2d_max_batch(void);
+/* (ABI 28) Workgroup tiles a savsr_conv2d_batch launch of `nconv` convs walks in the Winograd-y form with `algo` (SAVSR_CONV_WINOGRAD_Y or
+ * _THROUGHPUT): nconv x cout / 64 x (16-row x 32-px tiles, the image's last h % 16 <= 8 rows as strip tiles where the algo's rule takes
+ * them).  Host arithmetic only -- the plan the launcher applies; -1 for shapes the form does not take. */
+int64_t savsr_conv_wy_tile_count(int h, int w, int cout, int nconv, int algo);
 int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -79,6 +79,7 @@ class SatuTiling(C.Structure):
 SIGNATURES = {
     "savsr_version": (C.c_char_p, []),
     "savsr_conv2d_max_batch": (C.c_int, []),
+    "savsr_conv_wy_tile_count": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "savsr_osconv_weights_max_batch": (C.c_int, []),
     "savsr_conv_wy_packed_elems": (C.c_int64, [C.c_int, C.c_int]),
     "savsr_conv_wy_pack_index": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

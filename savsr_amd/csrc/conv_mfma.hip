@@ -931,6 +931,41 @@ static int fill_params(const savsr_conv_desc* d, ConvParams& p) {
     return 0;
 }
 
+// Tiles of the Winograd-y form per (conv, channel block): mp.ntx / mp.nty set by the caller (16-row tiles); `per` = convs x channel blocks of the launch.
+// The last h % 16 rows: up to 8 of them can go as strip tiles (their 1 / 2 / 4 row pairs side by side over 8 / 4 / 2 segments per workgroup).
+static void wy_tile_plan(int h, int per, int algo, MultiConvParams& mp) {
+    const int left = h % 16, pairs = (left + 1) / 2;
+    mp.wy_strip_l2 = pairs <= 1 ? 0 : (pairs <= 2 ? 1 : 2);
+    mp.wy_full = mp.wy_tiles = mp.ntx * mp.nty;
+    if (WY_STRIP && left > 0 && left <= 8) {
+        // Strips when they save the persistent grid a ROUND of tiles -- what a launch running ALONE pays for: a last-row tile of the full form is
+        // cheap (its idle waves leave the matrix pipe to the others), a strip tile costs a full tile, and with the rounds equal the full form is
+        // the faster one (6 x 128->64 at 180x320: 720 / 678 tiles, 3 rounds both, 126.1 against 129.1 us; 24 x 64->64: 12 -> 11 rounds, 366.8 ->
+        // 352.9 us; one-clip-at-a-time config 3 with strips in every launch: -0.9 %).  WINOGRAD_Y_THROUGHPUT -- another stream's launch fills
+        // the tail, the tile count decides -- also whenever at most 2 row pairs are left (>= 6 of a last-row tile's 8 waves idle: 10 such tiles
+        // become 3 or 2): bench line +1.5 ... +1.7 % against +1.0 % by rounds only.  Same bits either way.
+        const int segs = 8 >> mp.wy_strip_l2;
+        const int full = mp.ntx * (mp.nty - 1), tiles = full + (mp.ntx + segs - 1) / segs;
+        const int wgs = CONV_PERSISTENT_BLOCKS;
+        if (WY_STRIP == 2 || (pairs <= 2 && algo == SAVSR_CONV_WINOGRAD_Y_THROUGHPUT) || (per * tiles + wgs - 1) / wgs < (per * mp.wy_tiles + wgs - 1) / wgs) {
+            mp.wy_full = full;
+            mp.wy_tiles = tiles;
+        }
+    }
+}
+
+// Workgroup tiles of a savsr_conv2d_batch launch in the Winograd-y form (host arithmetic only: the plan the launcher applies).
+extern "C" int64_t savsr_conv_wy_tile_count(int h, int w, int cout, int nconv, int algo) {
+    if (h < 1 || w < 1 || cout < 64 || cout % 64 || nconv < 1 || nconv > CONV_MAX_BATCH ||
+        (algo != SAVSR_CONV_WINOGRAD_Y && algo != SAVSR_CONV_WINOGRAD_Y_THROUGHPUT)) return -1;
+    MultiConvParams mp;
+    mp.ncob = cout / 64;
+    mp.ntx = (w + CONV_TW - 1) / CONV_TW;
+    mp.nty = (h + 15) / 16;
+    wy_tile_plan(h, nconv * mp.ncob, algo, mp);
+    return (int64_t)nconv * mp.ncob * mp.wy_tiles;
+}
+
 extern "C" int savsr_conv2d_max_batch(void) { return CONV_MAX_BATCH; }
 
 extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* stream) {
@@ -960,25 +995,7 @@ extern "C" int savsr_conv2d_batch(const savsr_conv_desc* descs, int n, void* str
         // wpacked is the Winograd-y image (savsr_conv_wy_pack_index); one kernel, 16-row tiles, whatever the launch size
         if (d->ksize != 3 || d->cout % 64) return fail_arg("conv: algo WINOGRAD_Y needs ksize 3 and cout a multiple of 64");
         mp.nty = (d->h + 15) / 16;
-        // the last h % 16 rows: up to 8 of them go as strip tiles (their 1 / 2 / 4 row pairs side by side over 8 / 4 / 2 segments per workgroup)
-        const int left = d->h % 16, pairs = (left + 1) / 2;
-        mp.wy_strip_l2 = pairs <= 1 ? 0 : (pairs <= 2 ? 1 : 2);
-        mp.wy_full = mp.wy_tiles = mp.ntx * mp.nty;
-        if (WY_STRIP && left > 0 && left <= 8) {
-            // Strips when they save the persistent grid a ROUND of tiles -- what a launch running ALONE pays for: a last-row tile of the full form is
-            // cheap (its idle waves leave the matrix pipe to the others), a strip tile costs a full tile, and with the rounds equal the full form is
-            // the faster one (6 x 128->64 at 180x320: 720 / 678 tiles, 3 rounds both, 126.1 against 129.1 us; 24 x 64->64: 12 -> 11 rounds, 366.8 ->
-            // 352.9 us; one-clip-at-a-time config 3 with strips in every launch: -0.9 %).  WINOGRAD_Y_THROUGHPUT -- another stream's launch fills
-            // the tail, the tile count decides -- also whenever at most 2 row pairs are left (>= 6 of a last-row tile's 8 waves idle: 10 such tiles
-            // become 3 or 2): bench line +1.5 ... +1.7 % against +1.0 % by rounds only.  Same bits either way.
-            const int segs = 8 >> mp.wy_strip_l2;
-            const int full = mp.ntx * (mp.nty - 1), tiles = full + (mp.ntx + segs - 1) / segs;
-            const int per = n * mp.ncob, wgs = CONV_PERSISTENT_BLOCKS;
-            if (WY_STRIP == 2 || (pairs <= 2 && d->algo == SAVSR_CONV_WINOGRAD_Y_THROUGHPUT) || (per * tiles + wgs - 1) / wgs < (per * mp.wy_tiles + wgs - 1) / wgs) {
-                mp.wy_full = full;
-                mp.wy_tiles = tiles;
-            }
-        }
+        wy_tile_plan(d->h, n * mp.ncob, d->algo, mp);
         return launch_conv_wy(mp, st);
     }
     if (d->algo != SAVSR_CONV_DIRECT && d->algo != SAVSR_CONV_DIRECT_THROUGHPUT) return fail_arg("conv: unknown algo");

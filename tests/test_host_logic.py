@@ -51,6 +51,47 @@ def test_header_constants_match_the_binding():
             assert getattr(_lib, name[6:]) == val, name
 
 
+def test_winograd_y_strip_tile_plan():
+    """savsr_conv_wy_tile_count: the launcher's tile plan for the image's last rows (conv_mfma.hip `wy_tile_plan`).  Full tiles = 16 rows x 32 px;
+    when h % 16 leaves <= 8 rows they can go as strips of 2^l row pairs x (8 >> l) segments.  WINOGRAD_Y takes strips when they save the grid of
+    256 persistent workgroups a round of tiles, WINOGRAD_Y_THROUGHPUT also whenever <= 2 row pairs are left."""
+    lib = _lib.load()
+    WY, TP = _lib.CONV_WINOGRAD_Y, _lib.CONV_WINOGRAD_Y_THROUGHPUT
+
+    def plan(h, w, nconv, algo, cout=64):
+        ntx, nty, ncob = -(-w // 32), -(-h // 16), cout // 64
+        full = ntx * nty
+        left = h % 16
+        pairs = (left + 1) // 2
+        tiles = full
+        if 0 < left <= 8:
+            l2 = 0 if pairs <= 1 else (1 if pairs <= 2 else 2)
+            strips = ntx * (nty - 1) + -(-ntx // (8 >> l2))
+            per = nconv * ncob
+            if (pairs <= 2 and algo == TP) or -(-per * strips // 256) < -(-per * full // 256):
+                tiles = strips
+        return nconv * ncob * tiles
+
+    assert lib.savsr_conv_wy_tile_count(180, 320, 64, 1, WY) == 120            # alone: one round either way -> full tiles
+    assert lib.savsr_conv_wy_tile_count(180, 320, 64, 1, TP) == 113            # 11 x 10 full tiles + 3 strips of 2 row pairs x 4 segments
+    assert lib.savsr_conv_wy_tile_count(180, 320, 64, 24, WY) == 24 * 113      # 12 -> 11 rounds
+    assert lib.savsr_conv_wy_tile_count(180, 320, 64, 6, WY) == 6 * 120        # 3 rounds both
+    assert lib.savsr_conv_wy_tile_count(120, 180, 64, 24, TP) == 24 * 48       # 4 row pairs left, 5 rounds both: full tiles
+    assert lib.savsr_conv_wy_tile_count(24, 1280, 64, 4, WY) == 4 * 60         # 320 -> 240 tiles: 2 rounds -> 1
+    assert lib.savsr_conv_wy_tile_count(4, 70, 64, 1, TP) == 1                 # strips only: 3 segments in one workgroup
+    assert lib.savsr_conv_wy_tile_count(16, 32, 128, 2, TP) == 4               # no rows left; two channel blocks
+    for bad in ((0, 32, 64, 1, WY), (16, 32, 32, 1, WY), (16, 32, 64, 25, WY), (16, 32, 64, 1, _lib.CONV_DIRECT)):
+        assert lib.savsr_conv_wy_tile_count(*bad) == -1
+    rng = np.random.RandomState(5)
+    for _ in range(2000):
+        h, w, n = int(rng.randint(1, 600)), int(rng.randint(1, 1400)), int(rng.randint(1, 25))
+        cout = 64 * int(rng.randint(1, 3))
+        for algo in (WY, TP):
+            got = lib.savsr_conv_wy_tile_count(h, w, cout, n, algo)
+            assert got == plan(h, w, n, algo, cout), (h, w, n, cout, algo, got)
+            assert got <= n * (cout // 64) * -(-w // 32) * -(-h // 16)           # never more tiles than the full form
+
+
 def test_every_entry_point_has_a_row_in_integration_md():
     """INTEGRATION.md shows the reference-side binding: every product entry point of the header is named there beside what it replaces."""
     hdr = open(os.path.join(ROOT, "include", "savsr_hip.h")).read()
