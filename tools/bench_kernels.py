@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--stamps", action="store_true", help="conv / satu: print per-workgroup section timings (s_memtime); needs the instrumented library: SAVSR_DIAG=1 bash savsr_amd/csrc/build.sh, SAVSR_LIB_PATH=savsr_amd/csrc/libsavsr_hip_diag.so")
     ap.add_argument("--distinct", action="store_true", help="conv: every conv of the batch gets its own inputs and weights")
     ap.add_argument("--wy", action="store_true", help="conv (3x3, cout % 64 == 0): the Winograd-y form (SAVSR_CONV_WINOGRAD_Y) instead of the direct kernel")
+    ap.add_argument("--wy-tp", action="store_true", help="with --wy: algo SAVSR_CONV_WINOGRAD_Y_THROUGHPUT (strip tiles for the image's last rows whenever <= 2 row pairs are left)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     eng = E.HipEngine(synth.synth_state_dict(), SAVSR().cfg, dev)
@@ -41,7 +42,7 @@ def main():
         wt = torch.randn(a.cout, a.cin, a.ks, a.ks, generator=g) / (a.cin * a.ks * a.ks) ** 0.5
         bias = torch.randn(a.cout, generator=g).to(dev)
         from savsr_amd import _lib as L
-        mk = (lambda wt_: (E.pack_conv_weight_wy(wt_).to(dev), bias, a.cout, a.cin, a.ks, L.CONV_WINOGRAD_Y)) if a.wy else \
+        mk = (lambda wt_: (E.pack_conv_weight_wy(wt_).to(dev), bias, a.cout, a.cin, a.ks, L.CONV_WINOGRAD_Y_THROUGHPUT if a.wy_tp else L.CONV_WINOGRAD_Y)) if a.wy else \
             (lambda wt_: (E.pack_conv_weight(wt_).to(dev), bias, a.cout, a.cin, a.ks))
         nsrc = max(1, a.cin // 64)
         nset = a.batch if a.distinct else 1
