@@ -117,7 +117,7 @@ def test_conv2d_batch_wide_tiles(eng):
 
 @pytest.mark.parametrize("cin,cout,nsrc,h,w", [
     (64, 64, 1, 10, 12), (192, 64, 3, 9, 40), (128, 64, 2, 12, 33), (320, 128, 5, 8, 35), (16, 128, 1, 13, 31),
-    (128, 64, 1, 19, 11), (64, 64, 1, 50, 70), (128, 64, 2, 33, 65), (64, 64, 1, 1, 1), (64, 64, 1, 16, 32), (64, 64, 1, 17, 33)])
+    (128, 64, 1, 19, 11), (64, 64, 1, 50, 70), (128, 64, 2, 33, 65), (64, 64, 1, 1, 1), (64, 64, 1, 16, 32), (64, 64, 1, 17, 33), (64, 128, 1, 36, 300)])
 def test_conv2d_winograd_y(eng, cin, cout, nsrc, h, w):
     """SAVSR_CONV_WINOGRAD_Y (conv_wy.hip: F(2,3) along y on the split-bf16 matrix products) vs F.conv2d fp32 incl. the fused epilogue,
     same bound as the direct kernel (3e-5 absolute on outputs of magnitude ~4), and vs the direct kernel on the same inputs."""
@@ -135,14 +135,18 @@ def test_conv2d_winograd_y(eng, cin, cout, nsrc, h, w):
     sch = cin // nsrc
     xall = cl(x)
     srcs = [eng.full(xall, sch, i * sch) for i in range(nsrc)]
-    errs = []
-    for weights in ((_dev(E.pack_conv_weight_wy(wt)), _dev(bias), cout, cin, 3, _lib.CONV_WINOGRAD_Y), (_dev(E.pack_conv_weight(wt)), _dev(bias), cout, cin, 3)):
+    errs, kept = [], []
+    wy_img = _dev(E.pack_conv_weight_wy(wt))
+    for weights in ((wy_img, _dev(bias), cout, cin, 3, _lib.CONV_WINOGRAD_Y), (_dev(E.pack_conv_weight(wt)), _dev(bias), cout, cin, 3),
+                    (wy_img, _dev(bias), cout, cin, 3, _lib.CONV_WINOGRAD_Y_THROUGHPUT)):
         wide = torch.full((h, w, cout + 4), float("nan"), device="cuda:0")
         out = E.Src(wide, cout, cout + 4, 4)
         eng.conv("test", srcs, out, h, w, ACT_LRELU, 0.2, mul_px=_dev(mul), res1=eng.full(cl(res)), res2=eng.full(cl(res2)), res2_scale=0.9, weights=weights)
         torch.cuda.synchronize()
         assert bool(torch.isnan(wide[..., :4]).all())                        # nothing written outside the channel slice
         errs.append(float((pl(wide[..., 4:4 + cout]).double() - ref).abs().max()))
+        kept.append(wide)
+    assert torch.equal(kept[0][..., 4:], kept[2][..., 4:])                   # strip tiles for the last rows (generic epilogue: mask + second residual): same bits
     print('conv winograd-y', cin, cout, h, w, 'max-abs', errs[0], 'direct', errs[1])
     assert errs[0] < 3e-5          # measured 1.0 - 2.3e-5 (direct: 0.8 - 1.8e-5) on outputs of magnitude ~4
 
