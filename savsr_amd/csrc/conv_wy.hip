@@ -8,7 +8,8 @@
 //     M_i = sum_{kx, ci} U_i[co][ci][kx] * V_i[ci](x + kx - 1)                           (4 "positions" x 3 kx = 12 taps instead of 2 x 9)
 //     out(Y) = M0 + M1 + M2,  out(Y+1) = M1 - M2 - M3                                    (output transform, in registers)
 //
-// Why along y, and how it maps to a CU.  Workgroup = 8 waves = a 16-row x 32-pixel x 64-channel output tile; wave w owns the row
+// Why along y, and how it maps to a CU.  Workgroup = 8 waves = a 16-row x 32-pixel x 64-channel output tile (round 6: the image's
+// last h % 16 <= 8 rows can go as STRIP tiles -- 1 / 2 / 4 row pairs x 8 / 4 / 2 segments of 32 pixels; see `decode`); wave w owns the row
 // PAIR (2w, 2w+1), so its four transformed rows are built from its own four input rows and live in a WAVE-PRIVATE LDS region: no
 // activation is shared between waves (a Winograd form along x, or the 2-D form of round 2, shares transformed rows / needs its
 // weights per transform position in registers).  Only the weights are shared: per 16-channel phase the 12 taps are a 48 KB slab
