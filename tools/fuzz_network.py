@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--cases", type=int, default=24)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-side", type=int, default=40)
+    ap.add_argument("--throughput", action="store_true",
+                    help="the throughput flow on medium frames (33..200 x 64..352): two clips of one (shape, scale) through forward_many -- Winograd-y launches with "
+                         "strip tiles for the image's last rows wherever the launcher's rule takes them -- clip 0 against the oracle, repeat bitwise")
     a = ap.parse_args()
     rnd = random.Random(a.seed)
     sd = synth.synth_state_dict(seed=0)
@@ -31,7 +34,7 @@ def main():
     torch.set_num_threads(min(16, os.cpu_count() or 8))     # (the oracle's small convs crawl with one thread per core of a 128-core host: minutes per case)
     worst = 0.0
     for k in range(a.cases):
-        h, w = rnd.randint(4, a.max_side), rnd.randint(5, a.max_side)
+        h, w = (rnd.randint(33, 200), rnd.randint(64, 352)) if a.throughput else (rnd.randint(4, a.max_side), rnd.randint(5, a.max_side))
         kind = rnd.choice(["sym", "asym", "int", "frac"])
         if kind == "sym":
             s = round(rnd.uniform(1.05, 4.3), 2)
@@ -47,10 +50,18 @@ def main():
         with torch.no_grad():
             ref = O.forward(sd, lq, sc)
         net.set_scale(sc)
-        taps = {}
-        eager = net(lq.to("cuda:0"), taps=taps).cpu()
-        cap = net(lq.to("cuda:0")).cpu()
-        rep = net(lq.to("cuda:0")).cpu()
+        if a.throughput:
+            lq2 = synth.synth_clip(7, 3, h, w, seed=5000 + k)
+            items = [lq[0].to("cuda:0"), lq2[0].to("cuda:0")]
+            with torch.no_grad():
+                cap = net.forward_many(items, [sc, sc])[0][None].cpu()
+                rep = net.forward_many(items, [sc, sc])[0][None].cpu()
+                eager = net.forward_many(items[:1], [sc])[0][None].cpu()       # (a lone clip: same flow, same conv forms -> same bits)
+        else:
+            taps = {}
+            eager = net(lq.to("cuda:0"), taps=taps).cpu()
+            cap = net(lq.to("cuda:0")).cpu()
+            rep = net(lq.to("cuda:0")).cpu()
         err = float((cap - ref).abs().max())
         worst = max(worst, err)
         ok = tuple(cap.shape) == tuple(ref.shape) and err < 5e-5 and torch.equal(cap, rep) and torch.equal(cap, eager) and bool(torch.isfinite(cap).all())
