@@ -25,7 +25,7 @@ class EngineConfig:
     streams_large: int = 2                 # SAVSR_STREAMS_LARGE: ... when the LR frames of a call average at least `streams_large_px` pixels
     streams_large_px: int = 40000          # SAVSR_STREAMS_LARGE_PX
     clip_batch: int = 4                    # SAVSR_CLIP_BATCH: clips of one (shape, scale) per launch sequence (capped by the library's batch limits: 24 convs / 8 OSConvs per launch)
-    clip_batch_max_px: int = 200000        # SAVSR_CLIP_BATCH_MAX_PX: LR frames up to this many pixels share launch sequences (YAML workflow steady pass, one lease: 70 400 -> 154.6, 200 000 -> 158.2, 400 000 -> 158.0 frames/s)
+    clip_batch_max_px: int = 70400         # SAVSR_CLIP_BATCH_MAX_PX: LR frames up to this many pixels share launch sequences.  200 000 reads +2 % on the steady pass of bench.py's 6-scale job (154.6 -> 158.2 frames/s) but makes 5-7 GB contexts of the 300-340 x 450-510 frames of a shipped YAML's low scales: their first-touch allocation inside the capture costs 150-250 ms a context and the byte budget starts evicting -- a rank of eight holding such units: cold pass 12.8 -> 10.3 s, second pass 10.9 -> 8.9 s with 70 400 (profiles/r06_rank4_*.json)
     graphs: bool = True                    # SAVSR_GRAPHS: replay captured hipGraphs (0: issue every launch from Python -- diagnostics)
     capture_after: int = 0                 # SAVSR_CAPTURE_AFTER: a context's first n frames run eagerly, then the graphs are captured
     # ---- kernel forms ----------------------------------------------------------------------------------------------------------
@@ -58,7 +58,7 @@ class EngineConfig:
             streams_large=max(1, int(e("SAVSR_STREAMS_LARGE", e("SAVSR_STREAMS", "2")))),
             streams_large_px=int(e("SAVSR_STREAMS_LARGE_PX", "40000")),
             clip_batch=max(1, int(e("SAVSR_CLIP_BATCH", "4"))),
-            clip_batch_max_px=int(e("SAVSR_CLIP_BATCH_MAX_PX", "200000")),
+            clip_batch_max_px=int(e("SAVSR_CLIP_BATCH_MAX_PX", "70400")),
             graphs=_flag("SAVSR_GRAPHS", True),
             capture_after=max(0, int(e("SAVSR_CAPTURE_AFTER", "0"))),
             conv_wy=_flag("SAVSR_CONV_WY", True),
